@@ -1,0 +1,668 @@
+/*
+ * sl3d_oracle.c -- CPU restatement of the pranavkantgaur/3dscan hot path
+ *                  (stages 3, 4, 5, 7 and the output cast of stage 8).
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  It is the checker for the HIP path, never
+ * the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  Nothing under 3dscan_amd/ links or calls it.
+ *
+ * Parity status
+ *   stage 3 (wrapped phase)  : PINNED  by the reference's own known-answer image
+ *                              M_tech_project_console/Wrapped_phase_images/{Vertical,Horizontal}/Wrapped_phase_image.bmp
+ *   stage 4 (decode + unwrap): PINNED  by Unwrapped_phase_images/Gray_coded/{Vertical,Horizontal}/Unwrapped_phase_*.bmp
+ *   stage 5, 7, 8            : PARITY UNPINNED -- the artefacts that would pin them
+ *                              (c_p_map.xml, depth_map.xml, point_cloud_0.ply) are missing
+ *                              blobs of the reference tree and the reference has no tests.
+ *                              The five OpenCV 2.4.0 routines stage 7 calls (cvUndistortPoints,
+ *                              cvRodrigues2, cvGEMM, cvInvert, cvTranspose) are NOT in the
+ *                              reference tree (un-vendored dependency, opencv 2.4.0 per
+ *                              M_tech_project_console.cbp:55-58); they are restated here from
+ *                              their published algorithms.
+ *   (tests/golden/make_golden.py replays the two pinned stages on the full
+ *    1600x1200 captures and writes the committed crops under tests/golden/.)
+ *
+ * The reference cannot be compiled here (OpenCV 2.4 C API, PCL 1.6, gphoto2 are
+ * absent), so there is no oracle/_ref build.
+ *
+ * Conventions kept from the reference so the arithmetic is identical:
+ *   - `Pi` is the UNPARENTHESISED macro 22.0/7.0           (PROJECT_GLOBAL/global_cv.h:62)
+ *   - image-shaped state is laid out [col][row]            (PROJECT_GLOBAL/common_variables.h:12-21,56-62)
+ *   - loops run row-outer / col-inner over those arrays    (e.g. 3/wrapped_phase.cpp:165-166)
+ *   - float/double promotion and rounding points follow the C expressions of the
+ *     reference one for one; build with -O2 -ffp-contract=off (no FMA contraction).
+ *
+ * Every function cites the reference lines it follows (paths under /root/reference).
+ */
+#include <fenv.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define Pi 22.0/7.0 /* global_cv.h:62 -- textual macro, expands inside expressions */
+
+typedef struct {
+    int W, H;           /* Camera_imagewidth / Camera_imageheight        global_cv.h:49-50 */
+    int PW, PH;         /* Projector_imagewidth / Projector_imageheight  global_cv.h:52-53 */
+    int F;              /* number_of_patterns_fringe                     common_variables.h:10 */
+    int N_v, N_h;       /* number_of_patterns_binary_{vertical,horizontal} common_variables.h:8-9 */
+    int fw_v, fw_h;     /* fringe_width_pixels_{vertical,horizontal}     common_variables.h:23-24 */
+    int ncodes_v, ncodes_h; /* number_of_codes_* (debug image only)      common_variables.h:6-7 */
+    int exact_index;    /* 0: pixel row = floorf((float)f/(float)W) as 7/triangulation.cpp:264-265;
+                           1: integer row (needed above 2^24 pixels, where the reference is wrong) */
+    int col0, row0;     /* NOT in the reference: pixel-coordinate origin of this image inside a larger
+                           camera frame (crops / row stripes). Only T1's pixel coordinates use it;
+                           0,0 reproduces the reference exactly. */
+    int pcol0, prow0;   /* same for the projector table (always 0 in practice) */
+} orc_config;
+
+typedef struct {
+    orc_config c;
+    /* the reference's globals, all [col][row] i.e. index col*H+row */
+    int *selected_region;
+    int *valid_map_vertical, *valid_map_horizontal, *valid_map;
+    float *wrapped_phi_vertical, *wrapped_phi_horizontal;
+    float *unwrapped_phi_vertical, *unwrapped_phi_horizontal;
+    int *code_vertical, *code_horizontal;
+    long *c_p_map;                   /* [row*W+col][2] */
+    double *intersection_points;     /* [col][row][3] */
+    /* debug images (row-major, widthStep == W) used to replay the reference's KAT images */
+    unsigned char *wrapped_img[2];
+    unsigned char *unwrapped_img[2];
+    /* calibration (what the 8 XML files hold) */
+    double Kc[9], dc[5], rc[3], tc[3];
+    double Kp[9], dp[5], rp[3], tp[3];
+    /* stage 7 tables */
+    double *cam_undist_points_mat;   /* 3 x (W*H)  */
+    double *proj_undist_points_mat;  /* 3 x (PW*PH) */
+    double A_cam[12], A_proj[12];
+    int tables_ready;
+} orc_state;
+
+#define IDX(s, col, row) ((size_t)(col) * (size_t)(s)->c.H + (size_t)(row))
+
+/* ------------------------------------------------------------------------- */
+orc_state *orc_create(const orc_config *cfg)
+{
+    orc_state *s = (orc_state *)calloc(1, sizeof(orc_state));
+    if (!s) return NULL;
+    s->c = *cfg;
+    size_t n = (size_t)cfg->W * (size_t)cfg->H;
+    s->selected_region = (int *)calloc(n, sizeof(int));
+    s->valid_map_vertical = (int *)calloc(n, sizeof(int));
+    s->valid_map_horizontal = (int *)calloc(n, sizeof(int));
+    s->valid_map = (int *)calloc(n, sizeof(int));
+    /* The reference leaves these uninitialised (new[] without value-init); the
+       oracle defines them as zero so that comparisons are deterministic. */
+    s->wrapped_phi_vertical = (float *)calloc(n, sizeof(float));
+    s->wrapped_phi_horizontal = (float *)calloc(n, sizeof(float));
+    s->unwrapped_phi_vertical = (float *)calloc(n, sizeof(float));
+    s->unwrapped_phi_horizontal = (float *)calloc(n, sizeof(float));
+    s->code_vertical = (int *)calloc(n, sizeof(int));
+    s->code_horizontal = (int *)calloc(n, sizeof(int));
+    s->c_p_map = (long *)calloc(n * 2, sizeof(long));
+    s->intersection_points = (double *)calloc(n * 3, sizeof(double));
+    for (int a = 0; a < 2; a++) {
+        s->wrapped_img[a] = (unsigned char *)calloc(n, 1);
+        s->unwrapped_img[a] = (unsigned char *)calloc(n, 1);
+    }
+    return s;
+}
+
+void orc_destroy(orc_state *s)
+{
+    if (!s) return;
+    free(s->selected_region);
+    free(s->valid_map_vertical); free(s->valid_map_horizontal); free(s->valid_map);
+    free(s->wrapped_phi_vertical); free(s->wrapped_phi_horizontal);
+    free(s->unwrapped_phi_vertical); free(s->unwrapped_phi_horizontal);
+    free(s->code_vertical); free(s->code_horizontal);
+    free(s->c_p_map); free(s->intersection_points);
+    for (int a = 0; a < 2; a++) { free(s->wrapped_img[a]); free(s->unwrapped_img[a]); }
+    free(s->cam_undist_points_mat); free(s->proj_undist_points_mat);
+    free(s);
+}
+
+/* H0: the caller contract.  selected_region[col][row] in {0,1}
+   (m_tech_project_console.cpp:146-238); the mask plane is row-major u8, a pixel
+   is selected iff its byte == 1 (every consumer tests `==1`). */
+void orc_set_mask(orc_state *s, const unsigned char *mask, size_t stride)
+{
+    for (int row = 0; row < s->c.H; row++)
+        for (int col = 0; col < s->c.W; col++)
+            s->selected_region[IDX(s, col, row)] = (mask[(size_t)row * stride + col] == 1) ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Stage 3 -- 3/wrapped_phase.cpp                                            */
+/* ------------------------------------------------------------------------- */
+
+/* S3b: check_I_mod_criteria, 3/wrapped_phase.cpp:78-115 (modulation test is
+   commented out :84-104, so validity = selection). */
+static void check_I_mod_criteria(orc_state *s, int *valid_map_local)
+{
+    const int W = s->c.W, H = s->c.H;
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++)
+            valid_map_local[IDX(s, j, i)] = 0;
+    if (s->c.F == 4 || s->c.F == 3) {
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++)
+                if (s->selected_region[IDX(s, j, i)] == 1)
+                    valid_map_local[IDX(s, j, i)] = 1;
+    }
+    /* F==5: the block is commented out in the reference (:117-129) -> all invalid. */
+}
+
+#define PX(img, stride, row, col) ((unsigned char)(img)[(size_t)(row) * (stride) + (col)])
+
+/* S3c: create_wrapped_phase, 3/wrapped_phase.cpp:151-238. */
+static void create_wrapped_phase(orc_state *s, const unsigned char *const *g, size_t stride,
+                                 const int *valid_map_local, float *wrapped_phi,
+                                 unsigned char *wrapped_phase_image)
+{
+    const int W = s->c.W, H = s->c.H;
+    float t1 = 0.0, t2 = 0.0;
+    float t3 = 0.0;
+    memset(wrapped_phase_image, 0, (size_t)W * H); /* cvSet(...,0) :159 */
+
+    if (s->c.F == 3) { /* :162-185 */
+        for (int row_no = 0; row_no < H; row_no++)
+            for (int col_no = 0; col_no < W; col_no++) {
+                if (valid_map_local[IDX(s, col_no, row_no)] == 1) {
+                    t1 = (float)(PX(g[0], stride, row_no, col_no)) - (float)(PX(g[2], stride, row_no, col_no)); /* :171 */
+                    t2 = 2.0 * ((float)(PX(g[1], stride, row_no, col_no))) - (float)(PX(g[0], stride, row_no, col_no)) - (float)(PX(g[2], stride, row_no, col_no)); /* :172 */
+                    wrapped_phi[IDX(s, col_no, row_no)] = atan2(t1, t2); /* double atan2, rounded on store :175 */
+                    t3 = 128.0f + 127.0f * (wrapped_phi[IDX(s, col_no, row_no)] / (Pi)); /* :178 */
+                    wrapped_phase_image[(size_t)row_no * W + col_no] = (unsigned char)(t3); /* :179 */
+                }
+            }
+    }
+    if (s->c.F == 4) { /* :188-204 */
+        for (int h = 0; h < H; h++)
+            for (int w = 0; w < W; w++) {
+                if (valid_map_local[IDX(s, w, h)] == 1) {
+                    t1 = (float)(PX(g[3], stride, h, w)) - (float)(PX(g[1], stride, h, w)); /* :195 */
+                    t2 = (float)(PX(g[0], stride, h, w)) - (float)(PX(g[2], stride, h, w)); /* :196 */
+                    wrapped_phi[IDX(s, w, h)] = atan2(t1, t2); /* :198 */
+                    t3 = 127.0f + 128.0f * (wrapped_phi[IDX(s, w, h)] / (Pi)); /* :199 */
+                    wrapped_phase_image[(size_t)h * W + w] = (unsigned char)(t3);
+                }
+            }
+    }
+    if (s->c.F == 5) { /* :210-229 (Hariharan); unreachable through S3b, kept for completeness */
+        for (int h = 0; h < H; h++)
+            for (int w = 0; w < W; w++) {
+                if (valid_map_local[IDX(s, w, h)] == 1) {
+                    t1 = 2.0 * ((float)(PX(g[1], stride, h, w)) - (float)(PX(g[3], stride, h, w))); /* :217 */
+                    t2 = 2.0 * (float)(PX(g[2], stride, h, w)) - (float)(PX(g[0], stride, h, w)) - (float)(PX(g[4], stride, h, w)); /* :218 */
+                    wrapped_phi[IDX(s, w, h)] = atan2f(t1, t2); /* :220 */
+                    t3 = 127.0 + 128.0 * (wrapped_phi[IDX(s, w, h)] / (Pi)); /* :221 */
+                    wrapped_phase_image[(size_t)h * W + w] = (unsigned char)t3;
+                }
+            }
+    }
+}
+
+/* S3d: save_wrapped_image erosion, 3/wrapped_phase.cpp:250-279 (v) / :306-318 (h).
+   Followed literally, visited_pixel array included. */
+static void erode_valid_map(orc_state *s, int *valid_map_local, unsigned char *wrapped_phase_image)
+{
+    const int W = s->c.W, H = s->c.H;
+    unsigned char *visited_pixel = (unsigned char *)malloc((size_t)W * H);
+    for (int g = 0; g < 1; g++) {
+        memset(visited_pixel, 0, (size_t)W * H); /* :256-258 */
+#define VM(u, y) valid_map_local[IDX(s, (u), (y))]
+#define VS(u, y) visited_pixel[IDX(s, (u), (y))]
+        for (int y = 1; y < H - 1; y++)
+            for (int u = 1; u < W - 1; u++) {
+                if (((VM(u - 1, y - 1) != 1) && (VS(u - 1, y - 1) == 0)) || ((VM(u, y - 1) != 1) && (VS(u, y - 1) == 0)) ||
+                    ((VM(u + 1, y - 1) != 1) && (VS(u + 1, y - 1) == 0)) || ((VM(u - 1, y) != 1) && (VS(u - 1, y) == 0)) ||
+                    ((VM(u + 1, y) != 1) && (VS(u + 1, y) == 0)) || ((VM(u - 1, y + 1) != 1) && (VS(u - 1, y + 1) == 0)) ||
+                    ((VM(u, y + 1) != 1) && (VS(u, y + 1) == 0)) || ((VM(u + 1, y + 1) != 1) && (VS(u + 1, y + 1) == 0))) { /* :270 */
+                    VM(u, y) = 0;
+                    VS(u, y) = 1;
+                    wrapped_phase_image[(size_t)y * W + u] = 0; /* :274 */
+                }
+            }
+#undef VM
+#undef VS
+    }
+    free(visited_pixel);
+}
+
+/* compute_wrapped_phase(pattern_type), 3/wrapped_phase.cpp:402-467.
+   frames: F row-major 8-bit planes (what read_image :29-58 loads). */
+void orc_compute_wrapped_phase(orc_state *s, int pattern_type, const unsigned char *const *frames, size_t stride)
+{
+    int *valid_map_local = pattern_type == 0 ? s->valid_map_vertical : s->valid_map_horizontal;
+    float *wrapped_phi = pattern_type == 0 ? s->wrapped_phi_vertical : s->wrapped_phi_horizontal;
+    check_I_mod_criteria(s, valid_map_local);
+    create_wrapped_phase(s, frames, stride, valid_map_local, wrapped_phi, s->wrapped_img[pattern_type]);
+    erode_valid_map(s, valid_map_local, s->wrapped_img[pattern_type]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Stage 4 -- 4/phase_unwrap.cpp                                             */
+/* ------------------------------------------------------------------------- */
+#define THRESH 0 /* THRESH_VERT / THRESH_HORZ, 4/phase_unwrap.cpp:15-16 */
+
+/* S4b: decode_pixels Gray branch, 4/phase_unwrap.cpp:141-143,163-203 (v), :209-211,233-268 (h). */
+static void decode_pixels(orc_state *s, int N, const unsigned char *const *gray, const unsigned char *const *inv,
+                          size_t stride, const int *valid, int *code)
+{
+    const int W = s->c.W, H = s->c.H;
+    for (int u = 0; u < H; u++)
+        for (int v = 0; v < W; v++)
+            code[IDX(s, v, u)] = -1; /* :141-143 */
+    unsigned char *B = (unsigned char *)malloc((size_t)(N > 0 ? N : 1));
+    unsigned char *G = (unsigned char *)malloc((size_t)(N > 0 ? N : 1));
+    for (unsigned row = 0; row < (unsigned)H; row++)
+        for (unsigned col = 0; col < (unsigned)W; col++) {
+            if (valid[IDX(s, col, row)] == 1) {
+                for (int i = 0; i < N; i++) { G[i] = 0; B[i] = 0; }
+                code[IDX(s, col, row)] = 0;
+                for (int i = 0; i < N; i++) {
+                    if ((PX(gray[i], stride, row, col) - PX(inv[i], stride, row, col)) >= (unsigned char)THRESH) /* int arithmetic :183 */
+                        G[i] = 1;
+                    if (i == 0)
+                        B[i] = G[i];
+                    else
+                        B[i] = (B[i - 1] != G[i]) ? 1 : 0; /* :191 */
+                    code[IDX(s, col, row)] += B[i] * pow(2, N - 1 - i); /* int += double :193 */
+                }
+            }
+        }
+    free(B); free(G);
+}
+
+/* S4c: unwrap, 4/phase_unwrap.cpp:278-316.  Note the asymmetric loop ranges. */
+static void unwrap(orc_state *s, int pattern_type)
+{
+    const int W = s->c.W, H = s->c.H;
+    if (pattern_type == 0) {
+        /* unwrapped_phi_vertical = new float[..] (uninitialised in the reference; zero here) */
+        memset(s->unwrapped_phi_vertical, 0, sizeof(float) * (size_t)W * H);
+        for (int row = 0; row < H; row++)
+            for (int col = 1; col < W - 1; col++) {
+                if (s->valid_map_vertical[IDX(s, col, row)] == 1) {
+                    s->wrapped_phi_vertical[IDX(s, col, row)] += Pi; /* :290 */
+                    s->unwrapped_phi_vertical[IDX(s, col, row)] =
+                        s->wrapped_phi_vertical[IDX(s, col, row)] + s->code_vertical[IDX(s, col, row)] * 2.0 * Pi; /* :291 */
+                }
+            }
+    }
+    if (pattern_type == 1) {
+        memset(s->unwrapped_phi_horizontal, 0, sizeof(float) * (size_t)W * H);
+        for (int col = 0; col < W; col++)
+            for (int row = 1; row < H - 1; row++) {
+                if (s->valid_map_horizontal[IDX(s, col, row)] == 1) {
+                    s->wrapped_phi_horizontal[IDX(s, col, row)] += Pi; /* :308 */
+                    s->unwrapped_phi_horizontal[IDX(s, col, row)] =
+                        s->wrapped_phi_horizontal[IDX(s, col, row)] + s->code_horizontal[IDX(s, col, row)] * 2.0 * Pi; /* :309 */
+                }
+            }
+    }
+}
+
+/* S4d: save_unwrap_phase_image, 4/phase_unwrap.cpp:321-364 (needed to replay the KAT). */
+static void save_unwrap_phase_image(orc_state *s, int pattern_type)
+{
+    const int W = s->c.W, H = s->c.H;
+    unsigned char *img = s->unwrapped_img[pattern_type];
+    memset(img, 0, (size_t)W * H);
+    float t;
+    if (pattern_type == 0) {
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++)
+                if (s->valid_map_vertical[IDX(s, c, r)] == 1) {
+                    t = s->unwrapped_phi_vertical[IDX(s, c, r)] / (2.0 * Pi * s->c.ncodes_v); /* :334 */
+                    img[(size_t)r * W + c] = (unsigned char)(t * 255);                         /* :335 */
+                }
+    }
+    if (pattern_type == 1) {
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++)
+                if (s->valid_map_horizontal[IDX(s, c, r)] == 1) {
+                    t = s->unwrapped_phi_horizontal[IDX(s, c, r)] / (2.0 * Pi * s->c.ncodes_h); /* :353 */
+                    img[(size_t)r * W + c] = (unsigned char)(t * 255);
+                }
+    }
+}
+
+/* unwrap_phase(pattern_type), 4/phase_unwrap.cpp:367-393 (count==1: Gray-code mode).
+   gray/inv: N row-major planes each (frame index N of read_captured_images :63-90 is loaded
+   by the reference but never read by decode, so it is not an input here). */
+void orc_unwrap_phase(orc_state *s, int pattern_type, const unsigned char *const *gray,
+                      const unsigned char *const *inv, size_t stride)
+{
+    if (pattern_type == 0)
+        decode_pixels(s, s->c.N_v, gray, inv, stride, s->valid_map_vertical, s->code_vertical);
+    else
+        decode_pixels(s, s->c.N_h, gray, inv, stride, s->valid_map_horizontal, s->code_horizontal);
+    unwrap(s, pattern_type);
+    save_unwrap_phase_image(s, pattern_type);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Stage 5 -- 5/compute_correspondance.cpp                                   */
+/* ------------------------------------------------------------------------- */
+
+/* C1 merge_valid_maps :60-77, C2 compute_c_p_map :630-679. */
+void orc_compute_c_p_map(orc_state *s)
+{
+    const int W = s->c.W, H = s->c.H;
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++)
+            if ((s->valid_map_vertical[IDX(s, c, r)] == 1) && (s->valid_map_horizontal[IDX(s, c, r)] == 1))
+                s->valid_map[IDX(s, c, r)] = 1;
+            else
+                s->valid_map[IDX(s, c, r)] = 0;
+
+    memset(s->c_p_map, 0, sizeof(long) * 2 * (size_t)W * H); /* uninitialised in the reference */
+    long (*c_p_map)[2] = (long (*)[2])s->c_p_map;
+    const int fringe_width_pixels_vertical = s->c.fw_v, fringe_width_pixels_horizontal = s->c.fw_h;
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++) {
+            if (s->valid_map[IDX(s, c, r)] == 1) {
+                feclearexcept(FE_ALL_EXCEPT);
+                c_p_map[(size_t)r * W + c][0] = lrint(fringe_width_pixels_vertical * (s->unwrapped_phi_vertical[IDX(s, c, r)] / (2.0 * Pi))); /* :648 */
+                if (fetestexcept(FE_INVALID) != 0) {
+                    s->valid_map[IDX(s, c, r)] = 0;
+                    continue;
+                }
+                feclearexcept(FE_ALL_EXCEPT);
+                c_p_map[(size_t)r * W + c][1] = lrint(fringe_width_pixels_horizontal * (s->unwrapped_phi_horizontal[IDX(s, c, r)] / (2.0 * Pi))); /* :659 */
+                if (fetestexcept(FE_INVALID) != 0) {
+                    s->valid_map[IDX(s, c, r)] = 0;
+                    continue;
+                }
+                if ((c_p_map[(size_t)r * W + c][0] > (s->c.PW - 1)) || (c_p_map[(size_t)r * W + c][1] > (s->c.PH - 1)) ||
+                    (c_p_map[(size_t)r * W + c][0] < 0) || (c_p_map[(size_t)r * W + c][1] < 0)) { /* :671 */
+                    s->valid_map[IDX(s, c, r)] = 0;
+                }
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Stage 7 -- 7/triangulation.cpp + restated OpenCV 2.4.0 routines           */
+/* ------------------------------------------------------------------------- */
+void orc_set_calibration(orc_state *s, const double *Kc, const double *dc, const double *rc, const double *tc,
+                         const double *Kp, const double *dp, const double *rp, const double *tp)
+{
+    memcpy(s->Kc, Kc, sizeof s->Kc); memcpy(s->dc, dc, sizeof s->dc);
+    memcpy(s->rc, rc, sizeof s->rc); memcpy(s->tc, tc, sizeof s->tc);
+    memcpy(s->Kp, Kp, sizeof s->Kp); memcpy(s->dp, dp, sizeof s->dp);
+    memcpy(s->rp, rp, sizeof s->rp); memcpy(s->tp, tp, sizeof s->tp);
+    s->tables_ready = 0;
+}
+
+/* cvGEMM as used through cvMatMul (7/triangulation.cpp:302,373,1101,1116,1203,1205,1206):
+   D = A(m x k) * B(k x n), double accumulator, k ascending; D may alias A or B
+   (OpenCV copies through a temporary in that case). */
+static void mat_mul(const double *A, const double *B, double *D, int m, int k, int n)
+{
+    double *T = (double *)malloc(sizeof(double) * (size_t)m * n);
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++) {
+            double acc = 0;
+            for (int q = 0; q < k; q++)
+                acc += A[(size_t)i * k + q] * B[(size_t)q * n + j];
+            T[(size_t)i * n + j] = acc;
+        }
+    memcpy(D, T, sizeof(double) * (size_t)m * n);
+    free(T);
+}
+
+/* cvRodrigues2, vector -> matrix (OpenCV 2.4.0 modules/calib3d/src/calibration.cpp):
+   theta = |r|; theta < DBL_EPSILON -> I; else R = c*I + (1-c)*rr^T + s*[r]x. */
+static void rodrigues(const double *rvec, double *R)
+{
+    double rx = rvec[0], ry = rvec[1], rz = rvec[2];
+    double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+        for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double c = cos(theta), sn = sin(theta), c1 = 1. - c;
+    double itheta = theta ? 1. / theta : 0.;
+    rx *= itheta; ry *= itheta; rz *= itheta;
+    double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + sn * r_x[k];
+}
+
+/* cvUndistortPoints(src,dst,K,dist) with no R/P and a 5-element distortion vector
+   (k1,k2,p1,p2,k3) -- OpenCV 2.4.0 modules/imgproc/src/undistort.cpp:
+   normalise with the reciprocal focal lengths, 5 fixed-point iterations. */
+static void undistort_point(double px, double py, const double *K, const double *d, double *ox, double *oy)
+{
+    double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
+    double k[5] = {d[0], d[1], d[2], d[3], d[4]};
+    double x = (px - cx) * ifx, y = (py - cy) * ify, x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        double r2 = x * x + y * y;
+        double icdist = 1. / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+        double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    *ox = x; *oy = y;
+}
+
+/* T1: assign_3d_coordinates live part, 7/triangulation.cpp:262-307 (camera), :270-275,352-378 (projector).
+   Dead parts (cam_pixel_3D / proj_pixel_3D, transform_proj_coordinates) are not reproduced. */
+static void build_undist_table(const orc_state *s, int Wd, int Hd, int c0, int r0, const double *K, const double *d, double *mat)
+{
+    size_t n = (size_t)Wd * Hd;
+    for (size_t f = 0; f < n; f++) {
+        double pc = (double)(f % (size_t)Wd); /* column number :264 */
+        double pr = s->c.exact_index ? (double)(f / (size_t)Wd)
+                                     : (double)floorf((float)f / (float)Wd); /* row number :265 */
+        double ux, uy;
+        pc += (double)c0; pr += (double)r0; /* crop / stripe origin (0,0 in the reference) */
+        undistort_point(pc, pr, K, d, &ux, &uy); /* :290 / :363 */
+        mat[f] = ux; mat[n + f] = uy; mat[2 * n + f] = 1.0; /* :294-299 */
+    }
+    /* cvMatMul(K, mat, mat) :302 -- done column by column (same sums, same order) */
+    for (size_t f = 0; f < n; f++) {
+        double v[3] = {mat[f], mat[n + f], mat[2 * n + f]}, o[3];
+        for (int i = 0; i < 3; i++) {
+            double acc = 0;
+            for (int q = 0; q < 3; q++) acc += K[i * 3 + q] * v[q];
+            o[i] = acc;
+        }
+        mat[f] = o[0]; mat[n + f] = o[1]; mat[2 * n + f] = o[2];
+    }
+    /* Homogenize :305-307 (x = 0,1,2 in order; the last divides the w row by itself) */
+    for (size_t f = 0; f < n; f++)
+        for (int x = 0; x < 3; x++)
+            mat[(size_t)x * n + f] /= mat[2 * n + f];
+}
+
+/* T0: compute_A, 7/triangulation.cpp:1061-1126: A = K * [R|t]. */
+static void compute_A(const double *K, const double *rvec, const double *tvec, double *A)
+{
+    double R[9];
+    rodrigues(rvec, R);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) A[i * 4 + j] = R[i * 3 + j];
+        A[i * 4 + 3] = tvec[i];
+    }
+    mat_mul(K, A, A, 3, 3, 4);
+}
+
+void orc_prepare_triangulation(orc_state *s)
+{
+    if (s->tables_ready) return;
+    size_t nc = (size_t)s->c.W * s->c.H, np = (size_t)s->c.PW * s->c.PH;
+    free(s->cam_undist_points_mat); free(s->proj_undist_points_mat);
+    s->cam_undist_points_mat = (double *)malloc(sizeof(double) * 3 * nc);
+    s->proj_undist_points_mat = (double *)malloc(sizeof(double) * 3 * np);
+    build_undist_table(s, s->c.W, s->c.H, s->c.col0, s->c.row0, s->Kc, s->dc, s->cam_undist_points_mat);
+    build_undist_table(s, s->c.PW, s->c.PH, s->c.pcol0, s->c.prow0, s->Kp, s->dp, s->proj_undist_points_mat);
+    compute_A(s->Kc, s->rc, s->tc, s->A_cam);
+    compute_A(s->Kp, s->rp, s->tp, s->A_proj);
+    s->tables_ready = 1;
+}
+
+/* cvInvert(A,A) default CV_LU on a 3x3 double matrix -- OpenCV 2.4.0
+   modules/core/src/lapack.cpp: closed-form adjugate/determinant, zeros if det==0. */
+static void invert3(const double *S, double *D)
+{
+#define Sd(i, j) S[(i) * 3 + (j)]
+    double d = Sd(0, 0) * (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) - Sd(0, 1) * (Sd(1, 0) * Sd(2, 2) - Sd(1, 2) * Sd(2, 0)) +
+               Sd(0, 2) * (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0));
+    double t[9];
+    if (d != 0.) {
+        d = 1. / d;
+        t[0] = (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) * d;
+        t[1] = (Sd(0, 2) * Sd(2, 1) - Sd(0, 1) * Sd(2, 2)) * d;
+        t[2] = (Sd(0, 1) * Sd(1, 2) - Sd(0, 2) * Sd(1, 1)) * d;
+        t[3] = (Sd(1, 2) * Sd(2, 0) - Sd(1, 0) * Sd(2, 2)) * d;
+        t[4] = (Sd(0, 0) * Sd(2, 2) - Sd(0, 2) * Sd(2, 0)) * d;
+        t[5] = (Sd(0, 2) * Sd(1, 0) - Sd(0, 0) * Sd(1, 2)) * d;
+        t[6] = (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0)) * d;
+        t[7] = (Sd(0, 1) * Sd(2, 0) - Sd(0, 0) * Sd(2, 1)) * d;
+        t[8] = (Sd(0, 0) * Sd(1, 1) - Sd(0, 1) * Sd(1, 0)) * d;
+    } else {
+        for (int k = 0; k < 9; k++) t[k] = 0.;
+    }
+#undef Sd
+    memcpy(D, t, sizeof t);
+}
+
+/* triangulate(), 7/triangulation.cpp:1444-1561 -> compute_depth_method_3 :1223-1247
+   with compute_P :1134-1173, compute_F :1178-1192, compute_X_Y_Z :1198-1218. */
+void orc_triangulate(orc_state *s)
+{
+    const int W = s->c.W, H = s->c.H, PW = s->c.PW;
+    orc_prepare_triangulation(s);
+    const size_t nc = (size_t)W * H, np = (size_t)PW * s->c.PH;
+    const double *cu = s->cam_undist_points_mat, *pu = s->proj_undist_points_mat;
+    const double *A_cam = s->A_cam, *A_proj = s->A_proj;
+    long (*c_p_map)[2] = (long (*)[2])s->c_p_map;
+    memset(s->intersection_points, 0, sizeof(double) * 3 * nc); /* uninitialised in the reference */
+#define AC(i, j) A_cam[(i) * 4 + (j)]
+#define AP(i, j) A_proj[(i) * 4 + (j)]
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            if (s->valid_map[IDX(s, j, i)] == 1) {
+                double P[12], Fv[4], P_trans[12], I1[9], I2[12], V[3];
+                size_t ci = (size_t)i * W + j;
+                int corresponding_X = (int)c_p_map[ci][0];
+                int corresponding_Y = (int)c_p_map[ci][1];
+                size_t pi = (size_t)corresponding_Y * PW + corresponding_X;
+                for (int q = 0; q < 3; q++) { /* compute_P :1152-1168 */
+                    P[0 * 3 + q] = AC(0, q) - cu[ci] * AC(2, q);
+                    P[1 * 3 + q] = AC(1, q) - cu[nc + ci] * AC(2, q);
+                    P[2 * 3 + q] = AP(0, q) - pu[pi] * AP(2, q);
+                    P[3 * 3 + q] = AP(1, q) - pu[np + pi] * AP(2, q);
+                }
+                Fv[0] = AC(2, 3) * cu[ci] - AC(0, 3); /* compute_F :1181-1188 */
+                Fv[1] = AC(2, 3) * cu[nc + ci] - AC(1, 3);
+                Fv[2] = AP(2, 3) * pu[pi] - AP(0, 3);
+                Fv[3] = AP(2, 3) * pu[np + pi] - AP(1, 3);
+                for (int a = 0; a < 4; a++) /* cvTranspose :1202 */
+                    for (int b = 0; b < 3; b++) P_trans[b * 4 + a] = P[a * 3 + b];
+                mat_mul(P_trans, P, I1, 3, 4, 3);  /* :1203 */
+                invert3(I1, I1);                   /* :1204 */
+                mat_mul(I1, P_trans, I2, 3, 3, 4); /* :1205 */
+                mat_mul(I2, Fv, V, 3, 4, 1);       /* :1206 */
+                double *ip = s->intersection_points + 3 * IDX(s, j, i);
+                ip[0] = V[0]; ip[1] = V[1]; ip[2] = V[2]; /* :1209-1211 */
+            }
+        }
+#undef AC
+#undef AP
+}
+
+/* O1: the output cast and compaction of 8/save_point_cloud.cpp:33-37,85-104
+   (row-major scan, valid pixels only, double -> float). Returns the count. */
+long orc_save_point_cloud(const orc_state *s, float *xyz /* [count][3] or NULL */, long capacity)
+{
+    long y = 0;
+    for (int i = 0; i < s->c.H; i++)
+        for (int j = 0; j < s->c.W; j++)
+            if (s->valid_map[IDX(s, j, i)] == 1) {
+                if (xyz && y < capacity) {
+                    const double *ip = s->intersection_points + 3 * IDX(s, j, i);
+                    xyz[3 * y + 0] = (float)ip[0];
+                    xyz[3 * y + 1] = (float)ip[1];
+                    xyz[3 * y + 2] = (float)ip[2];
+                }
+                y++;
+            }
+    return y;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Row-major getters for the checker side (transpose out of [col][row]).     */
+/* which: 0 = vertical, 1 = horizontal, 2 = merged                           */
+/* ------------------------------------------------------------------------- */
+#define GETTER(name, type, expr)                                           \
+    void name(const orc_state *s, int which, type *out)                    \
+    {                                                                      \
+        for (int r = 0; r < s->c.H; r++)                                   \
+            for (int c = 0; c < s->c.W; c++)                               \
+                out[(size_t)r * s->c.W + c] = (type)(expr)[IDX(s, c, r)];  \
+    }
+GETTER(orc_get_valid_map, unsigned char,
+       (which == 0 ? s->valid_map_vertical : which == 1 ? s->valid_map_horizontal : s->valid_map))
+GETTER(orc_get_wrapped_phi, float, (which == 0 ? s->wrapped_phi_vertical : s->wrapped_phi_horizontal))
+GETTER(orc_get_unwrapped_phi, float, (which == 0 ? s->unwrapped_phi_vertical : s->unwrapped_phi_horizontal))
+GETTER(orc_get_code, int, (which == 0 ? s->code_vertical : s->code_horizontal))
+
+void orc_get_c_p_map(const orc_state *s, long *out /* [H*W][2] */)
+{
+    memcpy(out, s->c_p_map, sizeof(long) * 2 * (size_t)s->c.W * s->c.H);
+}
+
+void orc_get_intersection_points(const orc_state *s, double *out /* row-major [H][W][3] */)
+{
+    for (int r = 0; r < s->c.H; r++)
+        for (int c = 0; c < s->c.W; c++)
+            memcpy(out + 3 * ((size_t)r * s->c.W + c), s->intersection_points + 3 * IDX(s, c, r), 3 * sizeof(double));
+}
+
+void orc_get_debug_image(const orc_state *s, int stage /*3|4*/, int which, unsigned char *out)
+{
+    memcpy(out, stage == 3 ? s->wrapped_img[which] : s->unwrapped_img[which], (size_t)s->c.W * s->c.H);
+}
+
+void orc_get_projection_matrices(orc_state *s, double *A_cam, double *A_proj)
+{
+    orc_prepare_triangulation(s);
+    memcpy(A_cam, s->A_cam, sizeof s->A_cam);
+    memcpy(A_proj, s->A_proj, sizeof s->A_proj);
+}
+
+/* undistorted pixel coordinates of one camera (dev=0) / projector (dev=1) pixel: (u,v) of T1 */
+void orc_get_undist_point(orc_state *s, int dev, int col, int row, double *uv)
+{
+    orc_prepare_triangulation(s);
+    if (dev == 0) {
+        size_t n = (size_t)s->c.W * s->c.H, f = (size_t)row * s->c.W + col;
+        uv[0] = s->cam_undist_points_mat[f]; uv[1] = s->cam_undist_points_mat[n + f];
+    } else {
+        size_t n = (size_t)s->c.PW * s->c.PH, f = (size_t)row * s->c.PW + col;
+        uv[0] = s->proj_undist_points_mat[f]; uv[1] = s->proj_undist_points_mat[n + f];
+    }
+}
+
+/* One whole scan in main()'s order, m_tech_project_console.cpp:366-395:
+   S3(v), S3(h), S4(v), S4(h), S5, S7.  planes_v / planes_h hold F fringe, then N gray,
+   then N inverse-gray row-major planes.  This is what bench.py's cpu_baseline times. */
+void orc_run_scan(orc_state *s, const unsigned char *const *planes_v, const unsigned char *const *planes_h, size_t stride)
+{
+    orc_compute_wrapped_phase(s, 0, planes_v, stride);
+    orc_compute_wrapped_phase(s, 1, planes_h, stride);
+    orc_unwrap_phase(s, 0, planes_v + s->c.F, planes_v + s->c.F + s->c.N_v, stride);
+    orc_unwrap_phase(s, 1, planes_h + s->c.F, planes_h + s->c.F + s->c.N_h, stride);
+    orc_compute_c_p_map(s);
+    orc_triangulate(s);
+}
