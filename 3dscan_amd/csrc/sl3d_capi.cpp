@@ -1,0 +1,556 @@
+// sl3d_capi.cpp -- host side of the C ABI declared in include/sl3d.h.
+//
+// Owns the HBM layout (frame stack, mask with halo, dense results, optional stage planes), the
+// per-scan constants of stage 7 (Rodrigues, A = K*[R|t]: 7/triangulation.cpp:1061-1126) and the
+// exact atan2 table the kernels look the wrapped phase up in.  All compute happens in the HIP
+// kernels of sl3d_kernels.hip; there is no CPU implementation of the path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sl3d.h"
+#include "sl3d_internal.h"
+
+using namespace sl3d;
+
+struct sl3d_ctx {
+    sl3d_config cfg{};
+    KParams P{};
+    DevCal C{};
+    bool have_cal = false;
+    bool keep = false;
+    bool own_stream = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void *> allocs;
+    std::string err;
+    uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr;
+    float *d_points = nullptr;
+    float *d_atab = nullptr;  // two tables back to back
+    size_t mask_rows = 0;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(sl3d_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail((c), SL3D_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+extern "C" const char *sl3d_version(void) { return SL3D_VERSION_STRING " (gfx950, hip)"; }
+
+extern "C" const char *sl3d_strerror(int s)
+{
+    switch (s) {
+    case SL3D_OK: return "ok";
+    case SL3D_E_INVALID_ARG: return "invalid argument";
+    case SL3D_E_NO_DEVICE: return "no HIP device available (this library has no CPU fallback)";
+    case SL3D_E_HIP: return "HIP runtime error";
+    case SL3D_E_STATE: return "call order violated";
+    case SL3D_E_UNSUPPORTED: return "unsupported configuration";
+    case SL3D_E_NOMEM: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *sl3d_last_error(const sl3d_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+template <typename T>
+static int dev_alloc(sl3d_ctx *c, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? SL3D_E_NOMEM : SL3D_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return SL3D_OK;
+}
+
+// The wrapped phase is a function of two small integers (t1 in [-255,255], t2 in [-510,510]),
+// so the double-precision libm atan2 the reference calls (3/wrapped_phase.cpp:175) is tabulated
+// once on the host: table 0 = (float)atan2(t1,t2), table 1 = the same value after stage 4's
+// in-place `+= Pi` (4/phase_unwrap.cpp:290,308).
+static void build_atan_tables(std::vector<float> &tab)
+{
+    const size_t n = (size_t)SL3D_ATAN_T1 * SL3D_ATAN_T2;
+    tab.resize(2 * n);
+    for (int t1 = -255; t1 <= 255; t1++)
+        for (int t2 = -510; t2 <= 510; t2++) {
+            const float a = (float)t1, b = (float)t2;  // the reference holds t1,t2 in float
+            const float phi = (float)atan2((double)a, (double)b);
+            float sh = phi;
+            sh += 22.0 / 7.0;  // Pi macro of global_cv.h:62, evaluated in double, rounded on store
+            const size_t i = (size_t)(t1 + 255) * SL3D_ATAN_T2 + (size_t)(t2 + 510);
+            tab[i] = phi;
+            tab[n + i] = sh;
+        }
+}
+
+extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, SL3D_E_INVALID_ARG, "null argument");
+    *out = nullptr;
+    sl3d_config c = *cfg;
+    if (c.full_width == 0) c.full_width = c.width;
+    if (c.full_height == 0) c.full_height = c.height;
+    if (c.n_fringe == 0) c.n_fringe = 3;
+    if (c.max_views <= 0) c.max_views = 1;
+    if (c.width < 1 || c.height < 1 || c.col0 < 0 || c.row0 < 0 || c.col0 + c.width > c.full_width || c.row0 + c.height > c.full_height)
+        return fail(nullptr, SL3D_E_INVALID_ARG, "window does not fit the frame");
+    if (c.proj_width < 1 || c.proj_height < 1 || c.fringe_width_v < 1 || c.fringe_width_h < 1)
+        return fail(nullptr, SL3D_E_INVALID_ARG, "projector size / fringe width must be positive");
+    if (c.n_fringe < 3 || c.n_fringe > 5) return fail(nullptr, SL3D_E_UNSUPPORTED, "n_fringe must be 3, 4 or 5");
+    if (c.n_gray_v < 0 || c.n_gray_v > SL3D_MAX_GRAY || c.n_gray_h < 0 || c.n_gray_h > SL3D_MAX_GRAY)
+        return fail(nullptr, SL3D_E_UNSUPPORTED, "n_gray out of range");
+    if (c.n_codes_v <= 0) c.n_codes_v = (c.proj_width + c.fringe_width_v - 1) / c.fringe_width_v;
+    if (c.n_codes_h <= 0) c.n_codes_h = (c.proj_height + c.fringe_width_h - 1) / c.fringe_width_h;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, SL3D_E_NO_DEVICE, sl3d_strerror(SL3D_E_NO_DEVICE));
+    if (c.device < 0 || c.device >= ndev) return fail(nullptr, SL3D_E_INVALID_ARG, "device ordinal out of range");
+
+    sl3d_ctx *x = new sl3d_ctx();
+    x->cfg = c;
+    x->keep = (c.flags & SL3D_FLAG_KEEP_STAGES) != 0;
+#define CREATE_CHK(call)                                                                 \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            g_create_err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+            sl3d_destroy(x);                                                             \
+            return e_ == hipErrorOutOfMemory ? SL3D_E_NOMEM : SL3D_E_HIP;                \
+        }                                                                                \
+    } while (0)
+    CREATE_CHK(hipSetDevice(c.device));
+    if (c.stream) {
+        x->stream = (hipStream_t)c.stream;
+    } else {
+        CREATE_CHK(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+        x->own_stream = true;
+    }
+    CREATE_CHK(hipEventCreate(&x->ev0));
+    CREATE_CHK(hipEventCreate(&x->ev1));
+
+    KParams &P = x->P;
+    P.W = c.width; P.H = c.height; P.fullW = c.full_width; P.fullH = c.full_height;
+    P.col0 = c.col0; P.row0 = c.row0; P.PW = c.proj_width; P.PH = c.proj_height;
+    P.F = c.n_fringe; P.Nv = c.n_gray_v; P.Nh = c.n_gray_h; P.fwv = c.fringe_width_v; P.fwh = c.fringe_width_h;
+    P.ncodes_v = c.n_codes_v; P.ncodes_h = c.n_codes_h;
+    P.pitch = (c.width + 15) & ~15;
+    P.planes_per_view = 2 * P.F + 2 * P.Nv + 2 * P.Nh;
+    P.plane_stride = (size_t)P.pitch * P.H;
+    P.view_stride = (size_t)P.planes_per_view * P.plane_stride;
+    P.mpitch = P.pitch + 2 * SL3D_MASK_LPAD;
+    x->mask_rows = (size_t)P.H + 2 * SL3D_MASK_HALO;
+    P.mask_view_stride = (size_t)P.mpitch * x->mask_rows;
+    P.px_view_stride = (size_t)P.pitch * P.H;
+
+    const size_t V = (size_t)c.max_views;
+    int rc;
+#define ALLOC(ptr, count)                                              \
+    if ((rc = dev_alloc(x, &(ptr), (count))) != SL3D_OK) {             \
+        g_create_err = x->err;                                         \
+        sl3d_destroy(x);                                               \
+        return rc;                                                     \
+    }
+    ALLOC(x->d_frames, V * P.view_stride);
+    ALLOC(x->d_mask, V * P.mask_view_stride);
+    ALLOC(x->d_points, V * P.px_view_stride * 3);
+    ALLOC(x->d_valid, V * P.px_view_stride);
+    ALLOC(x->d_atab, (size_t)2 * SL3D_ATAN_T1 * SL3D_ATAN_T2);
+    CREATE_CHK(hipMemsetAsync(x->d_mask, 0, V * P.mask_view_stride, x->stream));
+    CREATE_CHK(hipMemsetAsync(x->d_frames, 0, V * P.view_stride, x->stream));
+    CREATE_CHK(hipMemsetAsync(x->d_valid, 0, V * P.px_view_stride, x->stream));
+    CREATE_CHK(hipMemsetAsync(x->d_points, 0, V * P.px_view_stride * 3 * sizeof(float), x->stream));
+    P.frames = x->d_frames; P.mask = x->d_mask; P.points = x->d_points; P.valid = x->d_valid;
+    {
+        std::vector<float> tab;
+        build_atan_tables(tab);
+        CREATE_CHK(hipMemcpyAsync(x->d_atab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, x->stream));
+        CREATE_CHK(hipStreamSynchronize(x->stream));
+        P.atab_phi = x->d_atab;
+        P.atab_shift = x->d_atab + (size_t)SL3D_ATAN_T1 * SL3D_ATAN_T2;
+    }
+    if (x->keep) {
+        const size_t n = V * P.px_view_stride;
+        for (int a = 0; a < 2; a++) {
+            ALLOC(P.wrapped[a], n); ALLOC(P.unwrapped[a], n); ALLOC(P.code[a], n);
+            ALLOC(P.valid_axis[a], n); ALLOC(P.dbg3[a], n); ALLOC(P.dbg4[a], n);
+            CREATE_CHK(hipMemsetAsync(P.wrapped[a], 0, n * 4, x->stream));
+            CREATE_CHK(hipMemsetAsync(P.unwrapped[a], 0, n * 4, x->stream));
+            CREATE_CHK(hipMemsetAsync(P.code[a], 0xff, n * 4, x->stream));
+            CREATE_CHK(hipMemsetAsync(P.valid_axis[a], 0, n, x->stream));
+            CREATE_CHK(hipMemsetAsync(P.dbg3[a], 0, n, x->stream));
+            CREATE_CHK(hipMemsetAsync(P.dbg4[a], 0, n, x->stream));
+        }
+        ALLOC(P.cpmap, n * 2); ALLOC(P.ipoints, n * 3);
+        CREATE_CHK(hipMemsetAsync(P.cpmap, 0, n * 16, x->stream));
+        CREATE_CHK(hipMemsetAsync(P.ipoints, 0, n * 24, x->stream));
+    }
+    CREATE_CHK(hipStreamSynchronize(x->stream));
+#undef ALLOC
+#undef CREATE_CHK
+    *out = x;
+    return SL3D_OK;
+}
+
+extern "C" void sl3d_destroy(sl3d_ctx *x)
+{
+    if (!x) return;
+    (void)hipSetDevice(x->cfg.device);
+    if (x->stream) (void)hipStreamSynchronize(x->stream);
+    for (void *p : x->allocs) (void)hipFree(p);
+    if (x->ev0) (void)hipEventDestroy(x->ev0);
+    if (x->ev1) (void)hipEventDestroy(x->ev1);
+    if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
+    delete x;
+}
+
+// ---- stage 7 per-scan constants (host, double) ---------------------------------------------------
+// cvRodrigues2 (vector -> matrix): theta = |r|; R = cos*I + (1-cos)*rr^T + sin*[r]x   (7/triangulation.cpp:1072,1080)
+static void rodrigues(const double r[3], double R[9])
+{
+    double rx = r[0], ry = r[1], rz = r[2];
+    const double theta = std::sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+        for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double c = std::cos(theta), s = std::sin(theta), c1 = 1.0 - c, it = 1.0 / theta;
+    rx *= it; ry *= it; rz *= it;
+    const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    const double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * (k % 4 == 0 ? 1.0 : 0.0) + c1 * rrt[k] + s * rx_[k];
+}
+
+// A = K * [R|t]   (compute_A, 7/triangulation.cpp:1090-1116)
+static void projection_matrix(const double K[9], const double rvec[3], const double tvec[3], double A[12])
+{
+    double R[9], Rt[12];
+    rodrigues(rvec, R);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Rt[i * 4 + j] = R[i * 3 + j];
+        Rt[i * 4 + 3] = tvec[i];
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += K[i * 3 + k] * Rt[k * 4 + j];
+            A[i * 4 + j] = acc;
+        }
+}
+
+static void fill_intr(Intr &I, const double K[9], const double d[5])
+{
+    memcpy(I.K, K, sizeof I.K);
+    I.ifx = 1.0 / K[0]; I.ify = 1.0 / K[4]; I.cx = K[2]; I.cy = K[5];
+    I.k1 = d[0]; I.k2 = d[1]; I.p1 = d[2]; I.p2 = d[3]; I.k3 = d[4];
+    I.has_dist = (d[0] != 0 || d[1] != 0 || d[2] != 0 || d[3] != 0 || d[4] != 0) ? 1 : 0;
+    I.affine = (K[6] == 0 && K[7] == 0 && K[8] == 1) ? 1 : 0;
+}
+
+extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
+                                    const double Kp[9], const double dp[5], const double rp[3], const double tp[3])
+{
+    if (!x || !Kc || !dc || !rc || !tc || !Kp || !dp || !rp || !tp) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    if (Kc[0] == 0 || Kc[4] == 0 || Kp[0] == 0 || Kp[4] == 0) return fail(x, SL3D_E_INVALID_ARG, "zero focal length");
+    projection_matrix(Kc, rc, tc, x->C.Ac);
+    projection_matrix(Kp, rp, tp, x->C.Ap);
+    fill_intr(x->C.cam, Kc, dc);
+    fill_intr(x->C.proj, Kp, dp);
+    x->have_cal = true;
+    return SL3D_OK;
+}
+
+static int check_view(sl3d_ctx *x, int view, int n = 1)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    if (view < 0 || n < 1 || view + n > x->cfg.max_views) return fail(x, SL3D_E_INVALID_ARG, "view index out of range");
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t stride)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    if (!m || stride < (size_t)x->cfg.full_width) return fail(x, SL3D_E_INVALID_ARG, "mask: null or stride < full_width");
+    const KParams &P = x->P;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    // window + halo, normalised to 0/1; cells outside the frame stay 0
+    std::vector<uint8_t> host(P.mask_view_stride, 0);
+    for (int r = -SL3D_MASK_HALO; r < P.H + SL3D_MASK_HALO; r++) {
+        const int gy = P.row0 + r;
+        if (gy < 0 || gy >= P.fullH) continue;
+        uint8_t *dst = host.data() + (size_t)(r + SL3D_MASK_HALO) * P.mpitch + SL3D_MASK_LPAD;
+        const uint8_t *src = m + (size_t)gy * stride;
+        for (int c = -SL3D_MASK_HALO; c < P.W + SL3D_MASK_HALO; c++) {
+            const int gx = P.col0 + c;
+            if (gx < 0 || gx >= P.fullW) continue;
+            dst[c] = src[gx] == 1 ? 1 : 0;
+        }
+    }
+    HIPCHK(x, hipMemcpyAsync(x->d_mask + (size_t)view * P.mask_view_stride, host.data(), host.size(), hipMemcpyHostToDevice, x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_set_frames(sl3d_ctx *x, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    const KParams &P = x->P;
+    const int N = axis == 0 ? P.Nv : P.Nh;
+    if ((axis != 0 && axis != 1) || !planes || n_planes != P.F + 2 * N || stride < (size_t)P.W)
+        return fail(x, SL3D_E_INVALID_ARG, "set_frames: expected n_fringe + 2*n_gray planes (fringe, gray, inverse) and stride >= width");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
+    for (int i = 0; i < n_planes; i++) {
+        if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames: null plane");
+        uint8_t *dst = x->d_frames + (size_t)view * P.view_stride + (size_t)(base + i) * P.plane_stride;
+        HIPCHK(x, hipMemcpy2DAsync(dst, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+    }
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
+{
+    int rc = check_view(x, src);
+    if (rc || (rc = check_view(x, dst))) return rc;
+    if (src == dst) return SL3D_OK;
+    const KParams &P = x->P;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)dst * P.view_stride, x->d_frames + (size_t)src * P.view_stride, P.view_stride,
+                             hipMemcpyDeviceToDevice, x->stream));
+    HIPCHK(x, hipMemcpyAsync(x->d_mask + (size_t)dst * P.mask_view_stride, x->d_mask + (size_t)src * P.mask_view_stride,
+                             P.mask_view_stride, hipMemcpyDeviceToDevice, x->stream));
+    return SL3D_OK;
+}
+
+// ---- compute -------------------------------------------------------------------------------------
+static int need_keep(sl3d_ctx *x)
+{
+    if (!x->keep) return fail(x, SL3D_E_STATE, "context was created without SL3D_FLAG_KEEP_STAGES");
+    return SL3D_OK;
+}
+
+static int launched(sl3d_ctx *x, int hip_err)
+{
+    if (hip_err != 0) return fail(x, SL3D_E_HIP, std::string("kernel launch: ") + hipGetErrorString((hipError_t)hip_err));
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_compute_wrapped_phase(sl3d_ctx *x, int view, int axis)
+{
+    int rc = check_view(x, view);
+    if (rc || (rc = need_keep(x))) return rc;
+    if (axis != 0 && axis != 1) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    return launched(x, launch_wrap(x->P, view, axis, x->stream));
+}
+
+extern "C" int sl3d_unwrap_phase(sl3d_ctx *x, int view, int axis)
+{
+    int rc = check_view(x, view);
+    if (rc || (rc = need_keep(x))) return rc;
+    if (axis != 0 && axis != 1) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    return launched(x, launch_unwrap(x->P, view, axis, x->stream));
+}
+
+extern "C" int sl3d_compute_c_p_map(sl3d_ctx *x, int view)
+{
+    int rc = check_view(x, view);
+    if (rc || (rc = need_keep(x))) return rc;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    return launched(x, launch_corr(x->P, view, x->stream));
+}
+
+extern "C" int sl3d_triangulate(sl3d_ctx *x, int view)
+{
+    int rc = check_view(x, view);
+    if (rc || (rc = need_keep(x))) return rc;
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    return launched(x, launch_tri(x->P, x->C, view, x->stream));
+}
+
+extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    return launched(x, launch_fused(x->P, x->C, first_view, n_views, x->keep, x->stream));
+}
+
+extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    HIPCHK(x, hipEventRecord(x->ev0, x->stream));
+    rc = launched(x, launch_fused(x->P, x->C, first_view, n_views, x->keep, x->stream));
+    if (rc) return rc;
+    HIPCHK(x, hipEventRecord(x->ev1, x->stream));
+    HIPCHK(x, hipEventSynchronize(x->ev1));
+    float t = 0;
+    HIPCHK(x, hipEventElapsedTime(&t, x->ev0, x->ev1));
+    if (ms) *ms = t;
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_timer_start(sl3d_ctx *x)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    HIPCHK(x, hipEventRecord(x->ev0, x->stream));
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_timer_stop(sl3d_ctx *x, float *ms)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    HIPCHK(x, hipEventRecord(x->ev1, x->stream));
+    HIPCHK(x, hipEventSynchronize(x->ev1));
+    float t = 0;
+    HIPCHK(x, hipEventElapsedTime(&t, x->ev0, x->ev1));
+    if (ms) *ms = t;
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_synchronize(sl3d_ctx *x)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+
+// ---- getters -------------------------------------------------------------------------------------
+template <typename T>
+static int get_plane(sl3d_ctx *x, int view, const T *dev_base, int comps, T *out, size_t out_stride_elems)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    if (!out) return fail(x, SL3D_E_INVALID_ARG, "null output");
+    if (!dev_base) return fail(x, SL3D_E_STATE, "plane not available (SL3D_FLAG_KEEP_STAGES not set?)");
+    const KParams &P = x->P;
+    if (out_stride_elems < (size_t)P.W * comps) return fail(x, SL3D_E_INVALID_ARG, "output stride too small");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const T *src = dev_base + (size_t)view * P.px_view_stride * comps;
+    HIPCHK(x, hipMemcpy2DAsync(out, out_stride_elems * sizeof(T), src, (size_t)P.pitch * comps * sizeof(T), (size_t)P.W * comps * sizeof(T),
+                               P.H, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_get_valid_map(sl3d_ctx *x, int view, int which, uint8_t *out, size_t stride)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    const uint8_t *src = which == SL3D_VALID_MERGED ? x->P.valid : (which == 0 || which == 1) ? x->P.valid_axis[which] : nullptr;
+    if (which < 0 || which > 2) return fail(x, SL3D_E_INVALID_ARG, "which must be 0, 1 or 2");
+    return get_plane<uint8_t>(x, view, src, 1, out, stride);
+}
+
+extern "C" int sl3d_get_wrapped_phase(sl3d_ctx *x, int view, int axis, float *out, size_t stride)
+{
+    if (!x || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
+    return get_plane<float>(x, view, x->P.wrapped[axis], 1, out, stride);
+}
+
+extern "C" int sl3d_get_unwrapped_phase(sl3d_ctx *x, int view, int axis, float *out, size_t stride)
+{
+    if (!x || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
+    return get_plane<float>(x, view, x->P.unwrapped[axis], 1, out, stride);
+}
+
+extern "C" int sl3d_get_code(sl3d_ctx *x, int view, int axis, int32_t *out, size_t stride)
+{
+    if (!x || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
+    return get_plane<int32_t>(x, view, x->P.code[axis], 1, out, stride);
+}
+
+extern "C" int sl3d_get_debug_image(sl3d_ctx *x, int view, int stage, int axis, uint8_t *out, size_t stride)
+{
+    if (!x || (axis != 0 && axis != 1) || (stage != 3 && stage != 4)) return fail(x, SL3D_E_INVALID_ARG, "stage must be 3 or 4, axis 0 or 1");
+    return get_plane<uint8_t>(x, view, stage == 3 ? x->P.dbg3[axis] : x->P.dbg4[axis], 1, out, stride);
+}
+
+extern "C" int sl3d_get_c_p_map(sl3d_ctx *x, int view, int64_t *out)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    return get_plane<int64_t>(x, view, (const int64_t *)x->P.cpmap, 2, out, (size_t)x->P.W * 2);
+}
+
+extern "C" int sl3d_get_intersection_points(sl3d_ctx *x, int view, double *out)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    return get_plane<double>(x, view, x->P.ipoints, 3, out, (size_t)x->P.W * 3);
+}
+
+extern "C" int sl3d_get_points(sl3d_ctx *x, int view, float *xyz, uint8_t *valid)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    int rc = SL3D_OK;
+    if (xyz) rc = get_plane<float>(x, view, x->P.points, 3, xyz, (size_t)x->P.W * 3);
+    if (rc == SL3D_OK && valid) rc = get_plane<uint8_t>(x, view, x->P.valid, 1, valid, (size_t)x->P.W);
+    return rc;
+}
+
+extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacity, int64_t *count)
+{
+    if (!x || !count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    const KParams &P = x->P;
+    std::vector<float> pts((size_t)P.W * P.H * 3);
+    std::vector<uint8_t> val((size_t)P.W * P.H);
+    int rc = sl3d_get_points(x, view, pts.data(), val.data());
+    if (rc) return rc;
+    // row-major scan, valid pixels only: 8/save_point_cloud.cpp:85-104
+    int64_t n = 0;
+    for (size_t i = 0; i < val.size(); i++)
+        if (val[i] == 1) {
+            if (xyz && n < capacity) memcpy(xyz + 3 * n, pts.data() + 3 * i, 3 * sizeof(float));
+            n++;
+        }
+    *count = n;
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_get_device_buffers(sl3d_ctx *x, sl3d_device_buffers *o)
+{
+    if (!x || !o) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    const KParams &P = x->P;
+    o->frames = x->d_frames;
+    o->frame_pitch = P.pitch;
+    o->plane_stride = P.plane_stride;
+    o->view_stride = P.view_stride;
+    o->planes_per_view = P.planes_per_view;
+    o->mask = x->d_mask;
+    o->mask_pitch = P.mpitch;
+    o->mask_view_stride = P.mask_view_stride;
+    o->points = x->d_points;
+    o->points_pitch = (size_t)P.pitch * 12;
+    o->points_view_stride = P.px_view_stride * 12;
+    o->valid = x->d_valid;
+    o->valid_pitch = P.pitch;
+    o->valid_view_stride = P.px_view_stride;
+    return SL3D_OK;
+}

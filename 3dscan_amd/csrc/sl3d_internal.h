@@ -1,0 +1,71 @@
+// sl3d_internal.h -- structures shared by the C-ABI host code (sl3d_capi.cpp) and the HIP
+// kernels (sl3d_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#define SL3D_MASK_HALO 2        // rows / columns of selection mask kept around the window
+#define SL3D_MASK_LPAD 16       // bytes in front of window column 0 in every mask row
+#define SL3D_ATAN_T1 511        // t1 = I0 - I2        in [-255, 255]
+#define SL3D_ATAN_T2 1021       // t2 = 2*I1 - I0 - I2 in [-510, 510]
+#define SL3D_MAX_GRAY 16
+
+namespace sl3d {
+
+// Intrinsics of one device (camera or projector) as stage 7 uses them (T1).
+struct Intr {
+    double K[9];
+    double ifx, ify, cx, cy;      // cvUndistortPoints normalises with the reciprocal focal lengths
+    double k1, k2, p1, p2, k3;
+    int has_dist;                 // any distortion coefficient non-zero (else the 5 iterations are an exact no-op)
+    int affine;                   // last row of K is (0,0,1): the homogeneous divide is an exact no-op
+};
+
+// Per-scan constants of stage 7 (T0): A = K*[R|t] for camera and projector.
+struct DevCal {
+    double Ac[12], Ap[12];
+    Intr cam, proj;
+};
+
+// Everything a kernel needs to address one context's buffers.
+struct KParams {
+    int W, H;                  // window
+    int fullW, fullH;          // camera frame
+    int col0, row0;            // window origin in the frame
+    int PW, PH;
+    int F, Nv, Nh;
+    int fwv, fwh;
+    int ncodes_v, ncodes_h;
+    int pitch;                 // bytes per row of every u8 plane (multiple of 16)
+    int planes_per_view;
+    size_t plane_stride;       // pitch * H
+    size_t view_stride;        // planes_per_view * plane_stride
+    int mpitch;                // mask row pitch (pitch + 32)
+    size_t mask_view_stride;   // mpitch * (H + 2*SL3D_MASK_HALO)
+    const uint8_t *frames;
+    const uint8_t *mask;       // 0/1 bytes, halo included
+    const float *atab_phi;     // (float)atan2(t1,t2)                        [stage 3 value]
+    const float *atab_shift;   // (float)((double)atab_phi + 22.0/7.0)       [value after stage 4's in-place shift]
+    // dense results
+    float *points;             // [view][row][pitch][3] f32
+    uint8_t *valid;            // [view][row][pitch]    merged valid map
+    size_t px_view_stride;     // pitch * H   (elements per view of every per-pixel plane)
+    // stage-boundary planes (NULL unless SL3D_FLAG_KEEP_STAGES)
+    float *wrapped[2];
+    float *unwrapped[2];
+    int32_t *code[2];
+    uint8_t *valid_axis[2];
+    uint8_t *dbg3[2];
+    uint8_t *dbg4[2];
+    int64_t *cpmap;            // [view][row][pitch][2]
+    double *ipoints;           // [view][row][pitch][3]
+};
+
+// launchers (sl3d_kernels.hip); `stream` is a hipStream_t
+int launch_fused(const KParams &P, const DevCal &C, int first_view, int n_views, bool keep, void *stream);
+int launch_wrap(const KParams &P, int view, int axis, void *stream);
+int launch_unwrap(const KParams &P, int view, int axis, void *stream);
+int launch_corr(const KParams &P, int view, void *stream);
+int launch_tri(const KParams &P, const DevCal &C, int view, void *stream);
+
+}  // namespace sl3d

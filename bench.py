@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused decode -> unwrap -> correspond -> triangulate kernel (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE from env)
+
+Workload (configs[1] of BASELINE.json): 1920x1080 camera, 3 phase-shift + 10 Gray-code bit planes per
+axis, reference-faithful two-axis mode (every Gray frame is thresholded against its inverse frame, so a
+view is 2*(3+10+10) = 46 frames), synthetic captures resident in HBM.  A step is ONE launch of the fused
+kernel over a batch of `--views` views per GPU (default 16, i.e. 2 GB of frames + results: larger than
+the 256 MiB Infinity Cache, so the kernel really streams from HBM).  With N GPUs every view is sharded by
+image rows (1080/N rows per GPU) and the batch grows to N*views views, so per-GPU work is fixed (weak
+scaling); no collective is needed by the per-pixel map itself (the mask halo comes from the input mask).
+The optional assembly of the dense clouds over RCCL is measured separately and reported in `assemble`.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--views", type=int, default=16, help="views per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--ngray", type=int, default=10)
+    ap.add_argument("--fringe-width", type=int, default=2)
+    ap.add_argument("--noise", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-assemble", action="store_true", help="skip the separate RCCL assembly measurement (N>1)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of one view timed on the CPU (0 = whole view)")
+    return ap.parse_args()
+
+
+class _DevMem:
+    """Expose a raw device pointer to torch (zero copy) through the CUDA array interface."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def cpu_baseline(args, cap, cal, gpu_valid, gpu_xyz, gpu_cp_note):
+    """The oracle (CPU restatement of the reference loop: single thread, [col][row] arrays, pow() per bit,
+    fenv per pixel, stage-7 tables rebuilt per scan as triangulate() does) timed on one view of the
+    same workload; its results also check the GPU output of that view."""
+    import numpy as np
+    from oracle.oracle import Oracle
+
+    W, H = args.width, args.height
+    rows = args.cpu_sample_rows or H
+    pv = [p[:rows] for p in cap["planes_v"]]
+    ph = [p[:rows] for p in cap["planes_h"]]
+    syn = importlib.import_module("3dscan_amd.synth")
+    mask = syn.default_mask(W, H)[:rows]
+    o = Oracle(W, rows, W, H, args.ngray, args.ngray, args.fringe_width, args.fringe_width)
+    o.set_mask(mask)
+    o.set_calibration(*cal)
+    times = []
+    for _ in range(5):
+        o.invalidate_tables()
+        t0 = time.perf_counter()
+        o.run_scan(pv, ph)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    v = o.valid_map(2) == 1
+    I = np.s_[0:rows - 3]  # the oracle treats the sample as its own image: skip its last rows
+    ok = bool(np.array_equal(gpu_valid[:rows][I] == 1, v[I]))
+    ref = o.intersection_points()[I][v[I]]
+    got = gpu_xyz[:rows][I][v[I]].astype(np.float64) if ok else None
+    rel = float(np.max(np.linalg.norm(got - ref, axis=-1) / np.linalg.norm(ref, axis=-1))) if ok and len(ref) else None
+    return {
+        "value": round(W * rows / t / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": f"1 view {W}x{rows} of the same workload (N={args.ngray}, two axes), single thread, reference loop order and "
+                  f"[col][row] layout, median of 5 runs ({t:.2f} s each)",
+        "gpu_matches_oracle": {"valid_map_bit_exact": ok, "max_rel_point_error": rel},
+    }
+
+
+def main():
+    args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    # torch first: its bundled HIP runtime must be the one libsl3d.so binds to (one runtime per process)
+    import torch
+    import torch.distributed as dist
+
+    dmod = importlib.import_module("3dscan_amd.distributed")
+    rank, local_rank, world = dmod.env_ranks()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    syn = importlib.import_module("3dscan_amd.synth")
+    scm = importlib.import_module("3dscan_amd.scanner")
+    W, H, N, fw, V = args.width, args.height, args.ngray, args.fringe_width, args.views
+    PW, PH = W, H
+    row0, rows = dmod.shard_rows(H, world, rank)
+    n_views = V * world  # batch grows with the GPU count; each GPU holds `rows` rows of every view
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    n_distinct = min(2, n_views)
+    caps = [syn.make_capture(W, rows, PW, PH, N, N, fw, fw, row0=row0, full=(W, H), noise=args.noise, view=i,
+                             plane=(2.0 * i, 0.05, 0.05 - 0.02 * i)) for i in range(n_distinct)]
+    cal = syn.cal_tuple(caps[0]["cal"])
+    sc = scm.Scanner(W, rows, PW, PH, N, N, fw, fw, max_views=n_views, device=local_rank, full_size=(W, H), origin=(0, row0))
+    sc.set_calibration(*cal)
+    full_mask = syn.default_mask(W, H)
+    for i, c in enumerate(caps):
+        sc.set_mask(full_mask, view=i)
+        sc.set_frames(0, c["planes_v"], view=i)
+        sc.set_frames(1, c["planes_h"], view=i)
+    for v in range(n_distinct, n_views):
+        sc.copy_view(v % n_distinct, v)
+    sc.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sc.run(0, n_views)
+    barrier()
+    t0 = time.perf_counter()
+    sc.timer_start()                       # HIP event on the stream the kernel is launched on
+    for _ in range(args.steps):
+        sc.run(0, n_views)
+    ev_ms = sc.timer_stop()                # second event, waited for
+    barrier()
+    dt = time.perf_counter() - t0
+    dt = dmod.max_over_ranks(dt, dev)
+    ev_ms = dmod.max_over_ranks(ev_ms, dev)
+
+    px_per_launch = n_views * rows * W                     # pixels one launch processes on one GPU
+    total_px = args.steps * px_per_launch * world
+    value = total_px / dt / 1e6
+    alg_bytes_px = 2 * 3 + 4 * N + 1 + 13                  # read 2F+2Nv+2Nh frame bytes + 1 mask, write xyz f32 + valid
+    launch_s = ev_ms / 1e3 / args.steps
+    achieved = alg_bytes_px * px_per_launch / launch_s / 1e9
+
+    out = {
+        "metric": "Mpixels/s decode+unwrap+triangulate @1920x1080",
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {W}x{H} camera, 3 phase-shift + {N} Gray-code bit planes per axis, two axes, "
+                               f"Gray frames thresholded against inverse frames (46 frames/view); one step = one fused-kernel "
+                               f"launch over {V} views per GPU, frames resident in HBM",
+                   "views_per_gpu_per_step": V, "rows_per_gpu": rows, "frames_per_view": 2 * (3 + 2 * N),
+                   "projector": f"{PW}x{PH}", "fringe_width": fw, "sharding": "image rows" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "sl3d::k_fused<false>", "algorithmic_bytes_per_pixel": alg_bytes_px,
+                     "pixels_per_launch": px_per_launch, "avg_launch_ms": round(launch_s * 1e3, 4)},
+    }
+
+    if world > 1 and not args.no_assemble:
+        out["assemble"] = measure_assemble(torch, dist, dmod, sc, n_views, V, rows, rank, world)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        xyz, valid = sc.points(0)
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, caps[0], cal, valid, xyz, None)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"error": repr(e)}
+    sc.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_assemble(torch, dist, dmod, sc, n_views, V, rows, rank, world):
+    """Assembly of the dense clouds over RCCL, outside the timed region: (a) gather of every stripe to rank 0,
+    (b) rotating roots (one all_to_all).  Reported as time per batch and the rate it would sustain."""
+    res = {}
+    try:
+        b = sc.device_buffers()
+        pitch = b.frame_pitch
+        pts = torch.as_tensor(_DevMem(b.points, n_views * b.points_view_stride), device="cuda").view(torch.float32)
+        pts = pts.view(n_views, rows, pitch * 3)
+        val = torch.as_tensor(_DevMem(b.valid, n_views * b.valid_view_stride), device="cuda").view(n_views, rows, pitch)
+        nbytes = pts.numel() * 4 + val.numel()
+        for name, fn in (("root_gather", lambda: (dmod.assemble_root(pts, rows), dmod.assemble_root(val, rows))),
+                         ("rotating_all_to_all", lambda: (dmod.assemble_rotating(pts, V), dmod.assemble_rotating(val, V)))):
+            fn()
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(); dist.barrier()
+            t = dmod.max_over_ranks((time.perf_counter() - t0) / reps, pts.device)
+            res[name] = {"ms_per_batch": round(t * 1e3, 3), "GB_per_rank": round(nbytes / 1e9, 4),
+                         "job_Mpixels_per_s_if_serialised": round(n_views * rows * world * (pitch) / t / 1e6, 1)}
+    except Exception as e:
+        res["error"] = repr(e)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,194 @@
+/*
+ * sl3d.h -- C ABI of the MI355X-native decode -> unwrap -> correspond -> triangulate path
+ *           of the pranavkantgaur/3dscan structured-light scanner.
+ *
+ * This is the drop-in boundary for stages 3, 4, 5 and 7 of the reference.  Each entry point
+ * names the reference interface it replaces (paths are relative to the reference tree).
+ * The reference's own four entry points (C++ linkage, no arguments, global-array results) are
+ * re-exported on top of this ABI by include/sl3d_shim.h / csrc/sl3d_shim.cpp.
+ *
+ * Conventions
+ *   - plain C: opaque handle, int status codes (0 = ok, negative = error), no exceptions.
+ *   - images are 8-bit single-channel row-major planes passed as (pointer, stride in bytes),
+ *     which is exactly what an IplImage holds (imageData, widthStep) after
+ *     cvLoadImage(..., CV_LOAD_IMAGE_GRAYSCALE)  [3/wrapped_phase.cpp:44, 4/phase_unwrap.cpp:78,84].
+ *   - results are row-major planes; the shim transposes into the reference's [col][row] globals.
+ *   - one context = one GPU + one HIP stream; all compute calls are asynchronous on that stream,
+ *     getters synchronise.  Calls on one context must be serialised by the caller; different
+ *     contexts are independent.
+ *   - a context processes a WINDOW (width x height at col0,row0) of a camera frame of
+ *     full_width x full_height: the whole frame on one GPU, or a row stripe per GPU.
+ *   - the library needs a HIP device: there is no CPU fallback (SL3D_E_NO_DEVICE).
+ */
+#ifndef SL3D_H
+#define SL3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL3D_VERSION_STRING "0.1.0"
+
+typedef struct sl3d_ctx sl3d_ctx;
+
+enum sl3d_status {
+    SL3D_OK = 0,
+    SL3D_E_INVALID_ARG = -1,
+    SL3D_E_NO_DEVICE = -2,   /* no HIP device / runtime: the product path has no CPU fallback */
+    SL3D_E_HIP = -3,         /* a HIP runtime call failed; see sl3d_last_error() */
+    SL3D_E_STATE = -4,       /* call order violated (e.g. triangulate before set_calibration) */
+    SL3D_E_UNSUPPORTED = -5,
+    SL3D_E_NOMEM = -6
+};
+
+/* pattern_type of the reference: 0 = vertical stripes (encode the projector COLUMN),
+ * 1 = horizontal stripes (encode the projector ROW)   [intermodule_dependencies.h:10,13] */
+enum sl3d_axis { SL3D_AXIS_VERTICAL = 0, SL3D_AXIS_HORIZONTAL = 1 };
+
+/* which valid map: valid_map_vertical / valid_map_horizontal / valid_map  [common_variables.h:18-21] */
+enum sl3d_valid_which { SL3D_VALID_VERTICAL = 0, SL3D_VALID_HORIZONTAL = 1, SL3D_VALID_MERGED = 2 };
+
+enum sl3d_flags {
+    /* allocate the stage-boundary planes (wrapped/unwrapped phase, code, per-axis valid maps,
+     * debug images, c_p_map, intersection_points).  Required for the per-stage entry points and
+     * their getters; sl3d_run() then also stores them ("parity mode", +~70 B/px of traffic).
+     * Without it only sl3d_run() and the point / valid getters are available (the timed mode). */
+    SL3D_FLAG_KEEP_STAGES = 1u
+};
+
+/* Replaces the compile-time macros and initialised globals of the reference:
+ * PROJECT_GLOBAL/global_cv.h:49-53 (dimensions) and common_variables.h:6-10,23-24. */
+typedef struct sl3d_config {
+    int32_t width, height;            /* window processed by this context (pixels)                 */
+    int32_t full_width, full_height;  /* Camera_imagewidth/height of the frame; 0 = same as window */
+    int32_t col0, row0;               /* window origin inside the frame                            */
+    int32_t proj_width, proj_height;  /* Projector_imagewidth / Projector_imageheight              */
+    int32_t n_fringe;                 /* number_of_patterns_fringe: 3 (or 4; 5 yields no valid pixel,
+                                         exactly as 3/wrapped_phase.cpp:106-129 does)              */
+    int32_t n_gray_v, n_gray_h;       /* number_of_patterns_binary_{vertical,horizontal}           */
+    int32_t fringe_width_v, fringe_width_h; /* fringe_width_pixels_{vertical,horizontal}           */
+    int32_t n_codes_v, n_codes_h;     /* number_of_codes_* (stage-4 debug image only); 0 = ceil(P/fw) */
+    int32_t max_views;                /* batch capacity: views resident in HBM at once (>= 1)      */
+    int32_t device;                   /* HIP device ordinal                                        */
+    uint32_t flags;                   /* sl3d_flags                                                */
+    void *stream;                     /* hipStream_t to run on, or NULL: the context creates one   */
+} sl3d_config;
+
+/* Device-resident layout, for callers that produce frames / consume points on the GPU
+ * (benchmarks, torch tensors, RCCL).  All pitches are in bytes unless noted. */
+typedef struct sl3d_device_buffers {
+    /* frames: view-major, then plane, then row.  Plane order inside a view:
+     *   vertical   axis: fringe[0..F), gray[0..N_v), inverse_gray[0..N_v)
+     *   horizontal axis: fringe[0..F), gray[0..N_h), inverse_gray[0..N_h)                         */
+    uint8_t *frames;
+    size_t frame_pitch;       /* bytes per row (multiple of 16, >= width)        */
+    size_t plane_stride;      /* bytes per plane = frame_pitch * height          */
+    size_t view_stride;       /* bytes per view  = planes_per_view * plane_stride */
+    int32_t planes_per_view;  /* 2*F + 2*N_v + 2*N_h                              */
+    /* selection mask with a 2-pixel halo; byte for window pixel (col,row) of a view is at
+     * mask + view*mask_view_stride + (row + 2)*mask_pitch + 16 + col; bytes are 0 or 1.           */
+    uint8_t *mask;
+    size_t mask_pitch;
+    size_t mask_view_stride;
+    /* dense results of sl3d_run(): xyz as 3 consecutive floats per pixel (NaN where invalid);
+     * pixel (col,row) of a view at points + view*points_view_stride + row*points_pitch + 12*col   */
+    float *points;
+    size_t points_pitch;        /* bytes per row = 12 * (frame_pitch)            */
+    size_t points_view_stride;  /* bytes per view                                */
+    uint8_t *valid;             /* merged valid map after stage 5, 0/1           */
+    size_t valid_pitch;         /* bytes per row (= frame_pitch)                 */
+    size_t valid_view_stride;   /* bytes per view                                */
+} sl3d_device_buffers;
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char *sl3d_version(void);
+const char *sl3d_strerror(int status);
+/* text of the last error on this context (HIP error string etc.); never NULL */
+const char *sl3d_last_error(const sl3d_ctx *ctx);
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+/* Replaces the `new[]` allocations the reference performs inside every stage and never frees
+ * (3/wrapped_phase.cpp:410-424, 4/phase_unwrap.cpp:282,300,373-376, 5/compute_correspondance.cpp:635-640,
+ * 7/triangulation.cpp:1513): all buffers are owned by the context and released by sl3d_destroy. */
+int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out);
+void sl3d_destroy(sl3d_ctx *ctx);
+
+/* ---- inputs ------------------------------------------------------------------------------- */
+/* The 8 calibration files read by read_parameters() 7/triangulation.cpp:149-180 and
+ * compute_A() :1061-1126: intrinsics K (3x3 row-major), distortion (k1,k2,p1,p2,k3),
+ * Rodrigues rotation vector and translation vector (world -> device) for camera and projector. */
+int sl3d_set_calibration(sl3d_ctx *ctx,
+                         const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
+                         const double Kp[9], const double dp[5], const double rp[3], const double tp[3]);
+
+/* selected_region of image_scissor() m_tech_project_console.cpp:146-238, handed over as a
+ * FULL-FRAME row-major u8 plane (full_width x full_height); a pixel is selected iff byte == 1
+ * (every consumer in the reference tests `== 1`).  The context copies its window plus halo. */
+int sl3d_set_mask(sl3d_ctx *ctx, int view, const uint8_t *full_frame_mask, size_t stride);
+
+/* The captured frames of one axis of one view, window-sized planes in host memory: what
+ * read_image() 3/wrapped_phase.cpp:29-58 (n_fringe planes) and read_captured_images()
+ * 4/phase_unwrap.cpp:51-131 (n_gray planes + n_gray inverse planes) load.
+ * planes[] order: fringe[0..F), gray[0..N), inverse_gray[0..N). */
+int sl3d_set_frames(sl3d_ctx *ctx, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride);
+
+/* Device-to-device duplicate of one resident view (frame stack + mask) into another slot of the batch. */
+int sl3d_copy_view(sl3d_ctx *ctx, int src_view, int dst_view);
+
+/* ---- the reference's four stage entry points (need SL3D_FLAG_KEEP_STAGES) ------------------- */
+/* void compute_wrapped_phase(int pattern_type)   3/wrapped_phase.cpp:402   */
+int sl3d_compute_wrapped_phase(sl3d_ctx *ctx, int view, int axis);
+/* void unwrap_phase(int pattern_type)            4/phase_unwrap.cpp:367    */
+int sl3d_unwrap_phase(sl3d_ctx *ctx, int view, int axis);
+/* void compute_c_p_map()                         5/compute_correspondance.cpp:630 */
+int sl3d_compute_c_p_map(sl3d_ctx *ctx, int view);
+/* void triangulate()                             7/triangulation.cpp:1444  */
+int sl3d_triangulate(sl3d_ctx *ctx, int view);
+
+/* ---- the fused hot path ------------------------------------------------------------------- */
+/* Stages 3(v) 3(h) 4(v) 4(h) 5 7 in main()'s order (m_tech_project_console.cpp:372-395) plus the
+ * float cast of 8/save_point_cloud.cpp:100-102, for views [first_view, first_view+n_views), as ONE
+ * kernel launch that reads every frame byte once and writes xyz (f32) + valid (u8). Asynchronous. */
+int sl3d_run(sl3d_ctx *ctx, int first_view, int n_views);
+/* same, bracketed by HIP events on the context's stream; returns the kernel time of this launch */
+int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);
+int sl3d_synchronize(sl3d_ctx *ctx);
+/* HIP-event stopwatch on the context's stream (the stream the kernels are launched on): start
+ * records an event, stop records a second one, waits for it and returns the elapsed device time
+ * between the two -- used to time a whole region of back-to-back launches without host syncs. */
+int sl3d_timer_start(sl3d_ctx *ctx);
+int sl3d_timer_stop(sl3d_ctx *ctx, float *elapsed_ms);
+
+/* ---- outputs (all synchronise the stream first; planes are window-sized, row-major) --------- */
+/* valid_map_vertical / _horizontal / valid_map  (int[W][H] in the reference), as 0/1 bytes */
+int sl3d_get_valid_map(sl3d_ctx *ctx, int view, int which, uint8_t *out, size_t stride);
+/* wrapped_phi_{vertical,horizontal}: after stage 3 the atan2 phase, after stage 4 shifted by
+ * +Pi in place on unwrapped pixels, as the reference does (4/phase_unwrap.cpp:290,308) */
+int sl3d_get_wrapped_phase(sl3d_ctx *ctx, int view, int axis, float *out, size_t stride_elems);
+int sl3d_get_unwrapped_phase(sl3d_ctx *ctx, int view, int axis, float *out, size_t stride_elems);
+/* code_{vertical,horizontal}: Gray-decoded period index, -1 where invalid (4/phase_unwrap.cpp:143) */
+int sl3d_get_code(sl3d_ctx *ctx, int view, int axis, int32_t *out, size_t stride_elems);
+/* the 8-bit debug images of stage 3 (3/wrapped_phase.cpp:178-179,274) and stage 4
+ * (4/phase_unwrap.cpp:334-335): the reference's known-answer images are these */
+int sl3d_get_debug_image(sl3d_ctx *ctx, int view, int stage, int axis, uint8_t *out, size_t stride);
+/* c_p_map: long[W*H][2] indexed [row*W+col] (common_variables.h:15), zeros where invalid */
+int sl3d_get_c_p_map(sl3d_ctx *ctx, int view, int64_t *out);
+/* intersection_points as row-major double [H][W][3] (the reference stores [col][row][3]) */
+int sl3d_get_intersection_points(sl3d_ctx *ctx, int view, double *out);
+/* dense f32 points [H][W][3] (NaN where invalid) + merged valid map [H][W]; either may be NULL */
+int sl3d_get_points(sl3d_ctx *ctx, int view, float *xyz, uint8_t *valid);
+/* the compacted cloud of 8/save_point_cloud.cpp:85-104: valid points in row-major scan order;
+ * writes at most `capacity` points, always returns the total count in *count */
+int sl3d_get_cloud(sl3d_ctx *ctx, int view, float *xyz, int64_t capacity, int64_t *count);
+
+/* ---- device-resident access ---------------------------------------------------------------- */
+int sl3d_get_device_buffers(sl3d_ctx *ctx, sl3d_device_buffers *out);
+/* normalise a mask written directly into the device buffer to 0/1 bytes is the caller's duty */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SL3D_H */

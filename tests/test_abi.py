@@ -1,0 +1,63 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, and refuses to run without a device (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, pkg
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sl3d.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sl3d_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(scanner_mod):
+    declared = _header_symbols()
+    assert declared, "no prototypes found in include/sl3d.h"
+    assert sorted(scanner_mod.ABI_SYMBOLS) == declared, "scanner.ABI_SYMBOLS out of sync with include/sl3d.h"
+    lib = ctypes.CDLL(scanner_mod.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libsl3d.so does not export {name}"
+
+
+def test_version_and_strerror(scanner_mod):
+    L = scanner_mod.load_library()
+    assert L.sl3d_version().decode().startswith("0.")
+    assert L.sl3d_strerror(0) == b"ok"
+    assert b"no CPU fallback" in L.sl3d_strerror(-2)
+
+
+def test_create_rejects_bad_config(scanner_mod):
+    L = scanner_mod.load_library()
+    h = ctypes.c_void_p()
+    cfg = scanner_mod.Config(0, 10, 0, 0, 0, 0, 64, 64, 3, 3, 3, 8, 8, 0, 0, 1, 0, 0, None)
+    assert L.sl3d_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert L.sl3d_create(None, ctypes.byref(h)) == -1
+
+
+def test_no_cpu_fallback(scanner_mod):
+    """Without a HIP device construction must fail loudly (SL3D_E_NO_DEVICE), never compute on the CPU."""
+    L = scanner_mod.load_library()
+    h = ctypes.c_void_p()
+    cfg = scanner_mod.Config(64, 32, 0, 0, 0, 0, 64, 64, 3, 3, 3, 8, 8, 0, 0, 1, 0, 0, None)
+    rc = L.sl3d_create(ctypes.byref(cfg), ctypes.byref(h))
+    if rc == 0:  # a GPU is present (GPU box): fine, clean up
+        L.sl3d_destroy(h)
+        pytest.skip("a HIP device is present")
+    assert rc == -2
+    with pytest.raises(scanner_mod.Sl3dError):
+        scanner_mod.Scanner(64, 32, 64, 64, 3, 3, 8, 8)
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under 3dscan_amd/ may reference it."""
+    base = os.path.join(ROOT, "3dscan_amd")
+    for dirpath, _, files in os.walk(base):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower() or f == "sl3d_kernels.hip" and "tests/test_oracle.py" in txt, f

@@ -1,0 +1,283 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and
+against the committed golden vectors.  Bars: valid maps, Gray-code indices, correspondences bit
+exact; wrapped / absolute phase bit exact (tighter than the 1e-5 BASELINE.json asks for);
+3D points within 1e-5 relative (assert_points_close)."""
+import numpy as np
+import pytest
+
+from conftest import assert_points_close, golden_calibration, load_golden, pkg
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _scanner():
+    return pkg("scanner")
+
+
+def _oracle_for(cap, W, H, PW, PH, Nv, Nh, fwv, fwh, mask, F=3):
+    o = Oracle(W, H, PW, PH, Nv, Nh, fwv, fwh, F=F)
+    o.set_mask(mask)
+    o.set_calibration(*pkg("synth").cal_tuple(cap["cal"]))
+    o.run_scan(cap["planes_v"], cap["planes_h"])
+    return o
+
+
+def _compare(sc, o, sel, staged, what):
+    """sel = selected pixels (mask == 1).  staged=True: per-stage kernels (all planes defined as the reference
+    leaves them); False: fused kernel in parity mode (planes defined on valid pixels)."""
+    for a in (0, 1):
+        assert np.array_equal(sc.valid_map(a), o.valid_map(a)), f"{what}: valid map axis {a}"
+    vm = o.valid_map(2)
+    assert np.array_equal(sc.valid_map(2), vm), f"{what}: merged valid map"
+    v = vm == 1
+    va = [o.valid_map(0) == 1, o.valid_map(1) == 1]
+    for a in (0, 1):
+        assert np.array_equal(sc.code(a)[va[a]], o.code(a)[va[a]]), f"{what}: code axis {a}"
+        where = sel if staged else va[a]
+        assert np.array_equal(sc.wrapped_phase(a)[where], o.wrapped_phi(a)[where]), f"{what}: wrapped phase axis {a}"
+        assert np.array_equal(sc.unwrapped_phase(a)[va[a]], o.unwrapped_phi(a)[va[a]]), f"{what}: unwrapped phase axis {a}"
+        if staged:
+            assert np.array_equal(sc.code(a), o.code(a))
+            assert np.array_equal(sc.debug_image(3, a), o.debug_image(3, a)), f"{what}: stage-3 debug image axis {a}"
+            assert np.array_equal(sc.debug_image(4, a), o.debug_image(4, a)), f"{what}: stage-4 debug image axis {a}"
+    assert np.array_equal(sc.c_p_map()[v], o.c_p_map()[v]), f"{what}: c_p_map"
+    ref = o.intersection_points()
+    assert_points_close(sc.intersection_points(), ref, v)
+    xyz, valid = sc.points()
+    assert np.array_equal(valid, vm)
+    assert_points_close(xyz, ref, v, rel=1e-5)
+    assert np.isnan(xyz[~v]).all()
+    cloud = sc.cloud()
+    assert cloud.shape == (int(v.sum()), 3)
+    assert np.array_equal(cloud, xyz[v])
+
+
+def _run_both(W, H, PW, PH, Nv, Nh, fwv, fwh, cap, mask, F=3):
+    S = _scanner()
+    o = _oracle_for(cap, W, H, PW, PH, Nv, Nh, fwv, fwh, mask, F=F)
+    cal = pkg("synth").cal_tuple(cap["cal"])
+    for staged in (True, False):
+        with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, n_fringe=F, keep_stages=True) as sc:
+            sc.set_calibration(*cal)
+            sc.set_mask(mask)
+            sc.set_frames(0, cap["planes_v"])
+            sc.set_frames(1, cap["planes_h"])
+            if staged:
+                sc.run_stages()
+            else:
+                sc.run()
+            _compare(sc, o, mask == 1, staged, "staged" if staged else "fused")
+    # the timed mode (no stage planes) must give the same points as parity mode
+    with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, n_fringe=F) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        sc.set_frames(0, cap["planes_v"])
+        sc.set_frames(1, cap["planes_h"])
+        sc.run()
+        xyz, valid = sc.points()
+        v = o.valid_map(2) == 1
+        assert np.array_equal(valid == 1, v)
+        assert_points_close(xyz, o.intersection_points(), v)
+    return o
+
+
+# ---- golden vectors from the reference's real captures -------------------------------------------
+@pytest.mark.parametrize("name", ["real_inside", "real_edge"])
+@pytest.mark.parametrize("staged", [True, False])
+def test_golden_real_captures(name, staged):
+    """Crops of the real 1600x1200 captures, processed as a window of the full frame; expected values are the
+    reference's own KAT images (stage 3/4, pinned) and the full-frame oracle run (stage 5/7)."""
+    S = _scanner()
+    g = load_golden(name)
+    cal, dims = golden_calibration()
+    H, W = g["mask"].shape
+    x0, y0 = [int(v) for v in g["origin"]]
+    N_v, N_h, fw_v, fw_h, nc_v, nc_h = [int(v) for v in g["params"]]
+    full = np.zeros((dims["H"], dims["W"]), np.uint8)
+    full[y0 - 2:y0 + H + 2, x0 - 2:x0 + W + 2] = g["mask_halo2"]
+    with S.Scanner(W, H, dims["PW"], dims["PH"], N_v, N_h, fw_v, fw_h, n_codes_v=nc_v, n_codes_h=nc_h,
+                   keep_stages=True, full_size=(dims["W"], dims["H"]), origin=(x0, y0)) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(full)
+        sc.set_frames(0, list(g["fringe_v"]) + list(g["gray_v"]) + list(g["inv_v"]))
+        sc.set_frames(1, list(g["fringe_h"]) + list(g["gray_h"]) + list(g["inv_h"]))
+        if staged:
+            sc.run_stages()
+            # reference-provided known answers, bit exact, on every pixel of the crop
+            assert np.array_equal(sc.debug_image(3, 0), g["kat_wrapped_v"])
+            assert np.array_equal(sc.debug_image(3, 1), g["kat_wrapped_h"])
+            assert np.array_equal(sc.debug_image(4, 0), g["kat_unwrapped_v"])
+            assert np.array_equal(sc.debug_image(4, 1), g["kat_unwrapped_h"])
+        else:
+            sc.run()
+        v = g["valid"] == 1
+        assert np.array_equal(sc.valid_map(0) == 1, g["kat_wrapped_v"] != 0)
+        assert np.array_equal(sc.valid_map(2) == 1, v)
+        assert np.array_equal(sc.code(0)[v], g["code_v"][v]) and np.array_equal(sc.code(1)[v], g["code_h"][v])
+        assert np.array_equal(sc.wrapped_phase(0)[v], g["wrapped_v"][v])
+        assert np.array_equal(sc.wrapped_phase(1)[v], g["wrapped_h"][v])
+        assert np.array_equal(sc.unwrapped_phase(0)[v], g["unwrapped_v"][v])
+        assert np.array_equal(sc.unwrapped_phase(1)[v], g["unwrapped_h"][v])
+        assert np.array_equal(sc.c_p_map()[v], g["c_p_map"][v])
+        assert_points_close(sc.intersection_points(), g["points"], v)
+        xyz, valid = sc.points()
+        assert np.array_equal(valid == 1, v)
+        assert_points_close(xyz, g["points"], v)
+
+
+# ---- synthetic captures: BASELINE.json configs -----------------------------------------------------
+def test_config1_640x480():
+    """configs[0]: 640x480, 3 phase + 8-bit Gray code per axis."""
+    syn = pkg("synth")
+    W, H, PW, PH, N, fw = 640, 480, 1024, 768, 8, 4
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw)
+    _run_both(W, H, PW, PH, N, N, fw, fw, cap, cap["mask"])
+
+
+def test_config2_1920x1080_noise():
+    """configs[1]: 1920x1080, 3 phase + 10 Gray per axis; camera noise +-2 so Gray thresholds see ties."""
+    syn = pkg("synth")
+    W, H, PW, PH, N, fw = 1920, 1080, 1920, 1080, 10, 2
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw, noise=2)
+    o = _run_both(W, H, PW, PH, N, N, fw, fw, cap, cap["mask"])
+    assert (o.valid_map(2) == 1).mean() > 0.5
+
+
+# ---- edge cases -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H", [(101, 37), (64, 5), (19, 64), (130, 3)])
+def test_ragged_sizes_random_masks(W, H):
+    """Widths that are not multiples of 4/16, tiny heights, random masks that touch the frame border
+    (border pixels keep their selection, the unwrap skips the first/last column/row)."""
+    syn = pkg("synth")
+    rng = np.random.default_rng(W * 1000 + H)
+    PW, PH, N, fw = 256, 256, 6, 4
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw, noise=3)
+    for p in (0.0, 0.5, 0.9, 1.0):
+        mask = (rng.random((H, W)) < p).astype(np.uint8)
+        if p == 0.9:
+            mask[rng.random((H, W)) < 0.05] = 2  # only the value 1 selects
+        _run_both(W, H, PW, PH, N, N, fw, fw, cap, mask)
+
+
+def test_saturated_and_flat_frames():
+    """All-equal frames: atan2(0,0) = 0, Gray ties decode as 1 (THRESH 0, >=)."""
+    W, H, PW, PH, N, fw = 96, 40, 128, 128, 5, 4
+    syn = pkg("synth")
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw)
+    for val in (0, 255, 17):
+        cap["planes_v"] = [np.full((H, W), val, np.uint8) for _ in cap["planes_v"]]
+        cap["planes_h"] = [np.full((H, W), val, np.uint8) for _ in cap["planes_h"]]
+        _run_both(W, H, PW, PH, N, N, fw, fw, cap, cap["mask"])
+
+
+def test_random_bytes():
+    """Uniform random frame bytes: exercises the whole atan2 lattice, all codes and out-of-range rejections."""
+    W, H, PW, PH, N, fw = 256, 128, 300, 200, 7, 3
+    syn = pkg("synth")
+    cap = syn.make_capture(W, H, 384, 384, N, N, fw, fw)
+    rng = np.random.default_rng(3)
+    cap["planes_v"] = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in cap["planes_v"]]
+    cap["planes_h"] = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in cap["planes_h"]]
+    o = _run_both(W, H, PW, PH, N, N, fw, fw, cap, cap["mask"])
+    frac = (o.valid_map(2) == 1).mean()
+    assert 0.0 < frac < 1.0  # some correspondences fall outside the projector and are rejected
+
+
+def test_four_step_and_five_step():
+    """F=4 uses the 4-step formula (3/wrapped_phase.cpp:188-204); F=5 yields no valid pixel, as in the reference."""
+    W, H, PW, PH, N, fw = 128, 48, 256, 256, 6, 4
+    syn = pkg("synth")
+    for F in (4, 5):
+        cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw, n_fringe=F, noise=1)
+        o = _run_both(W, H, PW, PH, N, N, fw, fw, cap, cap["mask"], F=F)
+        if F == 5:
+            assert (o.valid_map(2) == 1).sum() == 0
+
+
+def test_projector_distortion_and_skew():
+    """Non-zero projector distortion (5 iterations on the projector side too), tangential terms, a skewed K."""
+    syn = pkg("synth")
+    W, H, PW, PH, N, fw = 320, 200, 512, 384, 7, 4
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw)
+    cal = {k: np.array(v, dtype=np.float64).copy() for k, v in cap["cal"].items()}
+    cal["dp"] = np.array([0.05, -0.02, 0.001, -0.0005, 0.01])
+    cal["dc"] = np.array([0.0813, -0.1102, 0.0007, -0.0003, 0.02])
+    cal["Kc"][1] = 0.3  # skew
+    cap["cal"] = cal
+    _run_both(W, H, PW, PH, N, N, fw, fw, cap, cap["mask"])
+
+
+# ---- size-independent properties at full size --------------------------------------------------------
+def test_12mp_fused_equals_staged_and_row_shards():
+    """configs[2] (4096x3000): the oracle would take minutes, so use properties: (a) the fused kernel equals the
+    per-stage kernels bit for bit on codes / correspondences / valid, (b) processing the frame as two row
+    stripes (the multi-GPU decomposition) reproduces the single-context result exactly, (c) a 64-row stripe
+    equals the oracle run on that stripe (interior rows)."""
+    S, syn = _scanner(), pkg("synth")
+    W, H, PW, PH, N, fw = 4096, 3000, 2048, 2048, 10, 2
+    R0, RH = 1400, 64  # oracle stripe
+    cap = syn.make_capture(W, RH, PW, PH, N, N, fw, fw, row0=R0, full=(W, H), noise=1)
+    full_mask = syn.default_mask(W, H)
+    cal = syn.cal_tuple(cap["cal"])
+
+    def stripe(rows0, rows, planes_v, planes_h, keep):
+        sc = S.Scanner(W, rows, PW, PH, N, N, fw, fw, keep_stages=keep, full_size=(W, H), origin=(0, rows0))
+        sc.set_calibration(*cal)
+        sc.set_mask(full_mask)
+        sc.set_frames(0, planes_v)
+        sc.set_frames(1, planes_h)
+        return sc
+
+    with stripe(R0, RH, cap["planes_v"], cap["planes_h"], True) as a:
+        a.run()
+        fused = (a.valid_map(2), a.code(0), a.code(1), a.c_p_map(), a.points()[0])
+        a.run_stages()
+        v = a.valid_map(2) == 1
+        assert np.array_equal(fused[0] == 1, v)
+        assert np.array_equal(fused[1][v], a.code(0)[v]) and np.array_equal(fused[2][v], a.code(1)[v])
+        assert np.array_equal(fused[3][v], a.c_p_map()[v])
+        assert np.array_equal(fused[4][v], a.points()[0][v])
+    # (b) two half stripes
+    h2 = RH // 2
+    parts = []
+    for k in range(2):
+        sl = slice(k * h2, (k + 1) * h2)
+        with stripe(R0 + k * h2, h2, [p[sl] for p in cap["planes_v"]], [p[sl] for p in cap["planes_h"]], False) as s2:
+            s2.run()
+            parts.append(s2.points())
+    xyz2 = np.concatenate([p[0] for p in parts]); val2 = np.concatenate([p[1] for p in parts])
+    assert np.array_equal(val2, fused[0])
+    assert np.array_equal(xyz2[val2 == 1], fused[4][val2 == 1])
+    # (c) oracle on the stripe (its own small image with the stripe origin): compare away from the stripe's top/bottom rows
+    o = Oracle(W, RH, PW, PH, N, N, fw, fw, row0=R0)
+    o.set_mask(full_mask[R0:R0 + RH])
+    o.set_calibration(*cal)
+    o.run_scan(cap["planes_v"], cap["planes_h"])
+    I = np.s_[3:-3, :]
+    vo = o.valid_map(2)[I] == 1
+    assert np.array_equal(fused[0][I] == 1, vo)
+    assert np.array_equal(fused[3][I][vo], o.c_p_map()[I][vo])
+    assert_points_close(fused[4][I], o.intersection_points()[I], vo)
+
+
+def test_batch_of_views_matches_single_views():
+    """A batch launch over several views (one kernel) equals running the views one by one."""
+    S, syn = _scanner(), pkg("synth")
+    W, H, PW, PH, N, fw = 640, 200, 1024, 768, 8, 4
+    caps = [syn.make_capture(W, H, PW, PH, N, N, fw, fw, view=v, noise=2, plane=(0.0 + 3 * v, 0.05, 0.02 * v)) for v in range(3)]
+    cal = syn.cal_tuple(caps[0]["cal"])
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=3) as sc:
+        sc.set_calibration(*cal)
+        for v, c in enumerate(caps):
+            sc.set_mask(c["mask"], view=v)
+            sc.set_frames(0, c["planes_v"], view=v)
+            sc.set_frames(1, c["planes_h"], view=v)
+        sc.run(0, 3)
+        batch = [sc.points(v) for v in range(3)]
+        for v in range(3):
+            sc.run(v, 1)
+            xyz, val = sc.points(v)
+            assert np.array_equal(val, batch[v][1])
+            assert np.array_equal(xyz[val == 1], batch[v][0][val == 1])
+    assert not np.array_equal(batch[0][0][batch[0][1] == 1][:100], batch[1][0][batch[1][1] == 1][:100])

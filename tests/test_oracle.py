@@ -1,0 +1,172 @@
+"""CPU tests: the oracle against the reference's own known answers (golden crops of the real
+captures and of the KAT images the reference wrote), and the closed form of the boundary removal."""
+import numpy as np
+import pytest
+
+from conftest import golden_calibration, load_golden
+from oracle.oracle import Oracle
+
+CROPS = ["real_inside", "real_edge"]
+
+
+def _run_crop(g, with_cal=True):
+    H, W = g["mask"].shape
+    N_v, N_h, fw_v, fw_h, nc_v, nc_h = [int(v) for v in g["params"]]
+    PW, PH = int(g["full"][2]), int(g["full"][3])
+    o = Oracle(W, H, PW, PH, N_v, N_h, fw_v, fw_h, ncodes_v=nc_v, ncodes_h=nc_h,
+               col0=int(g["origin"][0]), row0=int(g["origin"][1]))
+    o.set_mask(g["mask"])
+    o.compute_wrapped_phase(0, list(g["fringe_v"]))
+    o.compute_wrapped_phase(1, list(g["fringe_h"]))
+    o.unwrap_phase(0, list(g["gray_v"]), list(g["inv_v"]))
+    o.unwrap_phase(1, list(g["gray_h"]), list(g["inv_h"]))
+    if with_cal:
+        cal, _ = golden_calibration()
+        o.set_calibration(*cal)
+        o.compute_c_p_map()
+        o.triangulate()
+    return o
+
+
+# A crop is processed as its own small image, so the boundary removal differs from the full-frame
+# run within 3 pixels of the crop border (the scan's `visited` logic looks 2 pixels up/left and the
+# crop border is never scanned); everything is compared on the crop interior.
+I = np.s_[3:-3, 3:-3]
+
+
+@pytest.mark.parametrize("name", CROPS)
+def test_stage3_kat(name):
+    """Stage 3 is pinned by the reference's Wrapped_phase_image.bmp (both axes), bit exact."""
+    g = load_golden(name)
+    o = _run_crop(g, with_cal=False)
+    for a, k in ((0, "kat_wrapped_v"), (1, "kat_wrapped_h")):
+        assert np.array_equal(o.debug_image(3, a)[I], g[k][I])
+        assert np.array_equal(o.valid_map(a)[I] == 1, g[k][I] != 0)
+
+
+@pytest.mark.parametrize("name", CROPS)
+def test_stage4_kat(name):
+    """Stage 4 is pinned by the reference's Unwrapped_phase_{vertical,horizontal}.bmp, bit exact."""
+    g = load_golden(name)
+    o = _run_crop(g, with_cal=False)
+    for a, k in ((0, "kat_unwrapped_v"), (1, "kat_unwrapped_h")):
+        assert np.array_equal(o.debug_image(4, a)[I], g[k][I])
+
+
+@pytest.mark.parametrize("name", CROPS)
+def test_crop_matches_full_frame_run(name):
+    """The crop run (with the crop origin for stage 7) reproduces the full-frame oracle run."""
+    g = load_golden(name)
+    o = _run_crop(g)
+    v = g["valid"][I] == 1
+    assert np.array_equal(o.valid_map(2)[I] == 1, v)
+    assert np.array_equal(o.code(0)[I][v], g["code_v"][I][v])
+    assert np.array_equal(o.code(1)[I][v], g["code_h"][I][v])
+    assert np.array_equal(o.unwrapped_phi(0)[I][v], g["unwrapped_v"][I][v])
+    assert np.array_equal(o.unwrapped_phi(1)[I][v], g["unwrapped_h"][I][v])
+    assert np.array_equal(o.c_p_map()[I][v], g["c_p_map"][I][v])
+    assert np.array_equal(o.intersection_points()[I][v], g["points"][I][v])
+    A_cam, A_proj = o.projection_matrices()
+    assert np.array_equal(A_cam, g["A_cam"]) and np.array_equal(A_proj, g["A_proj"])
+
+
+def closed_form_valid(S):
+    """Closed form of 3/wrapped_phase.cpp:253-279 used by the HIP kernels (see sl3d_kernels.hip)."""
+    H, W = S.shape
+    V = S == 1
+
+    def at(A, dx, dy, fill):
+        out = np.full_like(A, fill)
+        out[max(-dy, 0):H + min(-dy, 0), max(-dx, 0):W + min(-dx, 0)] = A[max(dy, 0):H + min(dy, 0), max(dx, 0):W + min(dx, 0)]
+        return out  # out[p] = A[p + d]
+
+    interior = np.zeros((H, W), bool)
+    interior[1:-1, 1:-1] = True
+    later, earlier = [(1, 0), (-1, 1), (0, 1), (1, 1)], [(-1, -1), (0, -1), (1, -1), (-1, 0)]
+    L = np.zeros((H, W), bool)
+    for d in later:
+        L |= ~at(V, *d, True)
+    border_unsel = ~interior & ~V
+    B = np.zeros((H, W), bool)
+    for d in earlier:
+        B |= at(border_unsel, *d, False)
+    OK = V | (interior & (L | B))
+    out = V & ~L
+    for d in earlier:
+        out &= at(OK, *d, True)
+    return np.where(interior, out, V)
+
+
+def test_boundary_removal_closed_form():
+    """The scan-order dependent boundary removal has the closed form the kernels implement."""
+    rng = np.random.default_rng(7)
+    H, W = 37, 53
+    fr = [np.zeros((H, W), np.uint8)] * 3
+    o = Oracle(W, H, 64, 64, 3, 3, 8, 8)
+    for trial in range(120):
+        p = rng.choice([0.02, 0.1, 0.3, 0.5, 0.8, 0.95, 1.0])
+        S = (rng.random((H, W)) < p).astype(np.uint8)
+        if trial % 3 == 0:
+            S[:] = 0
+            for _ in range(4):
+                y, x, h, w = rng.integers(0, H), rng.integers(0, W), rng.integers(1, 20), rng.integers(1, 20)
+                S[y:y + h, x:x + w] = 1
+            S ^= (rng.random((H, W)) < 0.02).astype(np.uint8)
+        if trial % 5 == 0:
+            S[rng.integers(0, H)] = 2  # only the value 1 selects a pixel
+        o.set_mask(S)
+        o.compute_wrapped_phase(0, fr)
+        assert np.array_equal(o.valid_map(0).astype(bool), closed_form_valid(S)), trial
+
+
+def test_boundary_removal_is_not_an_erosion():
+    """Documents the finding: a 3x3 erosion would also remove the top row (it would keep [4:8, 4:8])."""
+    S = np.zeros((12, 12), np.uint8)
+    S[3:9, 3:9] = 1
+    o = Oracle(12, 12, 64, 64, 3, 3, 8, 8)
+    o.set_mask(S)
+    o.compute_wrapped_phase(0, [np.zeros((12, 12), np.uint8)] * 3)
+    v = o.valid_map(0)
+    expect = np.zeros_like(S)
+    expect[3:8, 4:8] = 1  # left/right columns and the bottom row go (E, SW, S, SE are 'later'), the top row stays
+    assert np.array_equal(v, expect)
+
+
+def test_float_row_index_matches_integer_below_2p24():
+    """7/triangulation.cpp:265 derives the row with float division; exact for the sizes we test."""
+    for W, H in ((640, 480), (1920, 1080), (4096, 3000)):
+        f = np.arange(W * H, dtype=np.int64)
+        lit = np.floor(f.astype(np.float32) / np.float32(W)).astype(np.int64)
+        assert np.array_equal(lit, f // W)
+
+
+def test_synthetic_capture_decodes(synth):
+    """Oracle on a synthetic plane: decoded projector coordinates follow the analytic ones except where the
+    22/7 pattern period drifts against the Gray code (a property of the reference's patterns)."""
+    W, H, PW, PH, N, fw = 320, 240, 512, 384, 7, 4
+    cap = synth.make_capture(W, H, PW, PH, N, N, fw, fw)
+    o = Oracle(W, H, PW, PH, N, N, fw, fw)
+    o.set_mask(cap["mask"])
+    o.set_calibration(*synth.cal_tuple(cap["cal"]))
+    o.run_scan(cap["planes_v"], cap["planes_h"])
+    v = (o.valid_map(2) == 1) & cap["lit"]
+    assert v.mean() > 0.7
+    cp = o.c_p_map()
+    ex = np.abs(cp[..., 0] - cap["xp"])[v]
+    ey = np.abs(cp[..., 1] - cap["yp"])[v]
+    # errors are either sub-pixel (8-bit quantisation) or exactly one fringe period
+    assert np.mean(ex < 1.5) > 0.9 and np.mean(ey < 1.5) > 0.9
+    assert ex.max() < fw + 1.5 and ey.max() < fw + 1.5
+    good = v & (np.abs(cp[..., 0] - cap["xp"]) < 1.5) & (np.abs(cp[..., 1] - cap["yp"]) < 1.5)
+    err = np.linalg.norm(o.intersection_points() - cap["world"], axis=-1)[good]
+    assert np.median(err) < 0.5  # mm, 8-bit phase noise through a ~100 mm stand-off
+
+
+def test_point_cloud_order():
+    """O1: compaction in row-major scan order with the double -> float cast."""
+    g = load_golden("real_edge")
+    o = _run_crop(g)
+    cloud = o.point_cloud()
+    v = o.valid_map(2) == 1
+    assert cloud.shape == (int(v.sum()), 3)
+    assert np.array_equal(cloud, o.intersection_points()[v].astype(np.float32))
