@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -30,9 +32,9 @@ struct sl3d_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<void *> allocs;
     std::string err;
-    uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr;
+    uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
     float *d_points = nullptr;
-    float *d_atab = nullptr;  // two tables back to back
+    DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
     size_t mask_rows = 0;
 };
 
@@ -81,10 +83,11 @@ static int dev_alloc(sl3d_ctx *c, T **p, size_t count)
     return SL3D_OK;
 }
 
-// The wrapped phase is a function of two small integers (t1 in [-255,255], t2 in [-510,510]),
-// so the double-precision libm atan2 the reference calls (3/wrapped_phase.cpp:175) is tabulated
-// once on the host: table 0 = (float)atan2(t1,t2), table 1 = the same value after stage 4's
-// in-place `+= Pi` (4/phase_unwrap.cpp:290,308).
+// The wrapped phase is a function of two small integers (t1 in [-255,255], t2 in [-510,510]).
+// The kernels evaluate it in fp64 (atan2_lattice); this table of the double-precision libm atan2
+// the reference calls (3/wrapped_phase.cpp:175) -- table 0 = (float)atan2(t1,t2), table 1 = the
+// value after stage 4's in-place `+= Pi` (4/phase_unwrap.cpp:290,308) -- is what the device
+// function is verified against, exhaustively, before the first context of a process is handed out.
 static void build_atan_tables(std::vector<float> &tab)
 {
     const size_t n = (size_t)SL3D_ATAN_T1 * SL3D_ATAN_T2;
@@ -151,6 +154,7 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     P.col0 = c.col0; P.row0 = c.row0; P.PW = c.proj_width; P.PH = c.proj_height;
     P.F = c.n_fringe; P.Nv = c.n_gray_v; P.Nh = c.n_gray_h; P.fwv = c.fringe_width_v; P.fwh = c.fringe_width_h;
     P.ncodes_v = c.n_codes_v; P.ncodes_h = c.n_codes_h;
+    P.ablate = getenv("SL3D_ABLATE") ? atoi(getenv("SL3D_ABLATE")) : 0;
     P.pitch = (c.width + 15) & ~15;
     P.planes_per_view = 2 * P.F + 2 * P.Nv + 2 * P.Nh;
     P.plane_stride = (size_t)P.pitch * P.H;
@@ -160,6 +164,11 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     P.mask_view_stride = (size_t)P.mpitch * x->mask_rows;
     P.px_view_stride = (size_t)P.pitch * P.H;
 
+    if ((P.view_stride >> 32) != 0) {
+        g_create_err = "one view's frame stack exceeds 4 GiB: shard the frame by rows";
+        sl3d_destroy(x);
+        return SL3D_E_UNSUPPORTED;
+    }
     const size_t V = (size_t)c.max_views;
     int rc;
 #define ALLOC(ptr, count)                                              \
@@ -172,19 +181,42 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     ALLOC(x->d_mask, V * P.mask_view_stride);
     ALLOC(x->d_points, V * P.px_view_stride * 3);
     ALLOC(x->d_valid, V * P.px_view_stride);
-    ALLOC(x->d_atab, (size_t)2 * SL3D_ATAN_T1 * SL3D_ATAN_T2);
+    ALLOC(x->d_cal, 1);
+    ALLOC(x->d_band, V * P.px_view_stride);
     CREATE_CHK(hipMemsetAsync(x->d_mask, 0, V * P.mask_view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_frames, 0, V * P.view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_valid, 0, V * P.px_view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_points, 0, V * P.px_view_stride * 3 * sizeof(float), x->stream));
-    P.frames = x->d_frames; P.mask = x->d_mask; P.points = x->d_points; P.valid = x->d_valid;
+    CREATE_CHK(hipMemsetAsync(x->d_band, 0, V * P.px_view_stride, x->stream));
+    P.frames = x->d_frames; P.mask = x->d_mask; P.points = x->d_points; P.valid = x->d_valid; P.band = x->d_band;
     {
-        std::vector<float> tab;
-        build_atan_tables(tab);
-        CREATE_CHK(hipMemcpyAsync(x->d_atab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, x->stream));
-        CREATE_CHK(hipStreamSynchronize(x->stream));
-        P.atab_phi = x->d_atab;
-        P.atab_shift = x->d_atab + (size_t)SL3D_ATAN_T1 * SL3D_ATAN_T2;
+        // one-time (per process and device) proof that the device atan2 reproduces the host libm bit for bit
+        static std::mutex mu;
+        static std::set<int> verified;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!verified.count(c.device)) {
+            std::vector<float> tab;
+            build_atan_tables(tab);
+            const size_t n = (size_t)SL3D_ATAN_T1 * SL3D_ATAN_T2;
+            float *d_tab = nullptr;
+            unsigned *d_cnt = nullptr, h_cnt = 0;
+            CREATE_CHK(hipMalloc((void **)&d_tab, 2 * n * sizeof(float)));
+            CREATE_CHK(hipMalloc((void **)&d_cnt, sizeof(unsigned)));
+            CREATE_CHK(hipMemcpyAsync(d_tab, tab.data(), 2 * n * sizeof(float), hipMemcpyHostToDevice, x->stream));
+            CREATE_CHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned), x->stream));
+            CREATE_CHK((hipError_t)launch_atan_selfcheck(d_tab, d_tab + n, d_cnt, x->stream));
+            CREATE_CHK(hipMemcpyAsync(&h_cnt, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
+            CREATE_CHK(hipStreamSynchronize(x->stream));
+            (void)hipFree(d_tab);
+            (void)hipFree(d_cnt);
+            if (h_cnt != 0) {
+                g_create_err = "device atan2 differs from the host libm atan2 on " + std::to_string(h_cnt) +
+                               " of 521731 lattice points: bit-exact parity cannot be guaranteed on this host/GPU pair";
+                sl3d_destroy(x);
+                return SL3D_E_UNSUPPORTED;
+            }
+            verified.insert(c.device);
+        }
     }
     if (x->keep) {
         const size_t n = V * P.px_view_stride;
@@ -262,6 +294,9 @@ static void fill_intr(Intr &I, const double K[9], const double d[5])
     I.k1 = d[0]; I.k2 = d[1]; I.p1 = d[2]; I.p2 = d[3]; I.k3 = d[4];
     I.has_dist = (d[0] != 0 || d[1] != 0 || d[2] != 0 || d[3] != 0 || d[4] != 0) ? 1 : 0;
     I.affine = (K[6] == 0 && K[7] == 0 && K[8] == 1) ? 1 : 0;
+    I.has_tan = (d[2] != 0 || d[3] != 0) ? 1 : 0;
+    I.plain = (I.affine && K[1] == 0 && K[3] == 0) ? 1 : 0;
+    I.identity = (I.plain && !I.has_dist) ? 1 : 0;
 }
 
 extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
@@ -273,6 +308,9 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     projection_matrix(Kp, rp, tp, x->C.Ap);
     fill_intr(x->C.cam, Kc, dc);
     fill_intr(x->C.proj, Kp, dp);
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    HIPCHK(x, hipStreamSynchronize(x->stream));  // no launch may still be reading the previous constants
+    HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
     x->have_cal = true;
     return SL3D_OK;
 }
@@ -305,6 +343,34 @@ extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t str
         }
     }
     HIPCHK(x, hipMemcpyAsync(x->d_mask + (size_t)view * P.mask_view_stride, host.data(), host.size(), hipMemcpyHostToDevice, x->stream));
+
+    // Valid map of the quads within 3 pixels of the frame border, by the generic closed form of the
+    // reference's boundary removal (3/wrapped_phase.cpp:253-279; derivation in sl3d_kernels.hip).
+    // The fused kernel evaluates the interior with byte-parallel logic and reads this band at the border.
+    const int FW = P.fullW, FH = P.fullH;
+    auto V = [&](int gx, int gy) { return gx >= 0 && gy >= 0 && gx < FW && gy < FH && m[(size_t)gy * stride + gx] == 1; };
+    auto interior = [&](int gx, int gy) { return gx >= 1 && gx <= FW - 2 && gy >= 1 && gy <= FH - 2; };
+    auto L = [&](int gx, int gy) { return !V(gx + 1, gy) || !V(gx - 1, gy + 1) || !V(gx, gy + 1) || !V(gx + 1, gy + 1); };
+    auto BU = [&](int gx, int gy) { return gx >= 0 && gy >= 0 && gx < FW && gy < FH && !interior(gx, gy) && !V(gx, gy); };
+    auto Bq = [&](int gx, int gy) { return BU(gx - 1, gy - 1) || BU(gx, gy - 1) || BU(gx + 1, gy - 1) || BU(gx - 1, gy); };
+    auto OK = [&](int gx, int gy) { return V(gx, gy) || (interior(gx, gy) && (L(gx, gy) || Bq(gx, gy))); };
+    auto valid = [&](int gx, int gy) {
+        if (!V(gx, gy)) return false;
+        if (!interior(gx, gy)) return true;
+        if (L(gx, gy)) return false;
+        return OK(gx - 1, gy - 1) && OK(gx, gy - 1) && OK(gx + 1, gy - 1) && OK(gx - 1, gy);
+    };
+    std::vector<uint8_t> band(P.px_view_stride, 0);
+    for (int r = 0; r < P.H; r++) {
+        const int gy = P.row0 + r;
+        const bool row_band = !(gy >= 3 && gy <= FH - 4);
+        for (int c = 0; c < P.W; c += 4) {
+            const int gx = P.col0 + c;
+            if (!row_band && gx >= 4 && gx + 3 <= FW - 5) continue;  // same test as quad_valid_bits()
+            for (int k = 0; k < 4 && c + k < P.W; k++) band[(size_t)r * P.pitch + c + k] = valid(gx + k, gy) ? 1 : 0;
+        }
+    }
+    HIPCHK(x, hipMemcpyAsync(x->d_band + (size_t)view * P.px_view_stride, band.data(), band.size(), hipMemcpyHostToDevice, x->stream));
     HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
@@ -339,6 +405,8 @@ extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
                              hipMemcpyDeviceToDevice, x->stream));
     HIPCHK(x, hipMemcpyAsync(x->d_mask + (size_t)dst * P.mask_view_stride, x->d_mask + (size_t)src * P.mask_view_stride,
                              P.mask_view_stride, hipMemcpyDeviceToDevice, x->stream));
+    HIPCHK(x, hipMemcpyAsync(x->d_band + (size_t)dst * P.px_view_stride, x->d_band + (size_t)src * P.px_view_stride, P.px_view_stride,
+                             hipMemcpyDeviceToDevice, x->stream));
     return SL3D_OK;
 }
 
@@ -396,7 +464,7 @@ extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
-    return launched(x, launch_fused(x->P, x->C, first_view, n_views, x->keep, x->stream));
+    return launched(x, launch_fused(x->P, x->d_cal, first_view, n_views, x->keep, x->stream));
 }
 
 extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
@@ -406,7 +474,7 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
-    rc = launched(x, launch_fused(x->P, x->C, first_view, n_views, x->keep, x->stream));
+    rc = launched(x, launch_fused(x->P, x->d_cal, first_view, n_views, x->keep, x->stream));
     if (rc) return rc;
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));

@@ -19,6 +19,9 @@ struct Intr {
     double k1, k2, p1, p2, k3;
     int has_dist;                 // any distortion coefficient non-zero (else the 5 iterations are an exact no-op)
     int affine;                   // last row of K is (0,0,1): the homogeneous divide is an exact no-op
+    int has_tan;                  // p1 or p2 non-zero
+    int plain;                    // affine and K[1] == K[3] == 0 (no skew)
+    int identity;                 // plain and no distortion: undistort + re-project returns the pixel itself
 };
 
 // Per-scan constants of stage 7 (T0): A = K*[R|t] for camera and projector.
@@ -36,6 +39,7 @@ struct KParams {
     int F, Nv, Nh;
     int fwv, fwh;
     int ncodes_v, ncodes_h;
+    int ablate;                // debug only (env SL3D_ABLATE): bit0 skip fp64 chain, bit1 skip table gathers, bit2 skip camera undistortion
     int pitch;                 // bytes per row of every u8 plane (multiple of 16)
     int planes_per_view;
     size_t plane_stride;       // pitch * H
@@ -44,8 +48,7 @@ struct KParams {
     size_t mask_view_stride;   // mpitch * (H + 2*SL3D_MASK_HALO)
     const uint8_t *frames;
     const uint8_t *mask;       // 0/1 bytes, halo included
-    const float *atab_phi;     // (float)atan2(t1,t2)                        [stage 3 value]
-    const float *atab_shift;   // (float)((double)atab_phi + 22.0/7.0)       [value after stage 4's in-place shift]
+    const uint8_t *band;       // [view][row][pitch]: final valid bytes of the quads within 3 px of the frame border (set_mask)
     // dense results
     float *points;             // [view][row][pitch][3] f32
     uint8_t *valid;            // [view][row][pitch]    merged valid map
@@ -62,10 +65,11 @@ struct KParams {
 };
 
 // launchers (sl3d_kernels.hip); `stream` is a hipStream_t
-int launch_fused(const KParams &P, const DevCal &C, int first_view, int n_views, bool keep, void *stream);
+int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_views, bool keep, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);
 int launch_corr(const KParams &P, int view, void *stream);
 int launch_tri(const KParams &P, const DevCal &C, int view, void *stream);
+int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 
 }  // namespace sl3d

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sl3d_internal.h"
 
@@ -71,7 +72,7 @@ struct MaskView {
     {
         return V(gx, gy) || (interior(gx, gy) && (L(gx, gy) || B(gx, gy)));
     }
-    // generic (any position) evaluation of the closed form
+    // generic (any position) evaluation of the closed form (used by the per-stage kernel k_wrap)
     __device__ bool valid(int gx, int gy) const
     {
         if (!V(gx, gy)) return false;
@@ -94,7 +95,7 @@ __device__ __forceinline__ MaskView mask_view(const KParams &P, int view)
 // Fast path: 3 rows x 3 aligned dwords of 0/1 bytes, byte-parallel logic (all neighbours are
 // interior pixels of the frame, so B == false and interior == true).  Pixels within 3 of the
 // frame border take the generic path.
-__device__ __forceinline__ unsigned quad_valid_bits(const KParams &P, const MaskView &mv, int cq, int row)
+__device__ __forceinline__ unsigned quad_valid_bits(const KParams &P, const MaskView &mv, int view, int cq, int row)
 {
     const int c = cq * 4, gx = P.col0 + c, gy = P.row0 + row;
     unsigned bits = 0;
@@ -124,9 +125,10 @@ __device__ __forceinline__ unsigned quad_valid_bits(const KParams &P, const Mask
 #undef SHR2
         bits = (v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u);
     } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (mv.valid(gx + k, gy)) bits |= 1u << k;
+        // within 3 pixels of the frame border: the valid bytes of these few quads were evaluated by
+        // sl3d_set_mask (host, generic closed form) into the band plane
+        const unsigned w = *(const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + c);
+        bits = (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
     }
     // pixels of the pitch padding are not part of the window
     const int inside = P.W - c;  // number of window pixels in this quad (may be <= 0 or >= 4)
@@ -137,26 +139,99 @@ __device__ __forceinline__ unsigned quad_valid_bits(const KParams &P, const Mask
 // ------------------------------------------------------------------------------------------------
 // bit-exact phase chain
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int atan_index(int t1, int t2) { return (t1 + 255) * SL3D_ATAN_T2 + (t2 + 510); }
-
-// t1,t2 of create_wrapped_phase: 3-step 3/wrapped_phase.cpp:171-172, 4-step :195-196 (exact small integers)
-__device__ __forceinline__ int fringe_index(int F, int i0, int i1, int i2, int i3)
+// 1/d to ~1 ulp: v_rcp_f64 seed + two Newton steps
+__device__ __forceinline__ double recip(double d)
 {
-    if (F == 3) return atan_index(i0 - i2, 2 * i1 - i0 - i2);
-    return atan_index(i3 - i1, i0 - i2);
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
+// Wrapped phase without a table: (float)atan2((double)t1,(double)t2) for the small integers the
+// fringe frames produce (|t1| <= 255, |t2| <= 510), evaluated in fp64 so that, after rounding to
+// float, it equals the double-precision libm atan2 the reference calls (3/wrapped_phase.cpp:175)
+// on EVERY point of that lattice.  That equality is not assumed: sl3d_create() runs
+// k_atan_selfcheck over all 521,731 points against a table built with the host's libm and refuses
+// to create a context if a single value differs (tests/test_gpu_parity.py repeats the check).
+// Method: octant reduction on the integers, a second reduction lo/hi > tan(pi/8) -> (hi-lo)/(hi+lo)
+// (still a quotient of exact integers, so there is exactly one division), atan(r) = r + r*z*Q(z),
+// z = r^2, Q of degree 10 (|error| < 1e-17 on [0, tan(pi/8)]), pi/4, pi/2, pi as hi+lo pairs.
+// A 2 MB gather table costs more than this arithmetic: every wave-level gather pulls 64 separate
+// 128-B lines through the vector L1 for 256 useful bytes (tools/membench.hip, flags=4: -50%).
+__device__ __forceinline__ float atan2_lattice(int t1, int t2)
+{
+    const int ay = abs(t1), ax = abs(t2);
+    const int lo = min(ay, ax), hi = max(ay, ax);
+    const bool swap = ay > ax;
+    const bool red = 169 * lo > 70 * hi;  // lo/hi > 0.414201 (just below tan(pi/8))
+    const int num = red ? hi - lo : lo, den = red ? hi + lo : hi;
+    // correctly rounded num/den (den == 0 only for t1 == t2 == 0, where num == 0 as well: use 0/1)
+    const double n = (double)num, d = (double)(den == 0 ? 1 : den);
+    const double y = recip(d), q0 = n * y;
+    const double r = fma(fma(-q0, d, n), y, q0);
+    // atan(r) = r + r*z*Q(z), Q of degree 10 in z = r^2, Estrin evaluation (short dependency chain)
+    const double z = r * r, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double q01 = fma(0x1.999999999934ap-3, z, -0x1.5555555555555p-2);
+    const double q23 = fma(0x1.c71c7185314cbp-4, z, -0x1.24924924360cbp-3);
+    const double q45 = fma(0x1.3b1262d95579ep-4, z, -0x1.745d0b26b83e7p-4);
+    const double q67 = fma(0x1.dfe61e80903d2p-5, z, -0x1.10fa75382537fp-4);
+    const double q89 = fma(0x1.41603647c7a7cp-5, z, -0x1.a098bb6ba4941p-5);
+    const double q0123 = fma(q23, z2, q01);
+    const double q4567 = fma(q67, z2, q45);
+    const double q89a = fma(-0x1.3a2b7a07caea9p-6, z2, q89);
+    const double p = fma(q89a, z8, fma(q4567, z4, q0123));
+    const double a = fma(r, z * p, r);
+    // octant / quadrant: phi = C +- a with C in {0, pi/4, pi/2} as hi+lo pairs, then pi - phi, then the sign
+    const double PIO4_HI = 0x1.921fb54442d18p-1, PIO4_LO = 0x1.1a62633145c07p-55;
+    const double PI_HI = 0x1.921fb54442d18p+1, PI_LO = 0x1.1a62633145c07p-53;
+    // !swap,!red: a | !swap,red: pi/4 - a | swap,red: pi/4 + a | swap,!red: pi/2 - a
+    const bool neg_a = swap != red;              // subtract a
+    const double chi = (swap || red) ? ((swap && !red) ? 2.0 * PIO4_HI : PIO4_HI) : 0.0;
+    const double clo = (swap || red) ? ((swap && !red) ? 2.0 * PIO4_LO : PIO4_LO) : 0.0;
+    const double sa = neg_a ? -a : a;
+    double phi = chi + (sa + clo);               // chi - (a - clo) == chi + (-a + clo) exactly (negation is exact)
+    phi = t2 < 0 ? PI_HI - (phi - PI_LO) : phi;
+    phi = t1 < 0 ? -phi : phi;
+    return (float)phi;
+}
+
+// (t1,t2) of create_wrapped_phase: 3-step 3/wrapped_phase.cpp:171-172, 4-step :195-196 (exact small integers)
+__device__ __forceinline__ float wrapped_phase(int F, int i0, int i1, int i2, int i3)
+{
+    if (F == 3) return atan2_lattice(i0 - i2, 2 * i1 - i0 - i2);
+    return atan2_lattice(i3 - i1, i0 - i2);
+}
+
+// the value wrapped_phi holds after stage 4's in-place `+= Pi` (4/phase_unwrap.cpp:290,308)
+__device__ __forceinline__ float shift_pi(float phi) { return (float)((double)phi + PI_REF); }
+
+// Correctly rounded division by a constant without the IEEE divide expansion (Markstein): with
+// y = RN(1/c), q0 = RN(a*y), r = a - q0*c (exact, one fma), q = RN(q0 + r*y) equals RN(a/c).
+// tests/test_exactdiv.py proves q == a/c exhaustively for the two uses below: c = 7 over every
+// a = 44*code, code < 2^20, and c = 44/7 over every float a in [5e-4, 6e4] (all absolute phases).
+__device__ __forceinline__ double div_exact(double a, double c, double y)
+{
+    const double q0 = a * y;
+    const double r = fma(-q0, c, a);
+    return fma(r, y, q0);
 }
 
 // unwrapped = wrapped(+Pi already applied) + code*2.0*Pi          4/phase_unwrap.cpp:290-291, :308-309
+// code*2.0*Pi expands to ((code*2.0)*22.0)/7.0; the two products are exact integers (= 44*code)
 __device__ __forceinline__ float unwrap_value(float wrapped_shifted, int code)
 {
-    return (float)((double)wrapped_shifted + (double)code * 2.0 * PI_REF);
+    const double k = div_exact((double)(code * 44), 7.0, 1.0 / 7.0);
+    return (float)((double)wrapped_shifted + k);
 }
 
 // lrint(fw*(phi/(2.0*Pi))) with the FE_INVALID and range rejections   5/compute_correspondance.cpp:648-675
-// returns true if the coordinate is accepted
+// returns true if the coordinate is accepted.  phi is 0 (unset) or a positive finite absolute phase.
 __device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, long &out)
 {
-    const double a = (double)fw * ((double)unwrapped / (2.0 * PI_REF));
+    const double c = 2.0 * PI_REF;  // (2.0*Pi) -> (2.0*22.0)/7.0, folded at compile time exactly as on the host
+    const double a = (double)fw * div_exact((double)unwrapped, c, 1.0 / c);
     const double r = rint(a);  // round-half-even, the default rounding mode lrint runs under
     // FE_INVALID <=> NaN, inf or outside long; those and out-of-range values both clear the pixel
     const bool ok = (r >= 0.0) && (r <= (double)(limit - 1));
@@ -169,27 +244,46 @@ __device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, l
 // ------------------------------------------------------------------------------------------------
 // T1: cvUndistortPoints (5 fixed-point iterations) then K*(x,y,1) and the homogeneous divide
 //     7/triangulation.cpp:290-307 (camera), :363-378 (projector)
-__device__ __forceinline__ void undistort_reproject(double px, double py, const Intr &I, double &u, double &v)
+// Terms whose coefficient is exactly zero are skipped through wave-uniform flags; each skipped term is
+// an exact zero in the reference's arithmetic, so the value is unchanged.
+template <typename IntrT>
+__device__ __forceinline__ void undistort_reproject(double px, double py, const IntrT &I, double &u, double &v)
 {
     const double x0 = (px - I.cx) * I.ifx, y0 = (py - I.cy) * I.ify;
     double x = x0, y = y0;
     if (I.has_dist) {
+        if (I.has_tan) {
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const double r2 = fma(x, x, y * y);
-            const double icdist = 1.0 / fma(fma(fma(I.k3, r2, I.k2), r2, I.k1), r2, 1.0);
-            const double dx = fma(2.0 * I.p1 * x, y, I.p2 * fma(2.0 * x, x, r2));
-            const double dy = fma(I.p1, fma(2.0 * y, y, r2), 2.0 * I.p2 * x * y);
-            x = (x0 - dx) * icdist;
-            y = (y0 - dy) * icdist;
+            for (int j = 0; j < 5; j++) {
+                const double r2 = fma(x, x, y * y);
+                const double icdist = recip(fma(fma(fma(I.k3, r2, I.k2), r2, I.k1), r2, 1.0));
+                const double dx = fma(2.0 * I.p1 * x, y, I.p2 * fma(2.0 * x, x, r2));
+                const double dy = fma(I.p1, fma(2.0 * y, y, r2), 2.0 * I.p2 * x * y);
+                x = (x0 - dx) * icdist;
+                y = (y0 - dy) * icdist;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const double r2 = fma(x, x, y * y);
+                const double icdist = recip(fma(fma(fma(I.k3, r2, I.k2), r2, I.k1), r2, 1.0));
+                x = x0 * icdist;
+                y = y0 * icdist;
+            }
         }
     }
-    double uh = fma(I.K[0], x, fma(I.K[1], y, I.K[2]));
-    double vh = fma(I.K[3], x, fma(I.K[4], y, I.K[5]));
-    if (!I.affine) {
-        const double wh = fma(I.K[6], x, fma(I.K[7], y, I.K[8]));
-        uh /= wh;
-        vh /= wh;
+    double uh, vh;
+    if (I.plain) {  // K = [fx 0 cx; 0 fy cy; 0 0 1]
+        uh = fma(I.K[0], x, I.K[2]);
+        vh = fma(I.K[4], y, I.K[5]);
+    } else {
+        uh = fma(I.K[0], x, fma(I.K[1], y, I.K[2]));
+        vh = fma(I.K[3], x, fma(I.K[4], y, I.K[5]));
+        if (!I.affine) {
+            const double iw = recip(fma(I.K[6], x, fma(I.K[7], y, I.K[8])));
+            uh *= iw;
+            vh *= iw;
+        }
     }
     u = uh;
     v = vh;
@@ -197,33 +291,26 @@ __device__ __forceinline__ void undistort_reproject(double px, double py, const 
 
 // T2 + T3: P (4x3), F (4x1), V = (P^T P)^-1 P^T F   7/triangulation.cpp:1152-1168,1181-1188,1202-1206
 // evaluated as adj(P^T P) (P^T F) / det(P^T P) (symmetric normal matrix; within 1e-12 of the literal order)
-__device__ __forceinline__ void triangulate_px(const DevCal &C, double u, double v, double up, double vp, double X[3])
+template <typename AP>
+__device__ __forceinline__ void tri_row(AP A, double t, double &m00, double &m01, double &m02, double &m11,
+                                        double &m12, double &m22, double &g0, double &g1, double &g2, int r)
 {
-    double p[4][3], f[4];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        p[0][j] = fma(-u, C.Ac[8 + j], C.Ac[0 + j]);
-        p[1][j] = fma(-v, C.Ac[8 + j], C.Ac[4 + j]);
-        p[2][j] = fma(-up, C.Ap[8 + j], C.Ap[0 + j]);
-        p[3][j] = fma(-vp, C.Ap[8 + j], C.Ap[4 + j]);
-    }
-    f[0] = fma(C.Ac[11], u, -C.Ac[3]);
-    f[1] = fma(C.Ac[11], v, -C.Ac[7]);
-    f[2] = fma(C.Ap[11], up, -C.Ap[3]);
-    f[3] = fma(C.Ap[11], vp, -C.Ap[7]);
+    // row of P: A[r][0..2] - t*A[2][0..2]; entry of F: A[2][3]*t - A[r][3]
+    const double p0 = fma(-t, A[8], A[4 * r + 0]), p1 = fma(-t, A[9], A[4 * r + 1]), p2 = fma(-t, A[10], A[4 * r + 2]);
+    const double f = fma(A[11], t, -A[4 * r + 3]);
+    m00 = fma(p0, p0, m00); m01 = fma(p0, p1, m01); m02 = fma(p0, p2, m02);
+    m11 = fma(p1, p1, m11); m12 = fma(p1, p2, m12); m22 = fma(p2, p2, m22);
+    g0 = fma(p0, f, g0); g1 = fma(p1, f, g1); g2 = fma(p2, f, g2);
+}
+
+template <typename CalT>
+__device__ __forceinline__ void triangulate_px(const CalT &C, double u, double v, double up, double vp, double X[3])
+{
     double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0, g0 = 0, g1 = 0, g2 = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        m00 = fma(p[i][0], p[i][0], m00);
-        m01 = fma(p[i][0], p[i][1], m01);
-        m02 = fma(p[i][0], p[i][2], m02);
-        m11 = fma(p[i][1], p[i][1], m11);
-        m12 = fma(p[i][1], p[i][2], m12);
-        m22 = fma(p[i][2], p[i][2], m22);
-        g0 = fma(p[i][0], f[i], g0);
-        g1 = fma(p[i][1], f[i], g1);
-        g2 = fma(p[i][2], f[i], g2);
-    }
+    tri_row(C.Ac, u, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
+    tri_row(C.Ac, v, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
+    tri_row(C.Ap, up, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
+    tri_row(C.Ap, vp, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
     const double c00 = fma(m11, m22, -m12 * m12);
     const double c01 = fma(m02, m12, -m01 * m22);
     const double c02 = fma(m01, m12, -m02 * m11);
@@ -232,7 +319,7 @@ __device__ __forceinline__ void triangulate_px(const DevCal &C, double u, double
     const double c22 = fma(m00, m11, -m01 * m01);
     const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
     // cvInvert returns a zero matrix when det == 0 (then V = 0)
-    const double rdet = det != 0.0 ? 1.0 / det : 0.0;
+    const double rdet = det != 0.0 ? recip(det) : 0.0;
     X[0] = fma(c00, g0, fma(c01, g1, c02 * g2)) * rdet;
     X[1] = fma(c01, g0, fma(c11, g1, c12 * g2)) * rdet;
     X[2] = fma(c02, g0, fma(c12, g1, c22 * g2)) * rdet;
@@ -241,24 +328,47 @@ __device__ __forceinline__ void triangulate_px(const DevCal &C, double u, double
 // ------------------------------------------------------------------------------------------------
 // fused kernel
 // ------------------------------------------------------------------------------------------------
+// Hide a wave-uniform pointer from the optimiser: loads through it can neither be hoisted out of the
+// enclosing loop nor strength-reduced into dozens of live scalar registers.  (Without this the 46 plane
+// addresses and the 60 fp64 calibration constants are kept in SGPRs across the loops; gfx950 has 102, the
+// overflow is spilled to VGPR lanes and re-read with v_readlane -- measured at ~30 % of all VALU issue.)
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const GLOBAL_AS T *opaque(const T *p)
+{
+    asm volatile("" : "+s"(p));
+    return (const GLOBAL_AS T *)p;  // the asm hides the provenance: restate that this is global memory
+}
+__device__ __forceinline__ unsigned opaque_u32(unsigned v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+// dword at (wave-uniform base) + (32-bit lane offset): the saddr + voffset form of global_load_dword
+__device__ __forceinline__ unsigned ldg32(const GLOBAL_AS uint8_t *base, unsigned off)
+{
+    return *(const GLOBAL_AS unsigned *)(base + (size_t)off);
+}
+
+// one pixel, everything after the byte loads: stage 4 unwrap, stage 5, stage 7, stage 8 cast.
+// (cu,cv) = undistorted camera pixel coordinates of this pixel (T1, depends on the pixel only);
+// (wv,wh) = wrapped phases, already shifted by +Pi where stage 4 shifts them.
 struct PixelResult {
     float x, y, z;
     bool valid;
 };
 
-template <bool KEEP>
-__device__ __forceinline__ PixelResult pixel_chain(const KParams &P, const DevCal &C, int gx, int gy, int idx_v, int idx_h,
-                                                   int code_v, int code_h, size_t keep_off)
+template <bool KEEP, typename CalP>
+__device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, int gx, int gy, double cu, double cv,
+                                                   float wv, float wh, int code_v, int code_h, size_t keep_off)
 {
     PixelResult R;
     const float nanv = __builtin_nanf("");
     R.x = R.y = R.z = nanv;
-    // stage 4: the in-place +Pi and the unwrap skip the first/last column (v) or row (h) of the frame
+    // stage 4: the unwrap skips the first/last column (v) or row (h) of the frame; unwrapped stays unset (0 here)
     const bool in_v = gx >= 1 && gx <= P.fullW - 2;  // 4/phase_unwrap.cpp:285
     const bool in_h = gy >= 1 && gy <= P.fullH - 2;  // 4/phase_unwrap.cpp:304
-    const float wv = in_v ? P.atab_shift[idx_v] : P.atab_phi[idx_v];
-    const float wh = in_h ? P.atab_shift[idx_h] : P.atab_phi[idx_h];
-    const float uv = in_v ? unwrap_value(wv, code_v) : 0.0f;  // unwrapped stays unset (0 here) outside the loop range
+    const float uv = in_v ? unwrap_value(wv, code_v) : 0.0f;
     const float uh = in_h ? unwrap_value(wh, code_h) : 0.0f;
     long cx, cy;
     const bool okx = correspond(uv, P.fwv, P.PW, cx);
@@ -271,16 +381,22 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, const DevCa
         P.unwrapped[1][keep_off] = uh;
         P.code[0][keep_off] = code_v;
         P.code[1][keep_off] = code_h;
-        // c_p_map keeps whatever lrint produced even when the pixel is then rejected by the range
-        // test; rejected pixels are never compared, store 0 for those
+        // rejected pixels are never compared; store 0 for those
         P.cpmap[2 * keep_off + 0] = R.valid ? cx : 0;
         P.cpmap[2 * keep_off + 1] = R.valid ? cy : 0;
     }
     if (R.valid) {
-        double u, v, up, vp, X[3];
-        undistort_reproject((double)gx, (double)gy, C.cam, u, v);
-        undistort_reproject((double)cx, (double)cy, C.proj, up, vp);
-        triangulate_px(C, u, v, up, vp, X);
+        double up, vp, X[3];
+        const auto &C = *Cp;
+        if (C.proj.identity) {
+            // no projector distortion and K = [fx 0 cx; 0 fy cy; 0 0 1]: the reference's undistort +
+            // re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px): use x
+            up = (double)cx;
+            vp = (double)cy;
+        } else {
+            undistort_reproject((double)cx, (double)cy, C.proj, up, vp);
+        }
+        triangulate_px(C, cu, cv, up, vp, X);
         R.x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
         R.y = (float)X[1];
         R.z = (float)X[2];
@@ -293,99 +409,196 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, const DevCa
     return R;
 }
 
-template <bool KEEP>
-__global__ __launch_bounds__(256) void k_fused(const KParams P, const DevCal C, int first_view)
+// grid.x covers the quads (4 pixels) of one window, grid.y covers groups of `vpt` views: a lane keeps
+// its 4 pixels and walks through the views of its group, so the camera-side undistortion (the most
+// expensive per-pixel constant of stage 7) is computed once per pixel, not once per pixel per view.
+//
+// Memory-level parallelism: all 2F+2Nv+2Nh plane dwords of a view are requested back to back before
+// the first one is consumed (NMAX is the compile-time unroll bound of the Gray planes; plane indices
+// are clamped to N-1, so the surplus loads of a smaller N re-read a line that is already in L1).
+// A wave therefore has ~12 KiB of HBM requests in flight instead of a round trip per pair of bit planes.
+// Every plane is addressed as (wave-uniform 64-bit plane base) + (one 32-bit lane offset).
+//
+// The 4 pixels of a lane are processed by a ROLLED loop (one copy of the fp64 chain, low VGPR count);
+// per-pixel operands are picked by shifts / selects, and the 48 B of xyz a lane produces are staged
+// through LDS so they leave as three 16-B stores per lane (a wave writes 3 KiB contiguous).
+//
+// FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
+template <bool KEEP, int NMAX, bool FGEN>
+__global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
+    __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
+    const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(q / qpr), cq = (int)(q - (long)row * qpr);
     if (row >= P.H) return;
-    const int view = first_view + blockIdx.y;
-    const MaskView mv = mask_view(P, view);
-    // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
-    const unsigned vbits = P.F == 5 ? 0u : quad_valid_bits(P, mv, cq, row);
-
-    const size_t px = (size_t)view * P.px_view_stride + (size_t)row * P.pitch + (size_t)cq * 4;  // first pixel of the quad
-    float4 *out_xyz = (float4 *)(P.points + 3 * px);
+    const int gx0 = P.col0 + cq * 4, gy = P.row0 + row;
     const float nanv = __builtin_nanf("");
-    float o[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) o[i] = nanv;
-    unsigned vout = 0;
+    float *my_xyz = s_xyz + threadIdx.x * 12;
+    const unsigned lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;  // byte offset of the quad inside any plane
+    const unsigned ps = (unsigned)P.plane_stride;
 
-    if (KEEP) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            for (int a = 0; a < 2; a++) {
-                P.wrapped[a][px + k] = 0.f;
-                P.unwrapped[a][px + k] = 0.f;
-                P.code[a][px + k] = -1;  // 4/phase_unwrap.cpp:143
-                P.valid_axis[a][px + k] = (vbits >> k) & 1u;
-            }
-            P.cpmap[2 * (px + k)] = 0;
-            P.cpmap[2 * (px + k) + 1] = 0;
-            P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
-        }
+    double cu0 = 0, cu1 = 0, cu2 = 0, cu3 = 0, cv0 = 0, cv1 = 0, cv2 = 0, cv3 = 0;
+    if (cq * 4 < P.W && !(P.ablate & 4)) {
+        const auto &C0 = *opaque(Cglobal);
+        undistort_reproject((double)(gx0 + 0), (double)gy, C0.cam, cu0, cv0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the four chains sequential: interleaving them costs ~60 VGPRs
+        undistort_reproject((double)(gx0 + 1), (double)gy, C0.cam, cu1, cv1);
+        __builtin_amdgcn_sched_barrier(0);
+        undistort_reproject((double)(gx0 + 2), (double)gy, C0.cam, cu2, cv2);
+        __builtin_amdgcn_sched_barrier(0);
+        undistort_reproject((double)(gx0 + 3), (double)gy, C0.cam, cu3, cv3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (vbits != 0) {
-        const uint8_t *fb = P.frames + (size_t)view * P.view_stride + (size_t)row * P.pitch + (size_t)cq * 4;
-        const size_t ps = P.plane_stride;
-        // ---- vertical axis planes: fringe F, gray Nv, inverse Nv ----
-        unsigned f[2][4];
-        int code[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        const uint8_t *pl = fb;
+    const int Nv = P.Nv, Nh = P.Nh;
+    const int v_begin = first_view + (int)blockIdx.y * vpt;
+    const int v_end = min(v_begin + vpt, first_view + n_views);
+    for (int view = v_begin; view < v_end; view++) {
+        const MaskView mv = mask_view(P, view);
+        // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
+        const unsigned vbits = (FGEN && F == 5) ? 0u : quad_valid_bits(P, mv, view, cq, row);
+        const size_t px = (size_t)view * P.px_view_stride + (size_t)lane_off;  // first pixel of the quad
+        unsigned vout = 0;
+
+        if (KEEP) {
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const int N = a == 0 ? P.Nv : P.Nh;
-            f[a][0] = *(const unsigned *)(pl);
-            f[a][1] = *(const unsigned *)(pl + ps);
-            f[a][2] = *(const unsigned *)(pl + 2 * ps);
-            f[a][3] = P.F == 4 ? *(const unsigned *)(pl + 3 * ps) : 0u;
-            pl += (size_t)P.F * ps;
-            unsigned b = 0;  // running binary bit per pixel, bit k
-#pragma unroll 2
-            for (int i = 0; i < N; i++) {
-                const unsigned g = *(const unsigned *)(pl + (size_t)i * ps);
-                const unsigned iv = *(const unsigned *)(pl + (size_t)(N + i) * ps);
+            for (int k = 0; k < 4; k++) {
+                for (int a = 0; a < 2; a++) {
+                    P.wrapped[a][px + k] = 0.f;
+                    P.unwrapped[a][px + k] = 0.f;
+                    P.code[a][px + k] = -1;  // 4/phase_unwrap.cpp:143
+                    P.valid_axis[a][px + k] = (vbits >> k) & 1u;
+                }
+                P.cpmap[2 * (px + k)] = 0;
+                P.cpmap[2 * (px + k) + 1] = 0;
+                P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
+            }
+        }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // G_i = (gray - inverse >= 0); B_0 = G_0, B_i = B_{i-1} xor G_i; code = sum B_i 2^(N-1-i)
-                    const unsigned ge = ((g >> (8 * k)) & 255u) >= ((iv >> (8 * k)) & 255u) ? 1u : 0u;  // 4/phase_unwrap.cpp:183
-                    b ^= ge << k;
-                    code[a][k] = code[a][k] * 2 + (int)((b >> k) & 1u);
+        for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
+
+        if (vbits != 0) {
+            // planes of a view: vertical axis (fringe F, gray Nv, inverse Nv), then the horizontal axis
+            const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
+            const unsigned psv = opaque_u32(ps);  // per-view copy: plane offsets are recomputed (SALU), not kept live
+            unsigned f[2][4], g[2][NMAX], iv[2][NMAX];
+            // ---- issue every load of the view ----
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
+                f[a][0] = ldg32(vb, p0 + lane_off);
+                f[a][1] = ldg32(vb, p0 + psv + lane_off);
+                f[a][2] = ldg32(vb, p0 + 2u * psv + lane_off);
+                f[a][3] = (FGEN && F == 4) ? ldg32(vb, p0 + 3u * psv + lane_off) : 0u;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int N = a == 0 ? Nv : Nh;
+                const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
+#pragma unroll
+                for (int i = 0; i < NMAX; i++) {
+                    const unsigned ii = (unsigned)min(i, N - 1);  // clamp: planes beyond N re-read plane N-1 and are ignored below
+                    g[a][i] = ldg32(vb, pg + ii * psv + lane_off);
+                    iv[a][i] = ldg32(vb, pg + ((unsigned)N + ii) * psv + lane_off);
                 }
             }
-            pl += (size_t)2 * N * ps;
-        }
+            // ---- Gray decode: codes of the 4 pixels, 16 bits each (lo = px0 | px1<<16, hi = px2 | px3<<16) ----
+            unsigned clo[2] = {0, 0}, chi[2] = {0, 0};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((vbits >> k) & 1u) {
-                const int sh = 8 * k;
-                const int iv = fringe_index(P.F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
-                const int ih = fringe_index(P.F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
-                const PixelResult R = pixel_chain<KEEP>(P, C, P.col0 + cq * 4 + k, P.row0 + row, iv, ih, code[0][k], code[1][k], px + k);
-                o[3 * k + 0] = R.x;
-                o[3 * k + 1] = R.y;
-                o[3 * k + 2] = R.z;
-                vout |= (R.valid ? 1u : 0u) << (8 * k);
+            for (int a = 0; a < 2; a++) {
+                const int N = a == 0 ? Nv : Nh;
+                unsigned blo = 0, bhi = 0;  // running binary bit of px0/px1 (bits 0,16) and px2/px3
+#pragma unroll
+                for (int i = 0; i < NMAX; i++) {
+                    if (i < N) {
+                        const unsigned gg = g[a][i], ii = iv[a][i];
+                        // G_i = (gray - inverse >= 0)   4/phase_unwrap.cpp:183
+                        const unsigned g0 = (gg & 255u) >= (ii & 255u), g1 = ((gg >> 8) & 255u) >= ((ii >> 8) & 255u);
+                        const unsigned g2 = ((gg >> 16) & 255u) >= ((ii >> 16) & 255u), g3 = (gg >> 24) >= (ii >> 24);
+                        // B_0 = G_0, B_i = B_{i-1} xor G_i; code = sum B_i 2^(N-1-i)   :187-193
+                        blo ^= g0 | (g1 << 16);
+                        bhi ^= g2 | (g3 << 16);
+                        clo[a] = (clo[a] << 1) | blo;
+                        chi[a] = (chi[a] << 1) | bhi;
+                    }
+                }
+            }
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                if ((vbits >> k) & 1u) {
+                    const int sh = 8 * k, sh16 = 16 * (k & 1);
+                    const int code_v = (int)(((k < 2 ? clo[0] : chi[0]) >> sh16) & 0xffffu);
+                    const int code_h = (int)(((k < 2 ? clo[1] : chi[1]) >> sh16) & 0xffffu);
+                    // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
+                    float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
+                    float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
+                    const float wvs = shift_pi(wv), whs = shift_pi(wh);
+                    wv = (gx0 + k >= 1 && gx0 + k <= P.fullW - 2) ? wvs : wv;  // 4/phase_unwrap.cpp:285,290
+                    wh = (gy >= 1 && gy <= P.fullH - 2) ? whs : wh;            // 4/phase_unwrap.cpp:304,308
+                    const double cu = k == 0 ? cu0 : k == 1 ? cu1 : k == 2 ? cu2 : cu3;
+                    const double cv = k == 0 ? cv0 : k == 1 ? cv1 : k == 2 ? cv2 : cv3;
+                    PixelResult R;
+                    if (P.ablate & 1) {
+                        R.x = wv + (float)code_v; R.y = wh + (float)code_h; R.z = (float)(cu + cv); R.valid = true;
+                    } else {
+                        // calibration constants: scalar loads inside the loop (scalar cache), not 100 live SGPRs
+                        R = pixel_chain<KEEP>(P, opaque(Cglobal), gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
+                    }
+                    if (R.valid) {
+                        my_xyz[3 * k + 0] = R.x;
+                        my_xyz[3 * k + 1] = R.y;
+                        my_xyz[3 * k + 2] = R.z;
+                        vout |= 1u << (8 * k);
+                    }
+                }
             }
         }
+        // each lane reads back only what it wrote itself: no barrier needed
+        float4 *out_xyz = (float4 *)(P.points + 3 * px);
+        const float4 *sx = (const float4 *)my_xyz;
+        out_xyz[0] = sx[0];
+        out_xyz[1] = sx[1];
+        out_xyz[2] = sx[2];
+        *(unsigned *)(P.valid + px) = vout;
     }
-    out_xyz[0] = make_float4(o[0], o[1], o[2], o[3]);
-    out_xyz[1] = make_float4(o[4], o[5], o[6], o[7]);
-    out_xyz[2] = make_float4(o[8], o[9], o[10], o[11]);
-    *(unsigned *)(P.valid + px) = vout;
 }
 
-int launch_fused(const KParams &P, const DevCal &C, int first_view, int n_views, bool keep, void *stream)
+template <bool KEEP, bool FGEN>
+static void launch_fused_n(int nmax, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
+{
+    if (nmax <= 6)
+        hipLaunchKernelGGL((k_fused<KEEP, 6, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+    else if (nmax <= 8)
+        hipLaunchKernelGGL((k_fused<KEEP, 8, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+    else if (nmax <= 10)
+        hipLaunchKernelGGL((k_fused<KEEP, 10, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+    else if (nmax <= 12)
+        hipLaunchKernelGGL((k_fused<KEEP, 12, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+    else
+        hipLaunchKernelGGL((k_fused<KEEP, SL3D_MAX_GRAY, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+}
+
+int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_views, bool keep, void *stream)
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
-    dim3 grid((unsigned)((quads + 255) / 256), (unsigned)n_views, 1), block(256, 1, 1);
-    if (keep)
-        hipLaunchKernelGGL(k_fused<true>, grid, block, 0, (hipStream_t)stream, P, C, first_view);
-    else
-        hipLaunchKernelGGL(k_fused<false>, grid, block, 0, (hipStream_t)stream, P, C, first_view);
+    const unsigned bx = (unsigned)((quads + 255) / 256);
+    // views per lane: as many as possible (amortises the camera undistortion) while the grid still
+    // has >= ~8 blocks per CU to balance the tail
+    int vpt = 1;
+    while (vpt < 8 && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
+    if (getenv("SL3D_VPT")) vpt = atoi(getenv("SL3D_VPT"));
+    dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(256, 1, 1);
+    const int nmax = P.Nv > P.Nh ? P.Nv : P.Nh;
+    hipStream_t st = (hipStream_t)stream;
+    if (keep) {
+        if (P.F == 3) launch_fused_n<true, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<true, true>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else {
+        if (P.F == 3) launch_fused_n<false, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<false, true>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    }
     return (int)hipGetLastError();
 }
 
@@ -422,7 +635,7 @@ __global__ __launch_bounds__(256) void k_wrap(const KParams P, int view, int axi
         const int base = axis == 0 ? 0 : (P.F + 2 * P.Nv);
         const int i0 = load_px(P, view, base + 0, row, col), i1 = load_px(P, view, base + 1, row, col);
         const int i2 = load_px(P, view, base + 2, row, col), i3 = P.F == 4 ? load_px(P, view, base + 3, row, col) : 0;
-        phi = P.atab_phi[fringe_index(P.F, i0, i1, i2, i3)];  // :175 / :198
+        phi = wrapped_phase(P.F, i0, i1, i2, i3);  // :175 / :198
         // t3 = 128.0f+127.0f*(phi/(Pi)) (:178), 4-step 127.0f+128.0f*(...) (:199): double arithmetic, rounded to float, then to uchar
         const float t3 = P.F == 3 ? (float)(128.0f + 127.0f * (phi / (PI_REF))) : (float)(127.0f + 128.0f * (phi / (PI_REF)));
         dbg = (uint8_t)(int)t3;
@@ -513,6 +726,25 @@ __global__ __launch_bounds__(256) void k_tri(const KParams P, const DevCal C, in
     P.points[3 * px + 0] = x;
     P.points[3 * px + 1] = y;
     P.points[3 * px + 2] = z;
+}
+
+// Exhaustive self-check of atan2_lattice / shift_pi against the host-libm table (see sl3d_create)
+__global__ __launch_bounds__(256) void k_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= SL3D_ATAN_T1 * SL3D_ATAN_T2) return;
+    const int t1 = i / SL3D_ATAN_T2 - 255, t2 = i % SL3D_ATAN_T2 - 510;
+    const float phi = atan2_lattice(t1, t2);
+    const float sh = shift_pi(phi);
+    // bit comparison: also catches a wrong sign of zero
+    if (__float_as_uint(phi) != __float_as_uint(tab_phi[i]) || __float_as_uint(sh) != __float_as_uint(tab_shift[i])) atomicAdd(mismatches, 1u);
+}
+
+int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream)
+{
+    const int n = SL3D_ATAN_T1 * SL3D_ATAN_T2;
+    hipLaunchKernelGGL(k_atan_selfcheck, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tab_phi, tab_shift, mismatches);
+    return (int)hipGetLastError();
 }
 
 static dim3 px_grid(const KParams &P) { return dim3((unsigned)(((long)P.pitch * P.H + 255) / 256), 1, 1); }

@@ -1,0 +1,192 @@
+// membench.hip -- access-pattern microbenchmark behind the fused kernel's data-path design.
+// Streams P byte planes of n pixels (like the 47 planes of a view) and writes 13 B/pixel, with
+//   mode 0: one dword  (4 px)  per lane per plane  -> 256 B per wave-instruction
+//   mode 1: one dwordx4 (16 px) per lane per plane  -> 1 KiB per wave-instruction, registers
+//   mode 2: dwordx4 global->LDS DMA (global_load_lds), tile of 1024 px per 256-thread block, then ds_read_b32
+// Build: hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o tools/membench ; run: tools/membench [planes] [Mpx]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int P>
+__global__ __launch_bounds__(256) void k_dword(const uint8_t *in, size_t plane, float4 *out, unsigned *outv, size_t nquads)
+{
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    unsigned v[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(in + p * plane + q * 4);
+    unsigned a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+    float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+          fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+    out[q * 3 + 0] = make_float4(fa, fb, fc, fa);
+    out[q * 3 + 1] = make_float4(fb, fc, fa, fb);
+    out[q * 3 + 2] = make_float4(fc, fa, fb, fc);
+    outv[q] = a;
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_dwordx4(const uint8_t *in, size_t plane, float4 *out, uint4 *outv, size_t n16)
+{
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;  // 16 px per lane
+    if (q >= n16) return;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        uint4 v = *(const uint4 *)(in + p * plane + q * 16);
+        a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    unsigned w[4] = {a.x, a.y, a.z, a.w}, u[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float fa = __uint_as_float((w[k] & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((u[k] & 0x007fffffu) | 0x3f800000u);
+        out[q * 12 + 3 * k + 0] = make_float4(fa, fb, fa, fb);
+        out[q * 12 + 3 * k + 1] = make_float4(fb, fa, fb, fa);
+        out[q * 12 + 3 * k + 2] = make_float4(fa, fa, fb, fb);
+    }
+    outv[q] = a;
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_lds(const uint8_t *in, size_t plane, float4 *out, unsigned *outv, size_t nquads)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [P][1024]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t tile0 = (size_t)blockIdx.x * 1024;  // first pixel byte of the tile
+    for (int p = wave; p < P; p += 4) {
+        const uint8_t *src = in + p * plane + tile0 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
+                                         (void __attribute__((address_space(3))) *)(tile + p * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int p = 0; p < P; p++) { unsigned v = *(const unsigned *)(tile + p * 1024 + threadIdx.x * 4); a ^= v; b += v; c |= v >> (p & 7); }
+    if (q >= nquads) return;
+    float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+          fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+    out[q * 3 + 0] = make_float4(fa, fb, fc, fa);
+    out[q * 3 + 1] = make_float4(fb, fc, fa, fb);
+    out[q * 3 + 2] = make_float4(fc, fa, fb, fc);
+    outv[q] = a;
+}
+
+// incremental model of the fused kernel's data path: feature flags add one element at a time
+//   1: loop over 4 "views" per lane (planes of view v at +v*P*plane)   2: 9 mask dwords first, loads depend on them
+//   4: 8 dependent table gathers (2 MB table)   8: LDS round trip for the 48 B of output   16: ~600 dependent fp64 fma per quad
+template <int P, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_steps(const uint8_t *in, size_t plane, size_t view_stride, int nviews, const uint8_t *mask,
+                                                    const float *tab, float4 *out, unsigned *outv, size_t nquads, int flags)
+{
+    __shared__ __attribute__((aligned(16))) float sx[256 * 12];
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    const int v0 = (flags & 1) ? blockIdx.y * 4 : blockIdx.y, v1 = (flags & 1) ? v0 + 4 : v0 + 1;
+    for (int view = v0; view < v1 && view < nviews; view++) {
+        const uint8_t *base = in + (size_t)view * view_stride + q * 4;
+        unsigned m = 0xf;
+        if (flags & 2) {
+            const unsigned *mp = (const unsigned *)(mask + (size_t)view * nquads * 4 + q * 4);
+            unsigned acc = 0xffffffffu;
+#pragma unroll
+            for (int i = -4; i <= 4; i++) acc &= mp[(q + i < nquads && (long)q + i >= 0) ? i : 0] | 0x01010101u;
+            m = acc & 0xf;
+        }
+        float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0;
+        unsigned a = 0, b = 0, c = 0;
+        if (m) {
+            unsigned v[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(base + p * plane);
+            float w = 0;
+            if (flags & 4) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    unsigned idx = ((v[k % 6] >> (8 * (k & 3))) & 255) * 1021 + (((v[(k + 1) % 6] >> (8 * (k & 3))) & 255) * 3 + 100);
+                    w += tab[idx];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+            double acc = (double)w + (double)a;
+            if (flags & 16) {
+#pragma unroll 8
+                for (int i = 0; i < 600; i++) acc = fma(acc, 1.0000001, 1e-9);
+            }
+            float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u) + w, fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+                  fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u) + (float)acc;
+            o0 = make_float4(fa, fb, fc, fa); o1 = make_float4(fb, fc, fa, fb); o2 = make_float4(fc, fa, fb, fc);
+        }
+        if (flags & 8) {
+            float4 *my = (float4 *)(sx + threadIdx.x * 12);
+            my[0] = o0; my[1] = o1; my[2] = o2;
+            o0 = my[0]; o1 = my[1]; o2 = my[2];
+        }
+        float4 *op = out + ((size_t)view * nquads + q) * 3;
+        op[0] = o0; op[1] = o1; op[2] = o2;
+        outv[(size_t)view * nquads + q] = a;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    constexpr int P = 47;
+    size_t npx = (size_t)(argc > 1 ? atof(argv[1]) : 33.1776) * 1000000;
+    npx = (npx + 4095) / 4096 * 4096;
+    uint8_t *in; float4 *out; unsigned *outv;
+    CHK(hipMalloc(&in, npx * P)); CHK(hipMalloc(&out, npx * 12)); CHK(hipMalloc(&outv, npx));
+    std::vector<uint8_t> h(1 << 20);
+    for (auto &x : h) x = rand();
+    for (size_t o = 0; o < npx * P; o += h.size()) CHK(hipMemcpy(in + o, h.data(), std::min(h.size(), npx * P - o), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const double bytes = (double)npx * (P + 13);
+    for (int mode = 0; mode < 3; mode++) {
+        float best = 1e9;
+        for (int it = 0; it < 12; it++) {
+            CHK(hipEventRecord(e0));
+            if (mode == 0) hipLaunchKernelGGL(k_dword<P>, dim3((npx / 4 + 255) / 256), dim3(256), 0, 0, in, npx, out, outv, npx / 4);
+            if (mode == 1) hipLaunchKernelGGL(k_dwordx4<P>, dim3((npx / 16 + 255) / 256), dim3(256), 0, 0, in, npx, out, (uint4 *)outv, npx / 16);
+            if (mode == 2) hipLaunchKernelGGL(k_lds<P>, dim3(npx / 1024), dim3(256), P * 1024, 0, in, npx, out, outv, npx / 4);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (it >= 2 && ms < best) best = ms;
+        }
+        CHK(hipGetLastError());
+        const char *names[] = {"dword/lane (256 B per wave-load)", "dwordx4/lane (1 KiB per wave-load)", "dwordx4 global->LDS DMA + ds_read_b32"};
+        printf("mode %d %-40s %8.3f ms  %7.1f GB/s  %6.1f Gpx/s  (%.1f%% of 8 TB/s)\n", mode, names[mode], best, bytes / best / 1e6, npx / best / 1e6,
+               bytes / best / 1e6 / 80.0);
+    }
+    // ---- incremental model: 16 views of 1920x1080 ----
+    {
+        const int nviews = 16; const size_t vpx = 1920 * 1080, nq = vpx / 4;
+        uint8_t *fr, *mk; float *tab; float4 *o; unsigned *ov;
+        CHK(hipMalloc(&fr, vpx * P * nviews)); CHK(hipMalloc(&mk, vpx * nviews + 64)); CHK(hipMalloc(&tab, 511 * 1021 * 4));
+        CHK(hipMalloc(&o, vpx * 12 * nviews)); CHK(hipMalloc(&ov, vpx * nviews));
+        for (size_t off = 0; off < vpx * P * nviews; off += h.size()) CHK(hipMemcpy(fr + off, h.data(), std::min(h.size(), vpx * P * nviews - off), hipMemcpyHostToDevice));
+        CHK(hipMemset(mk, 1, vpx * nviews + 64)); CHK(hipMemset(tab, 0, 511 * 1021 * 4));
+        const double by = (double)vpx * nviews * (P + 14);
+        for (int occ = 0; occ < 2; occ++)
+            for (int flags : {0, 1, 3, 7, 15, 31, 4, 16, 2, 8}) {
+                float best = 1e9;
+                for (int it = 0; it < 8; it++) {
+                    dim3 grid((nq + 255) / 256, (flags & 1) ? nviews / 4 : nviews);
+                    CHK(hipEventRecord(e0));
+                    if (occ == 0) hipLaunchKernelGGL((k_steps<P, 8>), grid, dim3(256), 0, 0, fr, vpx, vpx * P, nviews, mk + 32, tab, o, ov, nq, flags);
+                    else hipLaunchKernelGGL((k_steps<P, 4>), grid, dim3(256), 0, 0, fr, vpx, vpx * P, nviews, mk + 32, tab, o, ov, nq, flags);
+                    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                    if (it >= 2 && ms < best) best = ms;
+                }
+                CHK(hipGetLastError());
+                printf("steps occ>=%d flags=%2d  %8.3f ms  %7.1f GB/s  %6.1f Gpx/s\n", occ == 0 ? 8 : 4, flags, best, by / best / 1e6, vpx * nviews / best / 1e6);
+            }
+    }
+    return 0;
+}
