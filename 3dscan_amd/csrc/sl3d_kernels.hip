@@ -187,11 +187,10 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2)
     const double PIO4_HI = 0x1.921fb54442d18p-1, PIO4_LO = 0x1.1a62633145c07p-55;
     const double PI_HI = 0x1.921fb54442d18p+1, PI_LO = 0x1.1a62633145c07p-53;
     // !swap,!red: a | !swap,red: pi/4 - a | swap,red: pi/4 + a | swap,!red: pi/2 - a
-    const bool neg_a = swap != red;              // subtract a
-    const double chi = (swap || red) ? ((swap && !red) ? 2.0 * PIO4_HI : PIO4_HI) : 0.0;
-    const double clo = (swap || red) ? ((swap && !red) ? 2.0 * PIO4_LO : PIO4_LO) : 0.0;
-    const double sa = neg_a ? -a : a;
-    double phi = chi + (sa + clo);               // chi - (a - clo) == chi + (-a + clo) exactly (negation is exact)
+    // i.e. phi = k*(pi/4) +- a with k = red + 2*(swap & !red) in {0,1,2}; k*PIO4_HI and k*PIO4_LO are exact
+    const double kq = (double)((red ? 1 : 0) + ((swap && !red) ? 2 : 0));
+    const double sa = (swap != red) ? -a : a;
+    double phi = fma(kq, PIO4_HI, 0.0) + (sa + kq * PIO4_LO);  // chi - (a - clo) == chi + (-a + clo): negation is exact
     phi = t2 < 0 ? PI_HI - (phi - PI_LO) : phi;
     phi = t1 < 0 ? -phi : phi;
     return (float)phi;
@@ -228,7 +227,7 @@ __device__ __forceinline__ float unwrap_value(float wrapped_shifted, int code)
 
 // lrint(fw*(phi/(2.0*Pi))) with the FE_INVALID and range rejections   5/compute_correspondance.cpp:648-675
 // returns true if the coordinate is accepted.  phi is 0 (unset) or a positive finite absolute phase.
-__device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, long &out)
+__device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, long &out, double &out_d)
 {
     const double c = 2.0 * PI_REF;  // (2.0*Pi) -> (2.0*22.0)/7.0, folded at compile time exactly as on the host
     const double a = (double)fw * div_exact((double)unwrapped, c, 1.0 / c);
@@ -236,6 +235,7 @@ __device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, l
     // FE_INVALID <=> NaN, inf or outside long; those and out-of-range values both clear the pixel
     const bool ok = (r >= 0.0) && (r <= (double)(limit - 1));
     out = ok ? (long)r : 0;
+    out_d = r;  // the same integer as a double (exact), for stage 7
     return ok;
 }
 
@@ -339,6 +339,16 @@ __device__ __forceinline__ const GLOBAL_AS T *opaque(const T *p)
     asm volatile("" : "+s"(p));
     return (const GLOBAL_AS T *)p;  // the asm hides the provenance: restate that this is global memory
 }
+// same for read-only constants: the constant address space tells the compiler the memory is never written
+// while the kernel runs, so wave-uniform loads become scalar loads (s_load, scalar cache) instead of
+// vector loads that every pixel iteration would have to wait for with vmcnt(0)
+#define CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const CONST_AS T *opaque_const(const T *p)
+{
+    asm volatile("" : "+s"(p));
+    return (const CONST_AS T *)p;
+}
 __device__ __forceinline__ unsigned opaque_u32(unsigned v)
 {
     asm volatile("" : "+s"(v));
@@ -371,8 +381,9 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, in
     const float uv = in_v ? unwrap_value(wv, code_v) : 0.0f;
     const float uh = in_h ? unwrap_value(wh, code_h) : 0.0f;
     long cx, cy;
-    const bool okx = correspond(uv, P.fwv, P.PW, cx);
-    const bool oky = correspond(uh, P.fwh, P.PH, cy);
+    double cxd, cyd;
+    const bool okx = correspond(uv, P.fwv, P.PW, cx, cxd);
+    const bool oky = correspond(uh, P.fwh, P.PH, cy, cyd);
     R.valid = okx && oky;
     if (KEEP) {
         P.wrapped[0][keep_off] = wv;
@@ -391,10 +402,10 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, in
         if (C.proj.identity) {
             // no projector distortion and K = [fx 0 cx; 0 fy cy; 0 0 1]: the reference's undistort +
             // re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px): use x
-            up = (double)cx;
-            vp = (double)cy;
+            up = cxd;
+            vp = cyd;
         } else {
-            undistort_reproject((double)cx, (double)cy, C.proj, up, vp);
+            undistort_reproject(cxd, cyd, C.proj, up, vp);
         }
         triangulate_px(C, cu, cv, up, vp, X);
         R.x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
 
     double cu0 = 0, cu1 = 0, cu2 = 0, cu3 = 0, cv0 = 0, cv1 = 0, cv2 = 0, cv3 = 0;
     if (cq * 4 < P.W && !(P.ablate & 4)) {
-        const auto &C0 = *opaque(Cglobal);
+        const auto &C0 = *opaque_const(Cglobal);
         undistort_reproject((double)(gx0 + 0), (double)gy, C0.cam, cu0, cv0);
         __builtin_amdgcn_sched_barrier(0);  // keep the four chains sequential: interleaving them costs ~60 VGPRs
         undistort_reproject((double)(gx0 + 1), (double)gy, C0.cam, cu1, cv1);
@@ -504,33 +515,36 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
                     iv[a][i] = ldg32(vb, pg + ((unsigned)N + ii) * psv + lane_off);
                 }
             }
-            // ---- Gray decode: codes of the 4 pixels, 16 bits each (lo = px0 | px1<<16, hi = px2 | px3<<16) ----
-            unsigned clo[2] = {0, 0}, chi[2] = {0, 0};
+            // ---- Gray decode, byte-parallel over the 4 pixels of the lane ----
+            // G_i = (gray - inverse >= 0) (4/phase_unwrap.cpp:183) for 4 bytes at once: the low 7 bits are
+            // compared by a borrow-protected subtraction, bit 7 decides unless the top bits are equal.
+            // B_0 = G_0, B_i = B_{i-1} xor G_i (:187-191) is a running xor of the masks; the code
+            // sum B_i 2^(N-1-i) (:193) is accumulated per byte: planes 0..7 in accA, planes 8..15 in accB.
+            unsigned accA[2] = {0, 0}, accB[2] = {0, 0};
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const int N = a == 0 ? Nv : Nh;
-                unsigned blo = 0, bhi = 0;  // running binary bit of px0/px1 (bits 0,16) and px2/px3
+                const unsigned H = 0x80808080u;
+                unsigned bacc = 0;  // running binary bit of pixel k at bit 8k+7
 #pragma unroll
                 for (int i = 0; i < NMAX; i++) {
                     if (i < N) {
-                        const unsigned gg = g[a][i], ii = iv[a][i];
-                        // G_i = (gray - inverse >= 0)   4/phase_unwrap.cpp:183
-                        const unsigned g0 = (gg & 255u) >= (ii & 255u), g1 = ((gg >> 8) & 255u) >= ((ii >> 8) & 255u);
-                        const unsigned g2 = ((gg >> 16) & 255u) >= ((ii >> 16) & 255u), g3 = (gg >> 24) >= (ii >> 24);
-                        // B_0 = G_0, B_i = B_{i-1} xor G_i; code = sum B_i 2^(N-1-i)   :187-193
-                        blo ^= g0 | (g1 << 16);
-                        bhi ^= g2 | (g3 << 16);
-                        clo[a] = (clo[a] << 1) | blo;
-                        chi[a] = (chi[a] << 1) | bhi;
+                        const unsigned x = g[a][i], y = iv[a][i];
+                        const unsigned t = (x | H) - (y & ~H);               // bit 8k+7: (x & 0x7f) >= (y & 0x7f)
+                        const unsigned ge = (x & ~y) | (~(x ^ y) & t);       // bit 8k+7: byte x >= byte y
+                        bacc ^= ge & H;
+                        if (i < 8) accA[a] = (accA[a] << 1) | (bacc >> 7);
+                        else accB[a] = (accB[a] << 1) | (bacc >> 7);
                     }
                 }
             }
+            const int shA_v = Nv > 8 ? Nv - 8 : 0, shA_h = Nh > 8 ? Nh - 8 : 0;
 #pragma unroll 1
             for (int k = 0; k < 4; k++) {
                 if ((vbits >> k) & 1u) {
-                    const int sh = 8 * k, sh16 = 16 * (k & 1);
-                    const int code_v = (int)(((k < 2 ? clo[0] : chi[0]) >> sh16) & 0xffffu);
-                    const int code_h = (int)(((k < 2 ? clo[1] : chi[1]) >> sh16) & 0xffffu);
+                    const int sh = 8 * k;
+                    const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
+                    const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
                     // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
                     float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
                     float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
                         R.x = wv + (float)code_v; R.y = wh + (float)code_h; R.z = (float)(cu + cv); R.valid = true;
                     } else {
                         // calibration constants: scalar loads inside the loop (scalar cache), not 100 live SGPRs
-                        R = pixel_chain<KEEP>(P, opaque(Cglobal), gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
+                        R = pixel_chain<KEEP>(P, opaque_const(Cglobal), gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
                     }
                     if (R.valid) {
                         my_xyz[3 * k + 0] = R.x;
@@ -693,8 +707,9 @@ __global__ __launch_bounds__(256) void k_corr(const KParams P, int view)
     bool v = P.valid_axis[0][px] == 1 && P.valid_axis[1][px] == 1;  // merge_valid_maps :60-77
     long cx = 0, cy = 0;
     if (v) {
-        const bool okx = correspond(P.unwrapped[0][px], P.fwv, P.PW, cx);
-        const bool oky = correspond(P.unwrapped[1][px], P.fwh, P.PH, cy);
+        double dx, dy;
+        const bool okx = correspond(P.unwrapped[0][px], P.fwv, P.PW, cx, dx);
+        const bool oky = correspond(P.unwrapped[1][px], P.fwh, P.PH, cy, dy);
         v = okx && oky;
     }
     P.valid[px] = v ? 1 : 0;
