@@ -435,8 +435,8 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, in
 // through LDS so they leave as three 16-B stores per lane (a wave writes 3 KiB contiguous).
 //
 // FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
-template <bool KEEP, int NMAX, bool FGEN>
-__global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+template <bool KEEP, int NMAX, bool FGEN, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
     const int F = FGEN ? P.F : 3;
@@ -579,19 +579,19 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
     }
 }
 
-template <bool KEEP, bool FGEN>
+template <bool KEEP, bool FGEN, int OCC>
 static void launch_fused_n(int nmax, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     if (nmax <= 6)
-        hipLaunchKernelGGL((k_fused<KEEP, 6, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 6, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else if (nmax <= 8)
-        hipLaunchKernelGGL((k_fused<KEEP, 8, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 8, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else if (nmax <= 10)
-        hipLaunchKernelGGL((k_fused<KEEP, 10, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 10, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else if (nmax <= 12)
-        hipLaunchKernelGGL((k_fused<KEEP, 12, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 12, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else
-        hipLaunchKernelGGL((k_fused<KEEP, SL3D_MAX_GRAY, FGEN>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, SL3D_MAX_GRAY, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
 }
 
 int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_views, bool keep, void *stream)
@@ -606,12 +606,18 @@ int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_vi
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(256, 1, 1);
     const int nmax = P.Nv > P.Nh ? P.Nv : P.Nh;
     hipStream_t st = (hipStream_t)stream;
+    static const int occ = getenv("SL3D_OCC") ? atoi(getenv("SL3D_OCC")) : 4;
     if (keep) {
-        if (P.F == 3) launch_fused_n<true, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<true, true>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (P.F == 3) launch_fused_n<true, false, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<true, true, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (P.F != 3) {
+        launch_fused_n<false, true, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (occ == 5) {
+        launch_fused_n<false, false, 5>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (occ == 6) {
+        launch_fused_n<false, false, 6>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        if (P.F == 3) launch_fused_n<false, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<false, true>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        launch_fused_n<false, false, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
     return (int)hipGetLastError();
 }

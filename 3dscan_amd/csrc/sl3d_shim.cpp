@@ -1,0 +1,344 @@
+// sl3d_shim.cpp -- drop-in for the reference's stage objects 3/4/5/7: same four C++ entry points, same
+// global arrays, same input files, but the arithmetic runs in the HIP kernels behind the C ABI.
+// See include/sl3d_shim.h.  Plain C++ (no HIP here); links against libsl3d.so.
+#include "../../include/sl3d_shim.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sl3d.h"
+
+namespace {
+
+constexpr int W = Camera_imagewidth, H = Camera_imageheight;
+const char *kReferenceRoot = "/home/pranav/Desktop/M_tech_project_console";  // 3/wrapped_phase.cpp:39, 7/triangulation.cpp:152
+
+struct Shim {
+    sl3d_ctx *ctx = nullptr;
+    std::string root;
+    bool root_set = false;
+    bool write_debug = false;
+    int status = SL3D_OK;
+    std::string err;
+    // the configuration the context was created with (the scalar globals may change between scans)
+    int F = 0, Nv = 0, Nh = 0, fwv = 0, fwh = 0, ncv = 0, nch = 0;
+} g;
+
+std::string data_root()
+{
+    if (g.root_set) return g.root;
+    const char *e = getenv("SL3D_DATA_ROOT");
+    return e ? std::string(e) : std::string(kReferenceRoot);
+}
+
+bool fail(int code, const std::string &msg)
+{
+    g.status = code;
+    g.err = msg;
+    fprintf(stderr, "\nsl3d shim: %s", msg.c_str());  // the reference reports with printf and carries on
+    return false;
+}
+
+bool ok(int rc, const char *what)
+{
+    if (rc == SL3D_OK) return true;
+    return fail(rc, std::string(what) + ": " + sl3d_strerror(rc) + ": " + sl3d_last_error(g.ctx));
+}
+
+// ---- 8-bit gray planes from BMP files: what cvLoadImage(..., CV_LOAD_IMAGE_GRAYSCALE) yields ----
+// (3/wrapped_phase.cpp:44, 4/phase_unwrap.cpp:78,84).  8-bit palettised and 24-bit BMPs; colour is converted
+// with OpenCV's fixed-point weights (B 1868, G 9617, R 4899, >> 14).
+inline uint8_t bgr2gray(int b, int gch, int r) { return (uint8_t)((b * 1868 + gch * 9617 + r * 4899 + (1 << 13)) >> 14); }
+
+bool read_bmp_gray(const std::string &path, std::vector<uint8_t> &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t hdr[54];
+    if (fread(hdr, 1, 54, f) != 54 || hdr[0] != 'B' || hdr[1] != 'M') { fclose(f); return false; }
+    auto u32 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8) | ((uint32_t)hdr[o + 2] << 16) | ((uint32_t)hdr[o + 3] << 24); };
+    const uint32_t data_off = u32(10), dib = u32(14);
+    const int32_t w = (int32_t)u32(18), hgt = (int32_t)u32(22);
+    const int bpp = hdr[28] | (hdr[29] << 8);
+    const uint32_t compression = u32(30);
+    uint32_t ncolors = u32(46);
+    if (w != W || (hgt != H && hgt != -H) || compression != 0 || (bpp != 8 && bpp != 24)) { fclose(f); return false; }
+    uint8_t pal[256];
+    for (int i = 0; i < 256; i++) pal[i] = (uint8_t)i;
+    if (bpp == 8) {
+        if (ncolors == 0) ncolors = 256;
+        fseek(f, 14 + dib, SEEK_SET);
+        for (uint32_t i = 0; i < ncolors && i < 256; i++) {
+            uint8_t q[4];
+            if (fread(q, 1, 4, f) != 4) { fclose(f); return false; }
+            pal[i] = bgr2gray(q[0], q[1], q[2]);
+        }
+    }
+    const size_t rowbytes = (((size_t)w * bpp + 31) / 32) * 4;
+    std::vector<uint8_t> row(rowbytes);
+    out.assign((size_t)W * H, 0);
+    fseek(f, data_off, SEEK_SET);
+    for (int i = 0; i < H; i++) {
+        if (fread(row.data(), 1, rowbytes, f) != rowbytes) { fclose(f); return false; }
+        const int y = hgt > 0 ? H - 1 - i : i;  // bottom-up unless the height is negative
+        uint8_t *dst = out.data() + (size_t)y * W;
+        if (bpp == 8)
+            for (int x = 0; x < W; x++) dst[x] = pal[row[x]];
+        else
+            for (int x = 0; x < W; x++) dst[x] = bgr2gray(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
+    }
+    fclose(f);
+    return true;
+}
+
+bool write_bmp_gray(const std::string &path, const uint8_t *img)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const uint32_t rowbytes = ((uint32_t)W + 3) & ~3u, off = 54 + 1024, size = off + rowbytes * H;
+    uint8_t hdr[54] = {0};
+    auto put32 = [&](int o, uint32_t v) { hdr[o] = v & 255; hdr[o + 1] = (v >> 8) & 255; hdr[o + 2] = (v >> 16) & 255; hdr[o + 3] = v >> 24; };
+    hdr[0] = 'B'; hdr[1] = 'M';
+    put32(2, size); put32(10, off); put32(14, 40); put32(18, W); put32(22, H);
+    hdr[26] = 1; hdr[28] = 8; put32(34, rowbytes * H); put32(46, 256);
+    fwrite(hdr, 1, 54, f);
+    for (int i = 0; i < 256; i++) { uint8_t q[4] = {(uint8_t)i, (uint8_t)i, (uint8_t)i, 0}; fwrite(q, 1, 4, f); }
+    std::vector<uint8_t> row(rowbytes, 0);
+    for (int y = H - 1; y >= 0; y--) { memcpy(row.data(), img + (size_t)y * W, W); fwrite(row.data(), 1, rowbytes, f); }
+    fclose(f);
+    return true;
+}
+
+// first readable of the given names below the data root
+bool load_frame(const std::vector<std::string> &names, std::vector<uint8_t> &out)
+{
+    for (const auto &n : names)
+        if (read_bmp_gray(data_root() + "/" + n, out)) return true;
+    return fail(SL3D_E_INVALID_ARG, "cannot read " + data_root() + "/" + names[0] + " (8/24-bit BMP of " + std::to_string(W) + "x" + std::to_string(H) + ")");
+}
+
+// the numbers inside <data>...</data> of an OpenCV XML matrix (cvReadByName of 7/triangulation.cpp:152-168,1069-1083)
+bool read_xml_matrix(const std::string &rel, int count, double *out)
+{
+    const std::string path = data_root() + "/" + rel;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return fail(SL3D_E_INVALID_ARG, "cannot open " + path);
+    std::string s;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    const size_t a = s.find("<data>"), b = s.find("</data>");
+    if (a == std::string::npos || b == std::string::npos) return fail(SL3D_E_INVALID_ARG, "no <data> in " + path);
+    const char *p = s.c_str() + a + 6;
+    const char *end = s.c_str() + b;
+    for (int i = 0; i < count; i++) {
+        char *q = nullptr;
+        out[i] = strtod(p, &q);
+        if (q == p || q > end) return fail(SL3D_E_INVALID_ARG, "too few numbers in " + path);
+        p = q;
+    }
+    return true;
+}
+
+bool ensure_ctx()
+{
+    const bool same = g.ctx && g.F == number_of_patterns_fringe && g.Nv == number_of_patterns_binary_vertical &&
+                      g.Nh == number_of_patterns_binary_horizontal && g.fwv == fringe_width_pixels_vertical &&
+                      g.fwh == fringe_width_pixels_horizontal && g.ncv == number_of_codes_vertical && g.nch == number_of_codes_horizontal;
+    if (same) return true;
+    if (g.ctx) sl3d_destroy(g.ctx);
+    g.ctx = nullptr;
+    sl3d_config c;
+    memset(&c, 0, sizeof c);
+    c.width = W; c.height = H; c.proj_width = Projector_imagewidth; c.proj_height = Projector_imageheight;
+    c.n_fringe = g.F = number_of_patterns_fringe;
+    c.n_gray_v = g.Nv = number_of_patterns_binary_vertical;
+    c.n_gray_h = g.Nh = number_of_patterns_binary_horizontal;
+    c.fringe_width_v = g.fwv = fringe_width_pixels_vertical;
+    c.fringe_width_h = g.fwh = fringe_width_pixels_horizontal;
+    c.n_codes_v = g.ncv = number_of_codes_vertical;
+    c.n_codes_h = g.nch = number_of_codes_horizontal;
+    c.max_views = 1;
+    c.device = getenv("SL3D_DEVICE") ? atoi(getenv("SL3D_DEVICE")) : 0;
+    c.flags = SL3D_FLAG_KEEP_STAGES;
+    const int rc = sl3d_create(&c, &g.ctx);
+    if (rc != SL3D_OK) return fail(rc, std::string("sl3d_create: ") + sl3d_strerror(rc) + ": " + sl3d_last_error(nullptr));
+    return true;
+}
+
+template <typename T, typename U>
+void to_col_row(const std::vector<T> &rowmajor, U (*dst)[Camera_imageheight])
+{
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++) dst[c][r] = (U)rowmajor[(size_t)r * W + c];
+}
+
+const char *axis_dir(int pattern_type) { return pattern_type == 0 ? "Vertical" : "Horizontal"; }
+
+}  // namespace
+
+extern "C" void sl3d_shim_set_data_root(const char *dir)
+{
+    g.root = dir ? dir : "";
+    g.root_set = dir != nullptr;
+}
+extern "C" void sl3d_shim_write_debug_images(int enable) { g.write_debug = enable != 0; }
+extern "C" int sl3d_shim_last_status(void) { return g.status; }
+extern "C" const char *sl3d_shim_last_error(void) { return g.err.c_str(); }
+extern "C" void sl3d_shim_reset(void)
+{
+    if (g.ctx) sl3d_destroy(g.ctx);
+    g.ctx = nullptr;
+}
+
+// ---- stage 3 ----------------------------------------------------------------------------------------
+void compute_wrapped_phase(int pattern_type)
+{
+    g.status = SL3D_OK;
+    if (pattern_type != 0 && pattern_type != 1) return;
+    if (!ensure_ctx()) return;
+    // the reference allocates these with new[] on every call and never frees them (3/wrapped_phase.cpp:410-424)
+    int (*&vm)[Camera_imageheight] = pattern_type == 0 ? valid_map_vertical : valid_map_horizontal;
+    float (*&wp)[Camera_imageheight] = pattern_type == 0 ? wrapped_phi_vertical : wrapped_phi_horizontal;
+    if (!vm) vm = new int[Camera_imagewidth][Camera_imageheight];
+    if (!wp) wp = new float[Camera_imagewidth][Camera_imageheight];
+
+    // selection mask from image_scissor (m_tech_project_console.cpp:146-238); without one: 1 inside the border
+    std::vector<uint8_t> mask((size_t)W * H, 0);
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++)
+            mask[(size_t)r * W + c] = selected_region ? (selected_region[c][r] == 1) : (r > 0 && r < H - 1 && c > 0 && c < W - 1);
+    if (!ok(sl3d_set_mask(g.ctx, 0, mask.data(), W), "sl3d_set_mask")) return;
+
+    // read_image: F fringe frames (3/wrapped_phase.cpp:29-58); the Gray/inverse planes are supplied by stage 4
+    const int F = number_of_patterns_fringe;
+    const int N = pattern_type == 0 ? number_of_patterns_binary_vertical : number_of_patterns_binary_horizontal;
+    std::vector<std::vector<uint8_t>> img(F + 2 * N, std::vector<uint8_t>((size_t)W * H, 0));
+    char name[256], alt[256];
+    for (int i = 0; i < F; i++) {
+        snprintf(name, sizeof name, "Captured_patterns/Fringe_patterns/%s/Undistorted/Captured_image_%d.bmp", axis_dir(pattern_type), i);
+        snprintf(alt, sizeof alt, "Captured_patterns/Fringe_patterns/%s/Undistorted/Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
+        if (!load_frame({name, alt}, img[i])) return;
+    }
+    // Gray planes may already be on disk: load them now so one upload covers the axis (stage 4 reloads them anyway)
+    for (int i = 0; i < N; i++) {
+        snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/Captured_image_%d.bmp", axis_dir(pattern_type), i);
+        snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
+        read_bmp_gray(data_root() + "/" + name, img[F + i]) || read_bmp_gray(data_root() + "/" + alt, img[F + i]);
+        snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Captured_image_%d.bmp", axis_dir(pattern_type), i);
+        snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
+        read_bmp_gray(data_root() + "/" + name, img[F + N + i]) || read_bmp_gray(data_root() + "/" + alt, img[F + N + i]);
+    }
+    std::vector<const uint8_t *> planes;
+    for (auto &v : img) planes.push_back(v.data());
+    if (!ok(sl3d_set_frames(g.ctx, 0, pattern_type, planes.data(), (int)planes.size(), W), "sl3d_set_frames")) return;
+    if (!ok(sl3d_compute_wrapped_phase(g.ctx, 0, pattern_type), "sl3d_compute_wrapped_phase")) return;
+
+    std::vector<uint8_t> v((size_t)W * H);
+    std::vector<float> p((size_t)W * H);
+    if (!ok(sl3d_get_valid_map(g.ctx, 0, pattern_type, v.data(), W), "sl3d_get_valid_map")) return;
+    if (!ok(sl3d_get_wrapped_phase(g.ctx, 0, pattern_type, p.data(), W), "sl3d_get_wrapped_phase")) return;
+    to_col_row(v, vm);
+    to_col_row(p, wp);
+    if (g.write_debug) {  // save_wrapped_image :346
+        std::vector<uint8_t> d((size_t)W * H);
+        if (ok(sl3d_get_debug_image(g.ctx, 0, 3, pattern_type, d.data(), W), "sl3d_get_debug_image"))
+            write_bmp_gray(data_root() + "/Wrapped_phase_images/" + axis_dir(pattern_type) + "/Wrapped_phase_image.bmp", d.data());
+    }
+}
+
+// ---- stage 4 ----------------------------------------------------------------------------------------
+void unwrap_phase(int pattern_type)
+{
+    g.status = SL3D_OK;
+    if (pattern_type != 0 && pattern_type != 1) return;
+    if (!g.ctx) { fail(SL3D_E_STATE, "unwrap_phase before compute_wrapped_phase"); return; }
+    int (*&code)[Camera_imageheight] = pattern_type == 0 ? code_vertical : code_horizontal;
+    float (*&uw)[Camera_imageheight] = pattern_type == 0 ? unwrapped_phi_vertical : unwrapped_phi_horizontal;
+    float (*&wp)[Camera_imageheight] = pattern_type == 0 ? wrapped_phi_vertical : wrapped_phi_horizontal;
+    if (!code) code = new int[Camera_imagewidth][Camera_imageheight];     // 4/phase_unwrap.cpp:373-376
+    if (!uw) uw = new float[Camera_imagewidth][Camera_imageheight];       // :282 / :300
+
+    // read_captured_images :51-131: N Gray + N inverse-Gray frames (frame index N is loaded there but never used)
+    const int F = number_of_patterns_fringe;
+    const int N = pattern_type == 0 ? number_of_patterns_binary_vertical : number_of_patterns_binary_horizontal;
+    std::vector<std::vector<uint8_t>> img(F + 2 * N, std::vector<uint8_t>((size_t)W * H, 0));
+    char name[256], alt[256];
+    for (int i = 0; i < F; i++) {  // the axis is uploaded as a whole: fringe frames again
+        snprintf(name, sizeof name, "Captured_patterns/Fringe_patterns/%s/Undistorted/Captured_image_%d.bmp", axis_dir(pattern_type), i);
+        snprintf(alt, sizeof alt, "Captured_patterns/Fringe_patterns/%s/Undistorted/Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
+        if (!load_frame({name, alt}, img[i])) return;
+    }
+    for (int i = 0; i < N; i++) {
+        snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/Captured_image_%d.bmp", axis_dir(pattern_type), i);
+        snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
+        if (!load_frame({name, alt}, img[F + i])) return;
+        snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Captured_image_%d.bmp", axis_dir(pattern_type), i);
+        snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
+        if (!load_frame({name, alt}, img[F + N + i])) return;
+    }
+    std::vector<const uint8_t *> planes;
+    for (auto &v : img) planes.push_back(v.data());
+    if (!ok(sl3d_set_frames(g.ctx, 0, pattern_type, planes.data(), (int)planes.size(), W), "sl3d_set_frames")) return;
+    if (!ok(sl3d_unwrap_phase(g.ctx, 0, pattern_type), "sl3d_unwrap_phase")) return;
+
+    std::vector<int32_t> cd((size_t)W * H);
+    std::vector<float> u((size_t)W * H), p((size_t)W * H);
+    if (!ok(sl3d_get_code(g.ctx, 0, pattern_type, cd.data(), W), "sl3d_get_code")) return;
+    if (!ok(sl3d_get_unwrapped_phase(g.ctx, 0, pattern_type, u.data(), W), "sl3d_get_unwrapped_phase")) return;
+    if (!ok(sl3d_get_wrapped_phase(g.ctx, 0, pattern_type, p.data(), W), "sl3d_get_wrapped_phase")) return;
+    to_col_row(cd, code);
+    to_col_row(u, uw);
+    if (wp) to_col_row(p, wp);  // stage 4 shifts wrapped_phi in place by +Pi (:290, :308)
+    if (g.write_debug) {       // save_unwrap_phase_image :321-364
+        std::vector<uint8_t> d((size_t)W * H);
+        if (ok(sl3d_get_debug_image(g.ctx, 0, 4, pattern_type, d.data(), W), "sl3d_get_debug_image"))
+            write_bmp_gray(data_root() + (pattern_type == 0 ? "/Unwrapped_phase_images/Gray_coded/Vertical/Unwrapped_phase_vertical.bmp"
+                                                            : "/Unwrapped_phase_images/Gray_coded/Horizontal/Unwrapped_phase_horizontal.bmp"),
+                           d.data());
+    }
+}
+
+// ---- stage 5 ----------------------------------------------------------------------------------------
+void compute_c_p_map()
+{
+    g.status = SL3D_OK;
+    if (!g.ctx) { fail(SL3D_E_STATE, "compute_c_p_map before the phase stages"); return; }
+    if (!valid_map) valid_map = new int[Camera_imagewidth][Camera_imageheight];  // 5/compute_correspondance.cpp:635
+    if (!c_p_map) c_p_map = new long int[total_camera_pixels][2];                 // :640
+    if (!ok(sl3d_compute_c_p_map(g.ctx, 0), "sl3d_compute_c_p_map")) return;
+    std::vector<uint8_t> v((size_t)W * H);
+    if (!ok(sl3d_get_valid_map(g.ctx, 0, SL3D_VALID_MERGED, v.data(), W), "sl3d_get_valid_map")) return;
+    to_col_row(v, valid_map);
+    static_assert(sizeof(long int) == sizeof(int64_t), "c_p_map is long[ ][2] on LP64");
+    ok(sl3d_get_c_p_map(g.ctx, 0, (int64_t *)c_p_map), "sl3d_get_c_p_map");
+}
+
+// ---- stage 7 ----------------------------------------------------------------------------------------
+void triangulate()
+{
+    g.status = SL3D_OK;
+    if (!g.ctx) { fail(SL3D_E_STATE, "triangulate before compute_c_p_map"); return; }
+    double Kc[9], dc[5], rc[3], tc[3], Kp[9], dp[5], rp[3], tp[3];
+    if (!read_xml_matrix("Camera_calibration/Matrices/cam_intrinsic_mat.xml", 9, Kc) ||            // 7/triangulation.cpp:152
+        !read_xml_matrix("Camera_calibration/Matrices/cam_distortion_vect.xml", 5, dc) ||          // :157
+        !read_xml_matrix("Projector_calibration/Matrices/proj_intrinsic_mat.xml", 9, Kp) ||        // :162
+        !read_xml_matrix("Projector_calibration/Matrices/proj_distortion_vect.xml", 5, dp) ||      // :167
+        !read_xml_matrix("Triangulation/Camera_extrinsic_parametrs/world_to_cam_rot_vect.xml", 3, rc) ||      // :1069
+        !read_xml_matrix("Triangulation/Camera_extrinsic_parametrs/world_to_cam_trans_vect.xml", 3, tc) ||    // :1074
+        !read_xml_matrix("Triangulation/Projector_extrinsic_parametrs/world_to_proj_rot_vect.xml", 3, rp) ||  // :1077
+        !read_xml_matrix("Triangulation/Projector_extrinsic_parametrs/world_to_proj_trans_vect.xml", 3, tp))  // :1082
+        return;
+    if (!ok(sl3d_set_calibration(g.ctx, Kc, dc, rc, tc, Kp, dp, rp, tp), "sl3d_set_calibration")) return;
+    if (!intersection_points) intersection_points = new double[Camera_imagewidth][Camera_imageheight][3];  // :1513
+    if (!ok(sl3d_triangulate(g.ctx, 0), "sl3d_triangulate")) return;
+    std::vector<double> pts((size_t)W * H * 3);
+    if (!ok(sl3d_get_intersection_points(g.ctx, 0, pts.data()), "sl3d_get_intersection_points")) return;
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++) memcpy(intersection_points[c][r], &pts[3 * ((size_t)r * W + c)], 3 * sizeof(double));
+}

@@ -1,0 +1,72 @@
+/*
+ * sl3d_shim.h -- the reference's own stage interface, re-exported on top of the C ABI (sl3d.h).
+ *
+ * Link libsl3d_shim.so (+ libsl3d.so) INSTEAD OF the reference's stage objects
+ *     3/wrapped_phase.o  4/phase_unwrap.o  5/compute_correspondance.o  7/triangulation.o
+ * (unit list: M_tech_project_console/M_tech_project_console.cbp:71-85) and main() keeps calling
+ *     compute_wrapped_phase(0); compute_wrapped_phase(1); unwrap_phase(0); unwrap_phase(1);
+ *     compute_c_p_map(); triangulate();                 [m_tech_project_console.cpp:372-395]
+ * The four functions have the reference's C++ signatures (PROJECT_GLOBAL/intermodule_dependencies.h:10-22)
+ * and fill the reference's global arrays, which stay DEFINED where the reference defines them
+ * (PROJECT_GLOBAL/common_variables.h, pulled in by 1/pattern_generator.cpp); for a build without the
+ * reference's objects, sl3d_shim_globals.cpp provides the same definitions.
+ *
+ * Compile-time dimensions follow PROJECT_GLOBAL/global_cv.h:49-53 and can be overridden with -D.
+ */
+#ifndef SL3D_SHIM_H
+#define SL3D_SHIM_H
+
+#ifndef Camera_imagewidth
+#define Camera_imagewidth 1600
+#endif
+#ifndef Camera_imageheight
+#define Camera_imageheight 1200
+#endif
+#ifndef Projector_imagewidth
+#define Projector_imagewidth 1280
+#endif
+#ifndef Projector_imageheight
+#define Projector_imageheight 720
+#endif
+#define total_camera_pixels (Camera_imagewidth * Camera_imageheight)
+
+/* ---- the reference's globals on the path (common_variables.h:6-24,56-62), all [col][row] ---- */
+extern int number_of_codes_vertical, number_of_codes_horizontal;
+extern int number_of_patterns_binary_vertical, number_of_patterns_binary_horizontal;
+extern int number_of_patterns_fringe;
+extern int fringe_width_pixels_vertical, fringe_width_pixels_horizontal;
+extern int (*code_vertical)[Camera_imageheight];
+extern int (*code_horizontal)[Camera_imageheight];
+extern long int (*c_p_map)[2];
+extern int (*selected_region)[Camera_imageheight];
+extern int (*valid_map_vertical)[Camera_imageheight];
+extern int (*valid_map_horizontal)[Camera_imageheight];
+extern int (*valid_map)[Camera_imageheight];
+extern float (*wrapped_phi_vertical)[Camera_imageheight];
+extern float (*wrapped_phi_horizontal)[Camera_imageheight];
+extern float (*unwrapped_phi_vertical)[Camera_imageheight];
+extern float (*unwrapped_phi_horizontal)[Camera_imageheight];
+extern double (*intersection_points)[Camera_imageheight][3];
+
+/* ---- the four entry points (C++ linkage, as in the reference) ---- */
+void compute_wrapped_phase(int pattern_type); /* 3/wrapped_phase.cpp:402 */
+void unwrap_phase(int pattern_type);          /* 4/phase_unwrap.cpp:367 (declared int at intermodule_dependencies.h:13, defined void) */
+void compute_c_p_map();                       /* 5/compute_correspondance.cpp:630 */
+void triangulate();                           /* 7/triangulation.cpp:1444 */
+
+/* ---- shim configuration (not in the reference) ----
+ * The reference reads its inputs from hard-coded paths: absolute /home/pranav/Desktop/M_tech_project_console/...
+ * in stages 3 and 7 (3/wrapped_phase.cpp:39-50, 7/triangulation.cpp:152-167,1069-1082), relative paths in
+ * stage 4 (4/phase_unwrap.cpp:68-86).  The shim reads the same files below one root directory:
+ * sl3d_shim_set_data_root(), else $SL3D_DATA_ROOT, else the reference's absolute path. */
+extern "C" {
+void sl3d_shim_set_data_root(const char *dir);
+/* write the stage-3/4 debug images (Wrapped_phase_image.bmp, Unwrapped_phase_*.bmp) like the reference does */
+void sl3d_shim_write_debug_images(int enable);
+/* status of the last shim call (an sl3d_status); the reference's functions return nothing */
+int sl3d_shim_last_status(void);
+const char *sl3d_shim_last_error(void);
+void sl3d_shim_reset(void); /* drop the context (e.g. before changing the scalar globals) */
+}
+
+#endif /* SL3D_SHIM_H */

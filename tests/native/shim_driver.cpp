@@ -1,0 +1,61 @@
+// Headless stand-in for the reference's main() (m_tech_project_console.cpp:366-395): sets the scalar globals
+// and selected_region, calls the four stage functions in main()'s order through the drop-in shim, and dumps
+// the reference-layout global arrays to a binary file for the Python test to compare with the oracle.
+//   shim_driver <data_root> <out.bin> Nv Nh fwv fwh ncv nch
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "sl3d_shim.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 9) return 2;
+    sl3d_shim_set_data_root(argv[1]);
+    sl3d_shim_write_debug_images(1);
+    number_of_patterns_binary_vertical = atoi(argv[3]);
+    number_of_patterns_binary_horizontal = atoi(argv[4]);
+    fringe_width_pixels_vertical = atoi(argv[5]);
+    fringe_width_pixels_horizontal = atoi(argv[6]);
+    number_of_codes_vertical = atoi(argv[7]);
+    number_of_codes_horizontal = atoi(argv[8]);
+    // image_scissor's result: selected_region[col][row] from mask.raw (row-major bytes)
+    selected_region = new int[Camera_imagewidth][Camera_imageheight];
+    {
+        std::vector<unsigned char> m((size_t)Camera_imagewidth * Camera_imageheight);
+        FILE *f = fopen((std::string(argv[1]) + "/mask.raw").c_str(), "rb");
+        if (!f || fread(m.data(), 1, m.size(), f) != m.size()) return 3;
+        fclose(f);
+        for (int r = 0; r < Camera_imageheight; r++)
+            for (int c = 0; c < Camera_imagewidth; c++) selected_region[c][r] = m[(size_t)r * Camera_imagewidth + c];
+    }
+    compute_wrapped_phase(0);
+    if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 10; }
+    compute_wrapped_phase(1);
+    if (sl3d_shim_last_status()) return 11;
+    unwrap_phase(0);
+    if (sl3d_shim_last_status()) return 12;
+    unwrap_phase(1);
+    if (sl3d_shim_last_status()) return 13;
+    compute_c_p_map();
+    if (sl3d_shim_last_status()) return 14;
+    triangulate();
+    if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 15; }
+
+    FILE *o = fopen(argv[2], "wb");
+    const size_t n = (size_t)Camera_imagewidth * Camera_imageheight;
+    fwrite(valid_map_vertical, sizeof(int), n, o);
+    fwrite(valid_map_horizontal, sizeof(int), n, o);
+    fwrite(valid_map, sizeof(int), n, o);
+    fwrite(wrapped_phi_vertical, sizeof(float), n, o);
+    fwrite(wrapped_phi_horizontal, sizeof(float), n, o);
+    fwrite(unwrapped_phi_vertical, sizeof(float), n, o);
+    fwrite(unwrapped_phi_horizontal, sizeof(float), n, o);
+    fwrite(code_vertical, sizeof(int), n, o);
+    fwrite(code_horizontal, sizeof(int), n, o);
+    fwrite(c_p_map, sizeof(long), 2 * n, o);
+    fwrite(intersection_points, sizeof(double), 3 * n, o);
+    fclose(o);
+    return 0;
+}

@@ -1,0 +1,109 @@
+"""GPU test of the drop-in shim: the reference's four entry points + global arrays, driven by a headless
+stand-in for main() that reads the same BMP / XML files the reference reads, compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import ROOT, assert_points_close, pkg
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+W, H, PW, PH, NV, NH, FWV, FWH = 160, 120, 256, 192, 6, 5, 8, 8
+
+
+def _xml(path, name, rows, cols, vals):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write('<?xml version="1.0"?>\n<opencv_storage>\n<%s type_id="opencv-matrix">\n  <rows>%d</rows>\n  <cols>%d</cols>\n  <dt>d</dt>\n  <data>\n    %s</data></%s>\n</opencv_storage>\n'
+                % (name, rows, cols, " ".join("%.17e" % v for v in vals), name))
+
+
+def test_shim_matches_oracle(tmp_path):
+    syn = pkg("synth")
+    cap = syn.make_capture(W, H, PW, PH, NV, NH, FWV, FWH, noise=2)
+    rng = np.random.default_rng(5)
+    mask = cap["mask"].copy()
+    mask[40:60, 50:90] = 0  # a hole, so the boundary removal has something to do
+    mask[rng.random((H, W)) < 0.01] = 0
+    cal = syn.cal_tuple(cap["cal"])
+    root = str(tmp_path)
+    ax = {0: "Vertical", 1: "Horizontal"}
+    for a, planes, N in ((0, cap["planes_v"], NV), (1, cap["planes_h"], NH)):
+        d1 = f"{root}/Captured_patterns/Fringe_patterns/{ax[a]}/Undistorted"
+        d2 = f"{root}/Captured_patterns/Coded_patterns/Gray_coded/{ax[a]}/Undistorted"
+        os.makedirs(d1); os.makedirs(d2)
+        os.makedirs(f"{root}/Wrapped_phase_images/{ax[a]}"); os.makedirs(f"{root}/Unwrapped_phase_images/Gray_coded/{ax[a]}")
+        for i in range(3):
+            Image.fromarray(planes[i]).save(f"{d1}/Captured_image_{i}.bmp")
+        for i in range(N):
+            Image.fromarray(planes[3 + i]).save(f"{d2}/Captured_image_{i}.bmp")
+            # one inverse frame as a 24-bit colour BMP: exercises the BGR->gray path of cvLoadImage(GRAYSCALE)
+            inv = planes[3 + N + i]
+            if i == 0:
+                Image.fromarray(np.stack([inv] * 3, -1)).save(f"{d2}/inverse_Captured_image_{i}.bmp")
+            else:
+                Image.fromarray(inv).save(f"{d2}/inverse_Captured_image_{i}.bmp")
+    mask.tofile(f"{root}/mask.raw")
+    Kc, dc, rc, tc, Kp, dp, rp, tp = cal
+    _xml(f"{root}/Camera_calibration/Matrices/cam_intrinsic_mat.xml", "cam_intrinsic_mat", 3, 3, Kc)
+    _xml(f"{root}/Camera_calibration/Matrices/cam_distortion_vect.xml", "cam_distortion_vect", 5, 1, dc)
+    _xml(f"{root}/Projector_calibration/Matrices/proj_intrinsic_mat.xml", "proj_intrinsic_mat", 3, 3, Kp)
+    _xml(f"{root}/Projector_calibration/Matrices/proj_distortion_vect.xml", "proj_distortion_vect", 5, 1, dp)
+    _xml(f"{root}/Triangulation/Camera_extrinsic_parametrs/world_to_cam_rot_vect.xml", "world_to_cam_rot_vect", 3, 1, rc)
+    _xml(f"{root}/Triangulation/Camera_extrinsic_parametrs/world_to_cam_trans_vect.xml", "world_to_cam_trans_vect", 3, 1, tc)
+    _xml(f"{root}/Triangulation/Projector_extrinsic_parametrs/world_to_proj_rot_vect.xml", "world_to_proj_rot_vect", 3, 1, rp)
+    _xml(f"{root}/Triangulation/Projector_extrinsic_parametrs/world_to_proj_trans_vect.xml", "world_to_proj_trans_vect", 3, 1, tp)
+
+    # build the shim + driver for this test's compile-time dimensions (the reference fixes them with macros too)
+    exe = f"{root}/shim_driver"
+    defs = [f"-DCamera_imagewidth={W}", f"-DCamera_imageheight={H}", f"-DProjector_imagewidth={PW}", f"-DProjector_imageheight={PH}"]
+    csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *defs, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "shim_driver.cpp"), os.path.join(csrc, "sl3d_shim.cpp"),
+                           os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"), "-lsl3d",
+                           "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
+    out = f"{root}/out.bin"
+    ncv, nch = -(-PW // FWV), -(-PH // FWH)
+    r = subprocess.run([exe, root, out, str(NV), str(NH), str(FWV), str(FWH), str(ncv), str(nch)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    n = W * H
+    raw = open(out, "rb").read()
+    off = 0
+
+    def take(dtype, count, shape):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=off).reshape(shape)
+        off += a.nbytes
+        return a
+
+    # the reference's layouts: [col][row] planes, c_p_map [row*W+col][2], intersection_points [col][row][3]
+    vv, vh, vm = (take(np.int32, n, (W, H)).T for _ in range(3))
+    wv, wh, uv, uh = (take(np.float32, n, (W, H)).T for _ in range(4))
+    cv, ch = (take(np.int32, n, (W, H)).T for _ in range(2))
+    cp = take(np.int64, 2 * n, (H, W, 2))
+    ip = take(np.float64, 3 * n, (W, H, 3)).transpose(1, 0, 2)
+
+    o = Oracle(W, H, PW, PH, NV, NH, FWV, FWH, ncodes_v=ncv, ncodes_h=nch)
+    o.set_mask(mask)
+    o.set_calibration(*cal)
+    o.run_scan(cap["planes_v"], cap["planes_h"])
+    assert np.array_equal(vv, o.valid_map(0)) and np.array_equal(vh, o.valid_map(1)) and np.array_equal(vm, o.valid_map(2))
+    sel = mask == 1
+    assert np.array_equal(wv[sel], o.wrapped_phi(0)[sel]) and np.array_equal(wh[sel], o.wrapped_phi(1)[sel])
+    assert np.array_equal(cv, o.code(0)) and np.array_equal(ch, o.code(1))
+    v = o.valid_map(2) == 1
+    assert np.array_equal(uv[o.valid_map(0) == 1], o.unwrapped_phi(0)[o.valid_map(0) == 1])
+    assert np.array_equal(uh[o.valid_map(1) == 1], o.unwrapped_phi(1)[o.valid_map(1) == 1])
+    assert np.array_equal(cp[v], o.c_p_map()[v])
+    assert_points_close(ip, o.intersection_points(), v)
+    # the debug images written next to the inputs are the reference's stage-3/4 outputs
+    for a in (0, 1):
+        d3 = np.array(Image.open(f"{root}/Wrapped_phase_images/{ax[a]}/Wrapped_phase_image.bmp"))
+        assert np.array_equal(d3, o.debug_image(3, a))
+    d4 = np.array(Image.open(f"{root}/Unwrapped_phase_images/Gray_coded/Vertical/Unwrapped_phase_vertical.bmp"))
+    assert np.array_equal(d4, o.debug_image(4, 0))
