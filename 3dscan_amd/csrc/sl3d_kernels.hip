@@ -157,7 +157,7 @@ __device__ __forceinline__ double recip(double d)
 // to create a context if a single value differs (tests/test_gpu_parity.py repeats the check).
 // Method: octant reduction on the integers, a second reduction lo/hi > tan(pi/8) -> (hi-lo)/(hi+lo)
 // (still a quotient of exact integers, so there is exactly one division), atan(r) = r + r*z*Q(z),
-// z = r^2, Q of degree 10 (|error| < 1e-17 on [0, tan(pi/8)]), pi/4, pi/2, pi as hi+lo pairs.
+// z = r^2, Q of degree 10 by Horner (|error| < 1e-17 on [0, tan(pi/8)]), pi/4, pi/2, pi as hi+lo pairs.
 // A 2 MB gather table costs more than this arithmetic: every wave-level gather pulls 64 separate
 // 128-B lines through the vector L1 for 256 useful bytes (tools/membench.hip, flags=4: -50%).
 __device__ __forceinline__ float atan2_lattice(int t1, int t2)
@@ -171,17 +171,21 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2)
     const double n = (double)num, d = (double)(den == 0 ? 1 : den);
     const double y = recip(d), q0 = n * y;
     const double r = fma(fma(-q0, d, n), y, q0);
-    // atan(r) = r + r*z*Q(z), Q of degree 10 in z = r^2, Estrin evaluation (short dependency chain)
-    const double z = r * r, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
-    const double q01 = fma(0x1.999999999934ap-3, z, -0x1.5555555555555p-2);
-    const double q23 = fma(0x1.c71c7185314cbp-4, z, -0x1.24924924360cbp-3);
-    const double q45 = fma(0x1.3b1262d95579ep-4, z, -0x1.745d0b26b83e7p-4);
-    const double q67 = fma(0x1.dfe61e80903d2p-5, z, -0x1.10fa75382537fp-4);
-    const double q89 = fma(0x1.41603647c7a7cp-5, z, -0x1.a098bb6ba4941p-5);
-    const double q0123 = fma(q23, z2, q01);
-    const double q4567 = fma(q67, z2, q45);
-    const double q89a = fma(-0x1.3a2b7a07caea9p-6, z2, q89);
-    const double p = fma(q89a, z8, fma(q4567, z4, q0123));
+    // atan(r) = r + r*z*Q(z), Q of degree 10 in z = r^2.  Horner: one VGPR + one constant per fma (the kernel
+    // is VALU-issue bound, the other waves of the SIMD cover the dependency latency; Estrin needed 8 more
+    // instructions for the powers of z and for moving second constants into VGPRs)
+    const double z = r * r;
+    double p = -0x1.3a2b7a07caea9p-6;
+    p = fma(p, z, 0x1.41603647c7a7cp-5);
+    p = fma(p, z, -0x1.a098bb6ba4941p-5);
+    p = fma(p, z, 0x1.dfe61e80903d2p-5);
+    p = fma(p, z, -0x1.10fa75382537fp-4);
+    p = fma(p, z, 0x1.3b1262d95579ep-4);
+    p = fma(p, z, -0x1.745d0b26b83e7p-4);
+    p = fma(p, z, 0x1.c71c7185314cbp-4);
+    p = fma(p, z, -0x1.24924924360cbp-3);
+    p = fma(p, z, 0x1.999999999934ap-3);
+    p = fma(p, z, -0x1.5555555555555p-2);
     const double a = fma(r, z * p, r);
     // octant / quadrant: phi = C +- a with C in {0, pi/4, pi/2} as hi+lo pairs, then pi - phi, then the sign
     const double PIO4_HI = 0x1.921fb54442d18p-1, PIO4_LO = 0x1.1a62633145c07p-55;
@@ -205,6 +209,8 @@ __device__ __forceinline__ float wrapped_phase(int F, int i0, int i1, int i2, in
 
 // the value wrapped_phi holds after stage 4's in-place `+= Pi` (4/phase_unwrap.cpp:290,308)
 __device__ __forceinline__ float shift_pi(float phi) { return (float)((double)phi + PI_REF); }
+// same, applied only where stage 4's loop runs: adding 0.0 in double and rounding back returns phi itself
+__device__ __forceinline__ float shift_pi_if(float phi, bool in_range) { return (float)((double)phi + (in_range ? PI_REF : 0.0)); }
 
 // Correctly rounded division by a constant without the IEEE divide expansion (Markstein): with
 // y = RN(1/c), q0 = RN(a*y), r = a - q0*c (exact, one fma), q = RN(q0 + r*y) equals RN(a/c).
@@ -439,6 +445,7 @@ template <bool KEEP, int NMAX, bool FGEN, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
+    __shared__ __attribute__((aligned(16))) double s_cam[256 * 8];  // undistorted camera coordinates of the lane's 4 pixels
     const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -450,17 +457,15 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
     const unsigned lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;  // byte offset of the quad inside any plane
     const unsigned ps = (unsigned)P.plane_stride;
 
-    double cu0 = 0, cu1 = 0, cu2 = 0, cu3 = 0, cv0 = 0, cv1 = 0, cv2 = 0, cv3 = 0;
-    if (cq * 4 < P.W && !(P.ablate & 4)) {
-        const auto &C0 = *opaque_const(Cglobal);
-        undistort_reproject((double)(gx0 + 0), (double)gy, C0.cam, cu0, cv0);
-        __builtin_amdgcn_sched_barrier(0);  // keep the four chains sequential: interleaving them costs ~60 VGPRs
-        undistort_reproject((double)(gx0 + 1), (double)gy, C0.cam, cu1, cv1);
-        __builtin_amdgcn_sched_barrier(0);
-        undistort_reproject((double)(gx0 + 2), (double)gy, C0.cam, cu2, cv2);
-        __builtin_amdgcn_sched_barrier(0);
-        undistort_reproject((double)(gx0 + 3), (double)gy, C0.cam, cu3, cv3);
-        __builtin_amdgcn_sched_barrier(0);
+    // T1 for the camera depends on the pixel only: once per lane, kept in LDS so the rolled pixel loop can
+    // index it (each lane reads back only what it wrote: no barrier)
+    double *my_cam = s_cam + threadIdx.x * 8;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        double cu = 0.0, cv = 0.0;
+        if (cq * 4 < P.W && !(P.ablate & 4)) undistort_reproject((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);
+        my_cam[2 * k] = cu;
+        my_cam[2 * k + 1] = cv;
     }
 
     const int Nv = P.Nv, Nh = P.Nh;
@@ -548,11 +553,9 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
                     // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
                     float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
                     float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
-                    const float wvs = shift_pi(wv), whs = shift_pi(wh);
-                    wv = (gx0 + k >= 1 && gx0 + k <= P.fullW - 2) ? wvs : wv;  // 4/phase_unwrap.cpp:285,290
-                    wh = (gy >= 1 && gy <= P.fullH - 2) ? whs : wh;            // 4/phase_unwrap.cpp:304,308
-                    const double cu = k == 0 ? cu0 : k == 1 ? cu1 : k == 2 ? cu2 : cu3;
-                    const double cv = k == 0 ? cv0 : k == 1 ? cv1 : k == 2 ? cv2 : cv3;
+                    wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
+                    wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
+                    const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
                     PixelResult R;
                     if (P.ablate & 1) {
                         R.x = wv + (float)code_v; R.y = wh + (float)code_h; R.z = (float)(cu + cv); R.valid = true;
@@ -606,18 +609,12 @@ int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_vi
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(256, 1, 1);
     const int nmax = P.Nv > P.Nh ? P.Nv : P.Nh;
     hipStream_t st = (hipStream_t)stream;
-    static const int occ = getenv("SL3D_OCC") ? atoi(getenv("SL3D_OCC")) : 4;
     if (keep) {
         if (P.F == 3) launch_fused_n<true, false, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
         else launch_fused_n<true, true, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (P.F != 3) {
-        launch_fused_n<false, true, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (occ == 5) {
-        launch_fused_n<false, false, 5>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (occ == 6) {
-        launch_fused_n<false, false, 6>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        launch_fused_n<false, false, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (P.F == 3) launch_fused_n<false, false, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<false, true, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
     return (int)hipGetLastError();
 }

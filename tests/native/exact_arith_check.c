@@ -3,7 +3,7 @@
  *  1. div_exact(a, c, 1/c): q0 = a*y, r = fma(-q0,c,a), q = fma(r,y,q0) equals a/c
  *       - c = 7        for every a = 44*code, code < 2^20            (unwrap: code*2.0*Pi)
  *       - c = 2*22/7   for every float a in [5e-4, 6e4] and a = 0     (correspondence: phi/(2.0*Pi))
- *  2. atan2_lattice (octant + pi/8 reduction, degree-10 Estrin polynomial, hi/lo constants) rounded to
+ *  2. atan2_lattice (octant + pi/8 reduction, degree-10 Horner polynomial, hi/lo constants) rounded to
  *     float equals (float)atan2 of libm on all 511 x 1021 lattice points (the device version replaces the
  *     single division by rcp + Newton + Markstein; the GPU self-check in sl3d_create covers that).
  * Prints "OK" and exits 0 when everything holds. */
@@ -25,9 +25,8 @@ static double atan2_lattice(int t1, int t2)
     int red = 169 * lo > 70 * hi;
     int num = red ? hi - lo : lo, den = red ? hi + lo : hi;
     double r = (double)num / (double)(den == 0 ? 1 : den);
-    double z = r * r, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
-    double q01 = fma(Q[1], z, Q[0]), q23 = fma(Q[3], z, Q[2]), q45 = fma(Q[5], z, Q[4]), q67 = fma(Q[7], z, Q[6]), q89 = fma(Q[9], z, Q[8]);
-    double p = fma(fma(Q[10], z2, q89), z8, fma(fma(q67, z2, q45), z4, fma(q23, z2, q01)));
+    double z = r * r, p = Q[10];
+    for (int i = 9; i >= 0; i--) p = fma(p, z, Q[i]);
     double a = fma(r, z * p, r);
     double kq = (double)((red ? 1 : 0) + ((swap && !red) ? 2 : 0));
     double sa = (swap != red) ? -a : a;
