@@ -28,6 +28,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_traffic(px_per_launch):
+    """HBM bytes per launch of the fused kernel from the latest committed PMC run (tools/profile.sh +
+    tools/summarize_profile.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, scaled by the factors
+    calibrated on tools/membench in the same session).  The profile is taken on this same command; bytes scale
+    with the pixels per launch.  None if no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    t = json.load(open(files[-1]))
+    scale = px_per_launch / (t["algorithmic_bytes_per_launch"] / 60.0)
+    return round(t["hbm_bytes_per_launch"] * scale)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +180,8 @@ def main():
                    "views_per_gpu_per_step": V, "rows_per_gpu": rows, "frames_per_view": 2 * (3 + 2 * N),
                    "projector": f"{PW}x{PH}", "fringe_width": fw, "sharding": "image rows" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": measured_traffic(px_per_launch) if alg_bytes_px == 60 else None,
                      "kernel": "sl3d::k_fused<false>", "algorithmic_bytes_per_pixel": alg_bytes_px,
                      "pixels_per_launch": px_per_launch, "avg_launch_ms": round(launch_s * 1e3, 4)},
     }
