@@ -464,7 +464,7 @@ extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
-    return launched(x, launch_fused(x->P, x->d_cal, first_view, n_views, x->keep, x->stream));
+    return launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0, first_view, n_views, x->keep, x->stream));
 }
 
 extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
@@ -474,7 +474,7 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
-    rc = launched(x, launch_fused(x->P, x->d_cal, first_view, n_views, x->keep, x->stream));
+    rc = launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0, first_view, n_views, x->keep, x->stream));
     if (rc) return rc;
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));

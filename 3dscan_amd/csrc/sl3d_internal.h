@@ -65,7 +65,7 @@ struct KParams {
 };
 
 // launchers (sl3d_kernels.hip); `stream` is a hipStream_t
-int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_views, bool keep, void *stream);
+int launch_fused(const KParams &P, const DevCal *d_cal, bool proj_identity, int first_view, int n_views, bool keep, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);
 int launch_corr(const KParams &P, int view, void *stream);

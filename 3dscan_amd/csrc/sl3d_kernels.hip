@@ -297,26 +297,33 @@ __device__ __forceinline__ void undistort_reproject(double px, double py, const 
 
 // T2 + T3: P (4x3), F (4x1), V = (P^T P)^-1 P^T F   7/triangulation.cpp:1152-1168,1181-1188,1202-1206
 // evaluated as adj(P^T P) (P^T F) / det(P^T P) (symmetric normal matrix; within 1e-12 of the literal order)
+// The third row of each projection matrix (A[2][0..3]) multiplies the variable in every entry of P and F.
+// An fp64 FMA can read only one scalar register, so with all of A in SGPRs every entry costs an extra
+// v_mov_b64; the kernel therefore keeps these 8 doubles in VGPRs (PinnedRows), loaded once per lane.
+struct PinnedRows {
+    double c2[4], p2[4];  // A_cam[2][0..3], A_proj[2][0..3]
+};
+
 template <typename AP>
-__device__ __forceinline__ void tri_row(AP A, double t, double &m00, double &m01, double &m02, double &m11,
+__device__ __forceinline__ void tri_row(AP A, const double a2[4], double t, double &m00, double &m01, double &m02, double &m11,
                                         double &m12, double &m22, double &g0, double &g1, double &g2, int r)
 {
     // row of P: A[r][0..2] - t*A[2][0..2]; entry of F: A[2][3]*t - A[r][3]
-    const double p0 = fma(-t, A[8], A[4 * r + 0]), p1 = fma(-t, A[9], A[4 * r + 1]), p2 = fma(-t, A[10], A[4 * r + 2]);
-    const double f = fma(A[11], t, -A[4 * r + 3]);
+    const double p0 = fma(-t, a2[0], A[4 * r + 0]), p1 = fma(-t, a2[1], A[4 * r + 1]), p2 = fma(-t, a2[2], A[4 * r + 2]);
+    const double f = fma(a2[3], t, -A[4 * r + 3]);
     m00 = fma(p0, p0, m00); m01 = fma(p0, p1, m01); m02 = fma(p0, p2, m02);
     m11 = fma(p1, p1, m11); m12 = fma(p1, p2, m12); m22 = fma(p2, p2, m22);
     g0 = fma(p0, f, g0); g1 = fma(p1, f, g1); g2 = fma(p2, f, g2);
 }
 
 template <typename CalT>
-__device__ __forceinline__ void triangulate_px(const CalT &C, double u, double v, double up, double vp, double X[3])
+__device__ __forceinline__ void triangulate_px(const CalT &C, const PinnedRows &R, double u, double v, double up, double vp, double X[3])
 {
     double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0, g0 = 0, g1 = 0, g2 = 0;
-    tri_row(C.Ac, u, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
-    tri_row(C.Ac, v, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
-    tri_row(C.Ap, up, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
-    tri_row(C.Ap, vp, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
+    tri_row(C.Ac, R.c2, u, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
+    tri_row(C.Ac, R.c2, v, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
+    tri_row(C.Ap, R.p2, up, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
+    tri_row(C.Ap, R.p2, vp, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
     const double c00 = fma(m11, m22, -m12 * m12);
     const double c01 = fma(m02, m12, -m01 * m22);
     const double c02 = fma(m01, m12, -m02 * m11);
@@ -374,8 +381,8 @@ struct PixelResult {
     bool valid;
 };
 
-template <bool KEEP, typename CalP>
-__device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, int gx, int gy, double cu, double cv,
+template <bool KEEP, bool PID, typename CalP>
+__device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, const PinnedRows &PR, int gx, int gy, double cu, double cv,
                                                    float wv, float wh, int code_v, int code_h, size_t keep_off)
 {
     PixelResult R;
@@ -402,10 +409,10 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, in
         P.cpmap[2 * keep_off + 0] = R.valid ? cx : 0;
         P.cpmap[2 * keep_off + 1] = R.valid ? cy : 0;
     }
-    if (R.valid) {
+    if (KEEP ? R.valid : true) {  // timed mode: branch-free (an invalid pixel's result is discarded by the caller)
         double up, vp, X[3];
         const auto &C = *Cp;
-        if (C.proj.identity) {
+        if (PID || C.proj.identity) {
             // no projector distortion and K = [fx 0 cx; 0 fy cy; 0 0 1]: the reference's undistort +
             // re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px): use x
             up = cxd;
@@ -413,7 +420,7 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, in
         } else {
             undistort_reproject(cxd, cyd, C.proj, up, vp);
         }
-        triangulate_px(C, cu, cv, up, vp, X);
+        triangulate_px(C, PR, cu, cv, up, vp, X);
         R.x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
         R.y = (float)X[1];
         R.z = (float)X[2];
@@ -441,7 +448,7 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, in
 // through LDS so they leave as three 16-B stores per lane (a wave writes 3 KiB contiguous).
 //
 // FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
-template <bool KEEP, int NMAX, bool FGEN, int OCC>
+template <bool KEEP, int NMAX, bool FGEN, int OCC, bool PID>
 __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
@@ -468,6 +475,13 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
         my_cam[2 * k + 1] = cv;
     }
 
+    PinnedRows PR;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        PR.c2[j] = Cglobal->Ac[8 + j];
+        PR.p2[j] = Cglobal->Ap[8 + j];
+        asm volatile("" : "+v"(PR.c2[j]), "+v"(PR.p2[j]));  // stay in VGPRs (see PinnedRows)
+    }
     const int Nv = P.Nv, Nh = P.Nh;
     const int v_begin = first_view + (int)blockIdx.y * vpt;
     const int v_end = min(v_begin + vpt, first_view + n_views);
@@ -492,8 +506,10 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
                 P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
             }
         }
+        if (KEEP || vbits == 0) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
+            for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
+        }
 
         if (vbits != 0) {
             // planes of a view: vertical axis (fringe F, gray Nv, inverse Nv), then the horizontal axis
@@ -544,31 +560,47 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
                 }
             }
             const int shA_v = Nv > 8 ? Nv - 8 : 0, shA_h = Nh > 8 ? Nh - 8 : 0;
+            if (KEEP) {
 #pragma unroll 1
-            for (int k = 0; k < 4; k++) {
-                if ((vbits >> k) & 1u) {
+                for (int k = 0; k < 4; k++) {
+                    if ((vbits >> k) & 1u) {
+                        const int sh = 8 * k;
+                        const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
+                        const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
+                        // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
+                        float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
+                        float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
+                        wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
+                        wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
+                        const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
+                        const PixelResult R = pixel_chain<true, false>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
+                        if (R.valid) {
+                            my_xyz[3 * k + 0] = R.x;
+                            my_xyz[3 * k + 1] = R.y;
+                            my_xyz[3 * k + 2] = R.z;
+                            vout |= 1u << (8 * k);
+                        }
+                    }
+                }
+            } else {
+                // timed mode: no divergent branch inside the pixel body, two pixels per iteration so the scheduler can
+                // interleave two independent fp64 dependency chains (the kernel is VALU-issue / latency bound)
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
                     const int sh = 8 * k;
                     const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
                     const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
-                    // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
                     float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
                     float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
                     wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                     wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                     const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
-                    PixelResult R;
-                    if (P.ablate & 1) {
-                        R.x = wv + (float)code_v; R.y = wh + (float)code_h; R.z = (float)(cu + cv); R.valid = true;
-                    } else {
-                        // calibration constants: scalar loads inside the loop (scalar cache), not 100 live SGPRs
-                        R = pixel_chain<KEEP>(P, opaque_const(Cglobal), gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
-                    }
-                    if (R.valid) {
-                        my_xyz[3 * k + 0] = R.x;
-                        my_xyz[3 * k + 1] = R.y;
-                        my_xyz[3 * k + 2] = R.z;
-                        vout |= 1u << (8 * k);
-                    }
+                    const PixelResult R = pixel_chain<false, PID>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
+                    const bool okpx = ((vbits >> k) & 1u) && R.valid;
+                    my_xyz[3 * k + 0] = okpx ? R.x : nanv;
+                    my_xyz[3 * k + 1] = okpx ? R.y : nanv;
+                    my_xyz[3 * k + 2] = okpx ? R.z : nanv;
+                    vout |= (okpx ? 1u : 0u) << sh;
                 }
             }
         }
@@ -582,22 +614,23 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
     }
 }
 
-template <bool KEEP, bool FGEN, int OCC>
+template <bool KEEP, bool FGEN, bool PID>
 static void launch_fused_n(int nmax, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     if (nmax <= 6)
-        hipLaunchKernelGGL((k_fused<KEEP, 6, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 6, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else if (nmax <= 8)
-        hipLaunchKernelGGL((k_fused<KEEP, 8, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 8, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else if (nmax <= 10)
-        hipLaunchKernelGGL((k_fused<KEEP, 10, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 10, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else if (nmax <= 12)
-        hipLaunchKernelGGL((k_fused<KEEP, 12, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, 12, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
     else
-        hipLaunchKernelGGL((k_fused<KEEP, SL3D_MAX_GRAY, FGEN, OCC>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+        hipLaunchKernelGGL((k_fused<KEEP, SL3D_MAX_GRAY, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
 }
 
-int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_views, bool keep, void *stream)
+// proj_identity: the projector has no distortion and a plain K (host knows; folded at compile time in the timed kernel)
+int launch_fused(const KParams &P, const DevCal *d_cal, bool proj_identity, int first_view, int n_views, bool keep, void *stream)
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = (unsigned)((quads + 255) / 256);
@@ -610,11 +643,14 @@ int launch_fused(const KParams &P, const DevCal *d_cal, int first_view, int n_vi
     const int nmax = P.Nv > P.Nh ? P.Nv : P.Nh;
     hipStream_t st = (hipStream_t)stream;
     if (keep) {
-        if (P.F == 3) launch_fused_n<true, false, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<true, true, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (P.F == 3) launch_fused_n<true, false, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<true, true, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (P.F != 3) {
+        launch_fused_n<false, true, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (proj_identity) {
+        launch_fused_n<false, false, true>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        if (P.F == 3) launch_fused_n<false, false, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<false, true, 4>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        launch_fused_n<false, false, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
     return (int)hipGetLastError();
 }
@@ -733,7 +769,9 @@ __global__ __launch_bounds__(256) void k_tri(const KParams P, const DevCal C, in
         double u, v, up, vp;
         undistort_reproject((double)(P.col0 + col), (double)(P.row0 + row), C.cam, u, v);
         undistort_reproject((double)P.cpmap[2 * px], (double)P.cpmap[2 * px + 1], C.proj, up, vp);
-        triangulate_px(C, u, v, up, vp, X);
+        PinnedRows PR;
+        for (int j = 0; j < 4; j++) { PR.c2[j] = C.Ac[8 + j]; PR.p2[j] = C.Ap[8 + j]; }
+        triangulate_px(C, PR, u, v, up, vp, X);
         x = (float)X[0];
         y = (float)X[1];
         z = (float)X[2];
