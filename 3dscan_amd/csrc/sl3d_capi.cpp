@@ -34,6 +34,10 @@ struct sl3d_ctx {
     std::string err;
     uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
     float *d_points = nullptr;
+    unsigned *d_blk_cnt = nullptr;            // compaction scratch: per-1024-pixel block counts,
+    unsigned long long *d_blk_off = nullptr;  // their exclusive scan, and the total
+    unsigned long long *d_total = nullptr;
+    float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
     size_t mask_rows = 0;
 };
@@ -182,6 +186,13 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     ALLOC(x->d_points, V * P.px_view_stride * 3);
     ALLOC(x->d_valid, V * P.px_view_stride);
     ALLOC(x->d_cal, 1);
+    {
+        const size_t nb = (P.px_view_stride + 1023) / 1024;
+        ALLOC(x->d_blk_cnt, nb);
+        ALLOC(x->d_blk_off, nb);
+        ALLOC(x->d_total, 1);
+        ALLOC(x->d_cloud, P.px_view_stride * 3);
+    }
     ALLOC(x->d_band, V * P.px_view_stride);
     CREATE_CHK(hipMemsetAsync(x->d_mask, 0, V * P.mask_view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_frames, 0, V * P.view_stride, x->stream));
@@ -583,22 +594,34 @@ extern "C" int sl3d_get_points(sl3d_ctx *x, int view, float *xyz, uint8_t *valid
     return rc;
 }
 
+extern "C" int sl3d_compact(sl3d_ctx *x, int view, const float **device_xyz, int64_t *count)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    if (!count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    rc = launched(x, launch_compact(x->P, view, x->d_blk_cnt, x->d_blk_off, x->d_total, x->d_cloud, x->stream));
+    if (rc) return rc;
+    unsigned long long n = 0;
+    HIPCHK(x, hipMemcpyAsync(&n, x->d_total, sizeof n, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    *count = (int64_t)n;
+    if (device_xyz) *device_xyz = x->d_cloud;
+    return SL3D_OK;
+}
+
 extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacity, int64_t *count)
 {
     if (!x || !count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
-    const KParams &P = x->P;
-    std::vector<float> pts((size_t)P.W * P.H * 3);
-    std::vector<uint8_t> val((size_t)P.W * P.H);
-    int rc = sl3d_get_points(x, view, pts.data(), val.data());
+    // row-major scan, valid pixels only (8/save_point_cloud.cpp:85-104), compacted on the device
+    const float *dev = nullptr;
+    int rc = sl3d_compact(x, view, &dev, count);
     if (rc) return rc;
-    // row-major scan, valid pixels only: 8/save_point_cloud.cpp:85-104
-    int64_t n = 0;
-    for (size_t i = 0; i < val.size(); i++)
-        if (val[i] == 1) {
-            if (xyz && n < capacity) memcpy(xyz + 3 * n, pts.data() + 3 * i, 3 * sizeof(float));
-            n++;
-        }
-    *count = n;
+    const int64_t n = *count < capacity ? *count : capacity;
+    if (xyz && n > 0) {
+        HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+    }
     return SL3D_OK;
 }
 

@@ -70,6 +70,8 @@ int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);
 int launch_corr(const KParams &P, int view, void *stream);
 int launch_tri(const KParams &P, const DevCal &C, int view, void *stream);
+int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned long long *block_offsets, unsigned long long *total,
+                   float *cloud, void *stream);
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 
 }  // namespace sl3d

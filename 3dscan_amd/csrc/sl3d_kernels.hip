@@ -520,10 +520,11 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
-                f[a][0] = ldg32(vb, p0 + lane_off);
-                f[a][1] = ldg32(vb, p0 + psv + lane_off);
-                f[a][2] = ldg32(vb, p0 + 2u * psv + lane_off);
-                f[a][3] = (FGEN && F == 4) ? ldg32(vb, p0 + 3u * psv + lane_off) : 0u;
+                // plane offsets are added to the scalar base (SALU); every load uses the same VGPR offset
+                f[a][0] = ldg32(vb + (size_t)p0, lane_off);
+                f[a][1] = ldg32(vb + (size_t)(p0 + psv), lane_off);
+                f[a][2] = ldg32(vb + (size_t)(p0 + 2u * psv), lane_off);
+                f[a][3] = (FGEN && F == 4) ? ldg32(vb + (size_t)(p0 + 3u * psv), lane_off) : 0u;
             }
 #pragma unroll
             for (int a = 0; a < 2; a++) {
@@ -532,8 +533,8 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
 #pragma unroll
                 for (int i = 0; i < NMAX; i++) {
                     const unsigned ii = (unsigned)min(i, N - 1);  // clamp: planes beyond N re-read plane N-1 and are ignored below
-                    g[a][i] = ldg32(vb, pg + ii * psv + lane_off);
-                    iv[a][i] = ldg32(vb, pg + ((unsigned)N + ii) * psv + lane_off);
+                    g[a][i] = ldg32(vb + (size_t)(pg + ii * psv), lane_off);
+                    iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + ii) * psv), lane_off);
                 }
             }
             // ---- Gray decode, byte-parallel over the 4 pixels of the lane ----
@@ -800,6 +801,86 @@ int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned
 {
     const int n = SL3D_ATAN_T1 * SL3D_ATAN_T2;
     hipLaunchKernelGGL(k_atan_selfcheck, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tab_phi, tab_shift, mismatches);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// O1 / N2: compaction of the dense cloud in the reference's row-major scan order
+// (8/save_point_cloud.cpp:33-37 counts the valid pixels, :85-104 appends them).  Three launches on the
+// context's stream: per-block counts (wave ballots), an exclusive scan of the block counts by one block,
+// and the scatter.  A block covers 1024 consecutive pixels of the pitch-padded plane; padding pixels are
+// never valid, so the scan order of the valid pixels is exactly the reference's.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact_count(const uint8_t *valid, size_t n_px, unsigned *block_counts)
+{
+    __shared__ unsigned s_cnt[4];
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    unsigned w = base < n_px ? *(const unsigned *)(valid + base) : 0u;  // 4 valid bytes (0/1)
+    unsigned c = __popc(w & 0x01010101u);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// exclusive scan of n counts by a single 1024-thread block (n is a few thousand .. tens of thousands)
+__global__ __launch_bounds__(1024) void k_compact_scan(const unsigned *counts, unsigned long long *offsets, int n, unsigned long long *total)
+{
+    __shared__ unsigned long long s_part[1024];
+    const int per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, n);
+    unsigned long long sum = 0;
+    for (int i = lo; i < hi; i++) sum += counts[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+        unsigned long long v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long run = threadIdx.x == 0 ? 0 : s_part[threadIdx.x - 1];
+    for (int i = lo; i < hi; i++) { offsets[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023) *total = s_part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_compact_scatter(const uint8_t *valid, const float *points, size_t n_px,
+                                                         const unsigned long long *block_offsets, float *cloud)
+{
+    __shared__ unsigned s_wave[4];
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    const unsigned w = base < n_px ? (*(const unsigned *)(valid + base) & 0x01010101u) : 0u;
+    const unsigned c = __popc(w);
+    // exclusive prefix of c over the block: wave scan by shuffles, then the 4 wave totals
+    unsigned incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if ((threadIdx.x & 63) >= off) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned wave_base = 0;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); i++) wave_base += s_wave[i];
+    unsigned long long dst = block_offsets[blockIdx.x] + wave_base + (incl - c);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if ((w >> (8 * k)) & 1u) {
+            const float *p = points + 3 * (base + k);
+            float *q = cloud + 3 * dst++;
+            q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+        }
+}
+
+int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned long long *block_offsets, unsigned long long *total,
+                   float *cloud, void *stream)
+{
+    const size_t n_px = P.px_view_stride;
+    const int nb = (int)((n_px + 1023) / 1024);
+    const uint8_t *valid = P.valid + (size_t)view * P.px_view_stride;
+    const float *points = P.points + 3 * (size_t)view * P.px_view_stride;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, st, valid, n_px, block_counts);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_counts, block_offsets, nb, total);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(256), 0, st, valid, points, n_px, block_offsets, cloud);
     return (int)hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_get_device_buffers",
+    "sl3d_get_cloud", "sl3d_compact", "sl3d_get_device_buffers",
 )
 
 
@@ -89,6 +89,7 @@ def load_library(path=None):
     L.sl3d_get_intersection_points.argtypes = [vp, i, vp]
     L.sl3d_get_points.argtypes = [vp, i, vp, vp]
     L.sl3d_get_cloud.argtypes = [vp, i, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sl3d_compact.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
     if path is None:
         _lib = L

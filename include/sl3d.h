@@ -184,6 +184,10 @@ int sl3d_get_points(sl3d_ctx *ctx, int view, float *xyz, uint8_t *valid);
  * writes at most `capacity` points, always returns the total count in *count */
 int sl3d_get_cloud(sl3d_ctx *ctx, int view, float *xyz, int64_t capacity, int64_t *count);
 
+/* the same compaction left on the device (valid until the next sl3d_compact / sl3d_get_cloud on this context):
+ * *device_xyz points at count*3 floats in HBM; the count comes back to the host */
+int sl3d_compact(sl3d_ctx *ctx, int view, const float **device_xyz, int64_t *count);
+
 /* ---- device-resident access ---------------------------------------------------------------- */
 int sl3d_get_device_buffers(sl3d_ctx *ctx, sl3d_device_buffers *out);
 /* normalise a mask written directly into the device buffer to 0/1 bytes is the caller's duty */
