@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--noise", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-assemble", action="store_true", help="skip the separate RCCL assembly measurement (N>1)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of one view timed on the CPU (0 = whole view)")
     return ap.parse_args()
 
@@ -116,10 +117,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)  # one GPU per rank on a real node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = dev if args.backend == "nccl" else None  # where the tiny timing reductions live
 
     syn = importlib.import_module("3dscan_amd.synth")
     scm = importlib.import_module("3dscan_amd.scanner")
@@ -133,7 +139,7 @@ def main():
     caps = [syn.make_capture(W, rows, PW, PH, N, N, fw, fw, row0=row0, full=(W, H), noise=args.noise, view=i,
                              plane=(2.0 * i, 0.05, 0.05 - 0.02 * i)) for i in range(n_distinct)]
     cal = syn.cal_tuple(caps[0]["cal"])
-    sc = scm.Scanner(W, rows, PW, PH, N, N, fw, fw, max_views=n_views, device=local_rank, full_size=(W, H), origin=(0, row0))
+    sc = scm.Scanner(W, rows, PW, PH, N, N, fw, fw, max_views=n_views, device=dev_index, full_size=(W, H), origin=(0, row0))
     sc.set_calibration(*cal)
     full_mask = syn.default_mask(W, H)
     for i, c in enumerate(caps):
@@ -159,8 +165,8 @@ def main():
     ev_ms = sc.timer_stop()                # second event, waited for
     barrier()
     dt = time.perf_counter() - t0
-    dt = dmod.max_over_ranks(dt, dev)
-    ev_ms = dmod.max_over_ranks(ev_ms, dev)
+    dt = dmod.max_over_ranks(dt, red_dev)
+    ev_ms = dmod.max_over_ranks(ev_ms, red_dev)
 
     px_per_launch = n_views * rows * W                     # pixels one launch processes on one GPU
     total_px = args.steps * px_per_launch * world
@@ -182,7 +188,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": measured_traffic(px_per_launch) if alg_bytes_px == 60 else None,
-                     "kernel": "sl3d::k_fused<false>", "algorithmic_bytes_per_pixel": alg_bytes_px,
+                     "kernel": "sl3d::k_fused<false, 10, false, 4, true>", "algorithmic_bytes_per_pixel": alg_bytes_px,
                      "pixels_per_launch": px_per_launch, "avg_launch_ms": round(launch_s * 1e3, 4)},
     }
 
