@@ -38,6 +38,7 @@ struct sl3d_ctx {
     unsigned long long *d_blk_off = nullptr;  // their exclusive scan, and the total
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
+    float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
     DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
     size_t mask_rows = 0;
 };
@@ -620,6 +621,46 @@ extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacit
     const int64_t n = *count < capacity ? *count : capacity;
     if (xyz && n > 0) {
         HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+    }
+    return SL3D_OK;
+}
+
+// register_point_clouds(), 9/register_point_clouds.cpp:23-155, without the PLY files: the clouds are the
+// compacted clouds of the resident views, view k is rotated about Y by theta_k around (tx,ty,tz), theta_0 = 0,
+// theta_{k+1} = theta_k + rot_step in float (:145), angles in degrees converted with Pi = 22/7 (:89-93).
+extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, float tx, float ty, float tz, float rot_step, float *xyz,
+                                   int64_t capacity, int64_t *total)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!total) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const KParams &P = x->P;
+    if (!x->d_reg) {
+        rc = dev_alloc(x, &x->d_reg, (size_t)x->cfg.max_views * P.px_view_stride * 3);
+        if (rc) return rc;
+    }
+    float theta = 0.0f;
+    int64_t off = 0;
+    for (int k = 0; k < n_views; k++) {
+        int64_t n = 0;
+        const float *cloud = nullptr;
+        rc = sl3d_compact(x, first_view + k, &cloud, &n);
+        if (rc) return rc;
+        // R entries as the reference stores them: double cos/sin of theta*Pi/180.0 (Pi = 22.0/7.0), rounded to float
+        const float R4[4] = {(float)cos(theta * 22.0 / 7.0 / 180.0), (float)(-1.0f * sin(theta * 22.0 / 7.0 / 180.0)),
+                             (float)sin(theta * 22.0 / 7.0 / 180.0), (float)cos(theta * 22.0 / 7.0 / 180.0)};
+        rc = launched(x, launch_register(cloud, x->d_reg + 3 * off, (long)n, R4, tx, ty, tz, x->stream));
+        if (rc) return rc;
+        HIPCHK(x, hipStreamSynchronize(x->stream));  // d_cloud is reused by the next view's compaction
+        off += n;
+        theta += rot_step;
+    }
+    *total = off;
+    const int64_t m = off < capacity ? off : capacity;
+    if (xyz && m > 0) {
+        HIPCHK(x, hipMemcpyAsync(xyz, x->d_reg, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         HIPCHK(x, hipStreamSynchronize(x->stream));
     }
     return SL3D_OK;

@@ -72,6 +72,7 @@ int launch_corr(const KParams &P, int view, void *stream);
 int launch_tri(const KParams &P, const DevCal &C, int view, void *stream);
 int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned long long *block_offsets, unsigned long long *total,
                    float *cloud, void *stream);
+int launch_register(const float *in, float *out, long n, const float R4[4], float tx, float ty, float tz, void *stream);
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 
 }  // namespace sl3d

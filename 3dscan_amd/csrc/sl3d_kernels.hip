@@ -884,6 +884,33 @@ int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned 
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// N3: turntable registration, 9/register_point_clouds.cpp:83-128.  Per point, in the reference's types:
+// p -= t (float), p = R*p with the float GEMM of cvMatMul (double accumulator, k ascending, rounded to float on
+// store), p += t (float).  R = rotation about Y by theta (row 1 and the last column are the identity's).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_register(const float *in, float *out, long n, float r00, float r02, float r20, float r22,
+                                                  float tx, float ty, float tz)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[3 * i + 0] - tx, y = in[3 * i + 1] - ty, z = in[3 * i + 2] - tz;  // :109-111
+    // rows of R: (r00, 0, r02, 0), (0, 1, 0, 0), (r20, 0, r22, 0); the products with exact zeros add nothing
+    const float X = (float)(((double)r00 * (double)x + 0.0 * (double)y) + (double)r02 * (double)z);  // :113
+    const float Y = (float)((0.0 * (double)x + 1.0 * (double)y) + 0.0 * (double)z);
+    const float Z = (float)(((double)r20 * (double)x + 0.0 * (double)y) + (double)r22 * (double)z);
+    out[3 * i + 0] = X + tx;  // :115-117
+    out[3 * i + 1] = Y + ty;
+    out[3 * i + 2] = Z + tz;
+}
+
+int launch_register(const float *in, float *out, long n, const float R4[4], float tx, float ty, float tz, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_register, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, R4[0], R4[1], R4[2], R4[3], tx, ty, tz);
+    return (int)hipGetLastError();
+}
+
 static dim3 px_grid(const KParams &P) { return dim3((unsigned)(((long)P.pitch * P.H + 255) / 256), 1, 1); }
 
 int launch_wrap(const KParams &P, int view, int axis, void *stream)

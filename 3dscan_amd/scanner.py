@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_compact", "sl3d_get_device_buffers",
+    "sl3d_get_cloud", "sl3d_compact", "sl3d_register_views", "sl3d_get_device_buffers",
 )
 
 
@@ -90,6 +90,7 @@ def load_library(path=None):
     L.sl3d_get_points.argtypes = [vp, i, vp, vp]
     L.sl3d_get_cloud.argtypes = [vp, i, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_compact.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.sl3d_register_views.argtypes = [vp, i, i, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
     if path is None:
         _lib = L
@@ -238,6 +239,15 @@ class Scanner:
         self._chk(self.L.sl3d_get_cloud(self._h, view, None, 0, C.byref(n)), "sl3d_get_cloud")
         out = np.empty((n.value, 3), dtype=np.float32)
         self._chk(self.L.sl3d_get_cloud(self._h, view, out.ctypes.data, n.value, C.byref(n)), "sl3d_get_cloud")
+        return out
+
+    def register_views(self, first_view, n_views, tx, ty, tz, rot_step):
+        """register_point_clouds(): rotate view k by k*rot_step degrees about Y through (tx,ty,tz), concatenate."""
+        n = C.c_int64(0)
+        self._chk(self.L.sl3d_register_views(self._h, first_view, n_views, tx, ty, tz, rot_step, None, 0, C.byref(n)), "sl3d_register_views")
+        out = np.empty((n.value, 3), dtype=np.float32)
+        self._chk(self.L.sl3d_register_views(self._h, first_view, n_views, tx, ty, tz, rot_step, out.ctypes.data, n.value, C.byref(n)),
+                  "sl3d_register_views")
         return out
 
     def device_buffers(self):

@@ -188,6 +188,13 @@ int sl3d_get_cloud(sl3d_ctx *ctx, int view, float *xyz, int64_t capacity, int64_
  * *device_xyz points at count*3 floats in HBM; the count comes back to the host */
 int sl3d_compact(sl3d_ctx *ctx, int view, const float **device_xyz, int64_t *count);
 
+/* register_point_clouds(unsigned, float tx, float ty, float tz, float rot_step)  9/register_point_clouds.cpp:23:
+ * the compacted clouds of views [first_view, first_view+n_views) are rotated about the Y axis through (tx,ty,tz)
+ * by 0, rot_step, 2*rot_step ... degrees and concatenated in view order; writes at most `capacity` points to xyz
+ * (may be NULL) and always returns the total count. */
+int sl3d_register_views(sl3d_ctx *ctx, int first_view, int n_views, float tx, float ty, float tz, float rot_step,
+                        float *xyz, int64_t capacity, int64_t *total);
+
 /* ---- device-resident access ---------------------------------------------------------------- */
 int sl3d_get_device_buffers(sl3d_ctx *ctx, sl3d_device_buffers *out);
 /* normalise a mask written directly into the device buffer to 0/1 bytes is the caller's duty */

@@ -54,6 +54,7 @@ def _load():
         L.orc_get_projection_matrices.argtypes = [vp, vp, vp]
         L.orc_get_undist_point.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.orc_run_scan.argtypes = [vp, vp, vp, C.c_size_t]
+        L.orc_register_point_clouds.argtypes = [C.c_uint, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
         _lib = L
     return _lib
 
@@ -181,3 +182,14 @@ class Oracle:
         out = np.empty((n, 3), dtype=np.float32)
         L.orc_save_point_cloud(self._s, out.ctypes.data, n)
         return out
+
+
+def register_point_clouds(clouds, tx, ty, tz, rot_step):
+    """9/register_point_clouds.cpp on in-memory clouds: list of (n_i,3) float32 arrays -> concatenated (sum n_i,3)."""
+    L = _load()
+    arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    counts = (C.c_long * len(arrs))(*[len(a) for a in arrs])
+    out = np.empty((sum(len(a) for a in arrs), 3), dtype=np.float32)
+    L.orc_register_point_clouds(len(arrs), ptrs, counts, tx, ty, tz, rot_step, out.ctypes.data)
+    return out

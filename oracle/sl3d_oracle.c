@@ -654,6 +654,41 @@ void orc_get_undist_point(orc_state *s, int dev, int col, int row, double *uv)
     }
 }
 
+/* N3: register_point_clouds, 9/register_point_clouds.cpp:83-148, on in-memory clouds (the reference reads PLY files).
+   clouds: n_clouds arrays of counts[i] xyz floats; out receives the concatenation.  R is a 4x4 float matrix whose
+   entries outside the rotation block the reference leaves uninitialised (:36-52 commented out): zero / identity here.
+   cvMatMul on CV_32FC1 accumulates in double, k ascending, and rounds to float on store. */
+void orc_register_point_clouds(unsigned num_point_clouds, const float *const *clouds, const long *counts, float tx, float ty, float tz,
+                               float rot_step, float *out)
+{
+    float R[4][4];
+    memset(R, 0, sizeof R);
+    R[1][1] = 1.0f; R[3][3] = 1.0f; /* :34-35 */
+    float theta = 0.0;              /* :79 */
+    long prev_last_point_id = 0;
+    for (unsigned i = 0; i < num_point_clouds; i++) {
+        R[0][0] = cos(theta * Pi / 180.0);          /* :89 */
+        R[0][2] = -1.0f * sin(theta * Pi / 180.0);  /* :90 */
+        R[2][0] = sin(theta * Pi / 180.0);          /* :92 */
+        R[2][2] = cos(theta * Pi / 180.0);          /* :93 */
+        for (long point_id = 0; point_id < counts[i]; point_id++) {
+            float point[4] = {clouds[i][3 * point_id], clouds[i][3 * point_id + 1], clouds[i][3 * point_id + 2], 1.0f}; /* :104-107 */
+            point[0] -= tx; point[1] -= ty; point[2] -= tz; /* :109-111 */
+            float res[4];
+            for (int r = 0; r < 4; r++) { /* cvMatMul(R,point,point) :113 */
+                double acc = 0;
+                for (int k = 0; k < 4; k++) acc += (double)R[r][k] * (double)point[k];
+                res[r] = (float)acc;
+            }
+            res[0] += tx; res[1] += ty; res[2] += tz; /* :115-117 */
+            float *o = out + 3 * (prev_last_point_id + point_id);
+            o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        }
+        theta += rot_step; /* :145 */
+        prev_last_point_id += counts[i];
+    }
+}
+
 /* One whole scan in main()'s order, m_tech_project_console.cpp:366-395:
    S3(v), S3(h), S4(v), S4(h), S5, S7.  planes_v / planes_h hold F fringe, then N gray,
    then N inverse-gray row-major planes.  This is what bench.py's cpu_baseline times. */

@@ -281,3 +281,29 @@ def test_batch_of_views_matches_single_views():
             assert np.array_equal(val, batch[v][1])
             assert np.array_equal(xyz[val == 1], batch[v][0][val == 1])
     assert not np.array_equal(batch[0][0][batch[0][1] == 1][:100], batch[1][0][batch[1][1] == 1][:100])
+
+
+def test_turntable_registration():
+    """N3 (9/register_point_clouds.cpp): per-view rotation about Y with Pi = 22/7, float accumulation of theta,
+    float GEMM with double accumulator -- bit exact against the oracle, clouds in the reference's scan order."""
+    from oracle.oracle import register_point_clouds
+    S, syn = _scanner(), pkg("synth")
+    W, H, PW, PH, N, fw = 200, 96, 256, 256, 6, 4
+    caps = [syn.make_capture(W, H, PW, PH, N, N, fw, fw, view=v, noise=1, plane=(1.0 * v, 0.05, 0.03)) for v in range(3)]
+    rng = np.random.default_rng(11)
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=3) as sc:
+        sc.set_calibration(*syn.cal_tuple(caps[0]["cal"]))
+        for v, c in enumerate(caps):
+            m = c["mask"].copy()
+            m[rng.random((H, W)) < 0.1 * v] = 0
+            sc.set_mask(m, view=v)
+            sc.set_frames(0, c["planes_v"], view=v)
+            sc.set_frames(1, c["planes_h"], view=v)
+        sc.run(0, 3)
+        clouds = [sc.cloud(v) for v in range(3)]
+        assert len({len(c) for c in clouds}) > 1
+        for tx, ty, tz, step in ((50.0, 30.0, -5.0, 30.0), (0.0, 0.0, 0.0, 0.0), (12.5, -3.25, 7.0, 7.3)):
+            got = sc.register_views(0, 3, tx, ty, tz, step)
+            ref = register_point_clouds(clouds, tx, ty, tz, step)
+            assert got.shape == ref.shape
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -170,3 +170,25 @@ def test_point_cloud_order():
     v = o.valid_map(2) == 1
     assert cloud.shape == (int(v.sum()), 3)
     assert np.array_equal(cloud, o.intersection_points()[v].astype(np.float32))
+
+
+def test_registration_oracle_matches_numpy():
+    """N3 oracle against a numpy restatement of the same float/double steps."""
+    from oracle.oracle import register_point_clouds
+    rng = np.random.default_rng(2)
+    clouds = [rng.normal(0, 50, (n, 3)).astype(np.float32) for n in (17, 0, 301)]
+    t = np.array([10.5, -2.0, 33.0], np.float32)
+    step = np.float32(40.0)
+    out = register_point_clouds(clouds, float(t[0]), float(t[1]), float(t[2]), float(step))
+    theta, parts = np.float32(0.0), []
+    for c in clouds:
+        a = float(theta) * 22.0 / 7.0 / 180.0
+        R = np.zeros((4, 4), np.float32)
+        R[1, 1] = R[3, 3] = 1
+        R[0, 0] = R[2, 2] = np.float32(np.cos(a)); R[0, 2] = np.float32(-1.0 * np.sin(a)); R[2, 0] = np.float32(np.sin(a))
+        p = np.concatenate([c - t, np.ones((len(c), 1), np.float32)], 1).astype(np.float32)
+        q = (R.astype(np.float64) @ p.astype(np.float64).T).T.astype(np.float32)[:, :3] + t
+        parts.append(q.astype(np.float32))
+        theta = np.float32(theta + step)
+    assert np.allclose(out, np.concatenate(parts), rtol=1e-6, atol=1e-5)
+    assert out.shape == (318, 3)
