@@ -307,3 +307,64 @@ def test_turntable_registration():
             ref = register_point_clouds(clouds, tx, ty, tz, step)
             assert got.shape == ref.shape
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("Nv,Nh,fwv,fwh,PW,PH", [(6, 5, 32, 32, 1280, 720), (12, 12, 1, 1, 600, 400), (16, 9, 3, 5, 500, 333),
+                                                (1, 2, 64, 64, 100, 200), (9, 8, 2, 4, 1024, 768)])
+def test_gray_depths_and_fringe_widths(Nv, Nh, fwv, fwh, PW, PH):
+    """Different bit depths per axis (the reference's own 6/5 with fw=32), the maximum of 16 planes, a single plane,
+    fringe widths that are not powers of two, projector sizes that are not multiples of the fringe width; random
+    frame bytes so every code value and many out-of-range correspondences occur."""
+    syn = pkg("synth")
+    W, H = 168, 60
+    cap = syn.make_capture(W, H, 256, 256, 8, 8, 4, 4)
+    rng = np.random.default_rng(Nv * 100 + Nh)
+    cap["planes_v"] = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(3 + 2 * Nv)]
+    cap["planes_h"] = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(3 + 2 * Nh)]
+    mask = (rng.random((H, W)) < 0.85).astype(np.uint8)
+    _run_both(W, H, PW, PH, Nv, Nh, fwv, fwh, cap, mask)
+
+
+def test_api_errors():
+    """Error behaviour of the C ABI on a live context: bad arguments and call-order violations are reported, not executed."""
+    S = _scanner()
+    with S.Scanner(64, 32, 128, 128, 5, 5, 4, 4) as sc:  # no KEEP_STAGES, no calibration yet
+        with pytest.raises(S.Sl3dError, match="call order"):
+            sc.run()
+        with pytest.raises(S.Sl3dError, match="call order"):
+            sc.compute_wrapped_phase(0)
+        with pytest.raises(S.Sl3dError, match="invalid argument"):
+            sc.set_frames(0, [np.zeros((32, 64), np.uint8)] * 5)  # needs 3 + 2*5 planes
+        with pytest.raises(S.Sl3dError, match="invalid argument"):
+            sc.run(0, 2)  # max_views is 1
+        with pytest.raises(S.Sl3dError):
+            sc.wrapped_phase(0)  # stage planes were not requested
+    with pytest.raises(S.Sl3dError, match="invalid argument"):
+        S.Scanner(64, 32, 128, 128, 5, 5, 4, 4, full_size=(32, 32))  # window larger than the frame
+    with pytest.raises(S.Sl3dError, match="unsupported"):
+        S.Scanner(64, 32, 128, 128, 17, 5, 4, 4)
+
+
+def test_rerun_is_idempotent_and_masks_can_change():
+    """Running the same view twice gives identical bits; changing only the mask changes only validity."""
+    S, syn = _scanner(), pkg("synth")
+    W, H, PW, PH, N, fw = 256, 64, 512, 256, 7, 4
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw, noise=2)
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw) as sc:
+        sc.set_calibration(*syn.cal_tuple(cap["cal"]))
+        sc.set_mask(cap["mask"])
+        sc.set_frames(0, cap["planes_v"])
+        sc.set_frames(1, cap["planes_h"])
+        sc.run()
+        a = sc.points()
+        sc.run()
+        b = sc.points()
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        m2 = cap["mask"].copy()
+        m2[:, W // 2:] = 0
+        sc.set_mask(m2)
+        sc.run()
+        c = sc.points()
+        assert c[1][:, W // 2:].sum() == 0
+        keep = c[1] == 1
+        assert np.array_equal(c[0][keep].view(np.uint32), a[0][keep].view(np.uint32))
