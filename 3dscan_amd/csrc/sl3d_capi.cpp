@@ -25,6 +25,7 @@ struct sl3d_ctx {
     sl3d_config cfg{};
     KParams P{};
     DevCal C{};
+    SynthParams S{};  // extrinsics kept for the synthetic-capture generator
     bool have_cal = false;
     bool keep = false;
     bool own_stream = false;
@@ -320,6 +321,11 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     projection_matrix(Kp, rp, tp, x->C.Ap);
     fill_intr(x->C.cam, Kc, dc);
     fill_intr(x->C.proj, Kp, dp);
+    rodrigues(rc, x->S.Rc);
+    rodrigues(rp, x->S.Rp);
+    memcpy(x->S.tc, tc, sizeof x->S.tc);
+    memcpy(x->S.tp, tp, sizeof x->S.tp);
+    memcpy(x->S.Kp, Kp, sizeof x->S.Kp);
     HIPCHK(x, hipSetDevice(x->cfg.device));
     HIPCHK(x, hipStreamSynchronize(x->stream));  // no launch may still be reading the previous constants
     HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
@@ -419,6 +425,44 @@ extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
                              P.mask_view_stride, hipMemcpyDeviceToDevice, x->stream));
     HIPCHK(x, hipMemcpyAsync(x->d_band + (size_t)dst * P.px_view_stride, x->d_band + (size_t)src * P.px_view_stride, P.px_view_stride,
                              hipMemcpyDeviceToDevice, x->stream));
+    return SL3D_OK;
+}
+
+static int launched(sl3d_ctx *x, int hip_err);
+
+// Synthetic capture of one view written straight into the resident frame stack (N1; formulas of
+// 1/pattern_generator.cpp:80-105,302,313,497 -- see k_synth).  Benchmark / test input, not part of the timed path.
+extern "C" int sl3d_synth_view(sl3d_ctx *x, int view, const double plane[3], uint64_t seed, int view_id, int noise, float gain, float offset)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    if (!plane) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
+    if (x->P.PW > x->P.fwv * (1 << x->P.Nv) || x->P.PH > x->P.fwh * (1 << x->P.Nh))
+        return fail(x, SL3D_E_INVALID_ARG, "Gray code too short for the projector size");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    SynthParams S = x->S;
+    S.z0 = plane[0]; S.a = plane[1]; S.b = plane[2];
+    S.seed = seed; S.view_id = view_id; S.noise = noise; S.gain = gain; S.offset = offset;
+    return launched(x, launch_synth(x->P, x->C, S, view, x->stream));
+}
+
+// the resident frames of one axis of one view, back to host planes (fringe, gray, inverse gray order)
+extern "C" int sl3d_get_frames(sl3d_ctx *x, int view, int axis, uint8_t *const *planes, int n_planes, size_t stride)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    const KParams &P = x->P;
+    const int N = axis == 0 ? P.Nv : P.Nh;
+    if ((axis != 0 && axis != 1) || !planes || n_planes != P.F + 2 * N || stride < (size_t)P.W)
+        return fail(x, SL3D_E_INVALID_ARG, "get_frames: expected n_fringe + 2*n_gray planes and stride >= width");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
+    for (int i = 0; i < n_planes; i++) {
+        const uint8_t *src = x->d_frames + (size_t)view * P.view_stride + (size_t)(base + i) * P.plane_stride;
+        HIPCHK(x, hipMemcpy2DAsync(planes[i], stride, src, P.pitch, P.W, P.H, hipMemcpyDeviceToHost, x->stream));
+    }
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 

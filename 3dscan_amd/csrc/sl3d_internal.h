@@ -30,6 +30,17 @@ struct DevCal {
     Intr cam, proj;
 };
 
+// Scene + camera model of the synthetic-capture generator (k_synth).
+struct SynthParams {
+    double Rc[9], tc[3], Rp[9], tp[3];  // world -> camera / projector
+    double Kp[9];
+    double z0, a, b;                    // plane Z = z0 + a*X + b*Y
+    float gain, offset;
+    int noise;                          // uniform integer noise in [-noise, noise]
+    unsigned long long seed;
+    int view_id;                        // enters the noise hash
+};
+
 // Everything a kernel needs to address one context's buffers.
 struct KParams {
     int W, H;                  // window
@@ -73,6 +84,7 @@ int launch_tri(const KParams &P, const DevCal &C, int view, void *stream);
 int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned long long *block_offsets, unsigned long long *total,
                    float *cloud, void *stream);
 int launch_register(const float *in, float *out, long n, const float R4[4], float tx, float ty, float tz, void *stream);
+int launch_synth(const KParams &P, const DevCal &C, const SynthParams &S, int view, void *stream);
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 
 }  // namespace sl3d

@@ -911,6 +911,118 @@ int launch_register(const float *in, float *out, long n, const float R4[4], floa
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// N1: synthetic captures generated in place.  A plane Z = z0 + a*X + b*Y in the world frame is
+// seen by the calibrated camera/projector pair; each camera pixel's ray (5-iteration undistortion, as stage 7
+// applies it) is intersected with the plane and projected into the projector -> (xp, yp); the projected patterns
+// follow the reference's generator: fringe k = 127 + 128*cosf((p/fw)*2*Pi - Pi - Pi/2 + k*Pi/2), Pi = 22/7
+// (1/pattern_generator.cpp:302,313), Gray bit i of floor(p/fw), MSB first, x255 (:80-105), inverse = 255 - pattern
+// (:497); then gain, offset and counter-hash noise.  Host twin: 3dscan_amd/synth.py (same formulas; the trig
+// functions differ in the last ulp, so a few bytes per million differ by one grey level).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ unsigned synth_camera(unsigned I, bool lit, const SynthParams &S, unsigned long long key, int gx, int gy)
+{
+    int nz = 0;
+    if (S.noise > 0) {
+        const unsigned long long idx = ((unsigned long long)gy << 20) + (unsigned long long)gx;
+        nz = (int)(splitmix64(idx ^ key) % (unsigned long long)(2 * S.noise + 1)) - S.noise;
+    }
+    const float lin = (lit ? S.gain * (float)I : 0.0f) + S.offset;
+    const double v = floor((double)lin + (double)nz + 0.5);
+    return (unsigned)fmin(fmax(v, 0.0), 255.0);
+}
+
+__global__ __launch_bounds__(256) void k_synth(const KParams P, const DevCal C, const SynthParams S, int view)
+{
+    const int qpr = P.pitch >> 2;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(q / qpr), cq = (int)(q - (long)row * qpr);
+    if (row >= P.H) return;
+    uint8_t *vb = (uint8_t *)P.frames + (size_t)view * P.view_stride + (size_t)row * P.pitch + (size_t)cq * 4;
+    const int gy = P.row0 + row;
+    double xp[4], yp[4];
+    bool lit[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int gx = P.col0 + cq * 4 + k;
+        // normalised undistorted ray of the camera pixel (the first half of undistort_reproject)
+        const Intr &I = C.cam;
+        const double x0 = ((double)gx - I.cx) * I.ifx, y0 = ((double)gy - I.cy) * I.ify;
+        double x = x0, y = y0;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icd = 1.0 / (1.0 + ((I.k3 * r2 + I.k2) * r2 + I.k1) * r2);
+            const double dx = 2.0 * I.p1 * x * y + I.p2 * (r2 + 2.0 * x * x), dy = I.p1 * (r2 + 2.0 * y * y) + 2.0 * I.p2 * x * y;
+            x = (x0 - dx) * icd;
+            y = (y0 - dy) * icd;
+        }
+        // world ray: origin ow = -Rc^T tc, direction dw = Rc^T (x,y,1); plane normal n = (-a,-b,1), n.X = z0
+        double dw[3], ow[3];
+        for (int i = 0; i < 3; i++) {
+            dw[i] = S.Rc[0 * 3 + i] * x + S.Rc[1 * 3 + i] * y + S.Rc[2 * 3 + i];
+            ow[i] = -(S.Rc[0 * 3 + i] * S.tc[0] + S.Rc[1 * 3 + i] * S.tc[1] + S.Rc[2 * 3 + i] * S.tc[2]);
+        }
+        const double lam = (S.z0 - (-S.a * ow[0] - S.b * ow[1] + ow[2])) / (-S.a * dw[0] - S.b * dw[1] + dw[2]);
+        double Xw[3], Xq[3];
+        for (int i = 0; i < 3; i++) Xw[i] = ow[i] + lam * dw[i];
+        for (int i = 0; i < 3; i++) Xq[i] = S.Rp[i * 3 + 0] * Xw[0] + S.Rp[i * 3 + 1] * Xw[1] + S.Rp[i * 3 + 2] * Xw[2] + S.tp[i];
+        xp[k] = S.Kp[0] * Xq[0] / Xq[2] + S.Kp[2];
+        yp[k] = S.Kp[4] * Xq[1] / Xq[2] + S.Kp[5];
+        lit[k] = xp[k] >= 0.0 && xp[k] < (double)P.PW && yp[k] >= 0.0 && yp[k] < (double)P.PH;
+    }
+    int plane = 0;
+#pragma unroll 1
+    for (int axis = 0; axis < 2; axis++) {
+        const int N = axis == 0 ? P.Nv : P.Nh, fw = axis == 0 ? P.fwv : P.fwh;
+        float pf[4];
+        int gray[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            pf[k] = (float)(axis == 0 ? xp[k] : yp[k]);
+            int code = (int)floorf(pf[k] / (float)fw);
+            code = min(max(code, 0), (1 << N) - 1);
+            gray[k] = code ^ (code >> 1);
+        }
+        int fidx = axis * 1000;  // frame index inside the noise key, as in synth.py
+        for (int fr = 0; fr < P.F + 2 * N; fr++, fidx++, plane++) {
+            const unsigned long long key =
+                splitmix64(S.seed * 0x100000001B3ull + (unsigned long long)S.view_id * 1000003ull + (unsigned long long)fidx);
+            unsigned word = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned I;
+                if (fr < P.F) {
+                    const double arg = (double)(pf[k] / (float)fw) * 2.0 * PI_REF - PI_REF - ((PI_REF) / 2.0) + (PI_REF / 2.0) * (double)fr;
+                    const float t = 127.0f + 128.0f * cosf((float)arg);
+                    I = (unsigned)fminf(fmaxf(t, 0.0f), 255.0f);
+                } else {
+                    const int i = (fr - P.F) % N;
+                    const unsigned bit = (unsigned)(gray[k] >> (N - 1 - i)) & 1u;
+                    I = (fr - P.F) < N ? bit * 255u : 255u - bit * 255u;
+                }
+                word |= synth_camera(I, lit[k], S, key, P.col0 + cq * 4 + k, gy) << (8 * k);
+            }
+            *(unsigned *)(vb + (size_t)plane * P.plane_stride) = word;
+        }
+    }
+}
+
+int launch_synth(const KParams &P, const DevCal &C, const SynthParams &S, int view, void *stream)
+{
+    const long quads = (long)(P.pitch >> 2) * P.H;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, C, S, view);
+    return (int)hipGetLastError();
+}
+
 static dim3 px_grid(const KParams &P) { return dim3((unsigned)(((long)P.pitch * P.H + 255) / 256), 1, 1); }
 
 int launch_wrap(const KParams &P, int view, int axis, void *stream)

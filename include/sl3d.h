@@ -138,6 +138,15 @@ int sl3d_set_frames(sl3d_ctx *ctx, int view, int axis, const uint8_t *const *pla
 /* Device-to-device duplicate of one resident view (frame stack + mask) into another slot of the batch. */
 int sl3d_copy_view(sl3d_ctx *ctx, int src_view, int dst_view);
 
+/* Synthetic capture generated on the device into view slot `view` (inputs for tests and benchmarks; the pattern
+ * formulas are the reference generator's, 1/pattern_generator.cpp:80-105,302,313,497, Pi = 22/7): plane[3] = z0,a,b of
+ * the scene plane Z = z0 + a*X + b*Y in the world frame of the calibration set with sl3d_set_calibration; camera
+ * model I' = clamp(round(gain*I + offset + noise)), noise uniform in [-noise, noise] from a counter hash of
+ * (seed, view_id, frame, row, col).  The mask is not touched. */
+int sl3d_synth_view(sl3d_ctx *ctx, int view, const double plane[3], uint64_t seed, int view_id, int noise, float gain, float offset);
+/* read the resident frames of one axis back (same plane order as sl3d_set_frames) */
+int sl3d_get_frames(sl3d_ctx *ctx, int view, int axis, uint8_t *const *planes, int n_planes, size_t stride);
+
 /* ---- the reference's four stage entry points (need SL3D_FLAG_KEEP_STAGES) ------------------- */
 /* void compute_wrapped_phase(int pattern_type)   3/wrapped_phase.cpp:402   */
 int sl3d_compute_wrapped_phase(sl3d_ctx *ctx, int view, int axis);
