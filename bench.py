@@ -13,6 +13,9 @@ image rows (1080/N rows per GPU) and the batch grows to N*views views, so per-GP
 scaling); no collective is needed by the per-pixel map itself (the mask halo comes from the input mask).
 The optional assembly of the dense clouds over RCCL is measured separately and reported in `assemble`.
 
+The defaults (300 warm-up + 2000 timed launches, ~1.2 s of GPU time) let the clocks settle: the kernel runs the
+package into its power limit (~1.39 kW at ~2.1 GHz), and a 25 ms run measures the ramp, not the steady state.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -45,8 +48,8 @@ def measured_traffic(px_per_launch):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--views", type=int, default=16, help="views per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
