@@ -160,7 +160,14 @@ __device__ __forceinline__ double recip(double d)
 // z = r^2, Q of degree 10 by Horner (|error| < 1e-17 on [0, tan(pi/8)]), pi/4, pi/2, pi as hi+lo pairs.
 // A 2 MB gather table costs more than this arithmetic: every wave-level gather pulls 64 separate
 // 128-B lines through the vector L1 for 256 useful bytes (tools/membench.hip, flags=4: -50%).
-__device__ __forceinline__ float atan2_lattice(int t1, int t2)
+// rcp_tab: optional LDS table of correctly rounded 1/d, d = 0..767 (entry 0 holds 1); nullptr = compute it
+#define SL3D_RCP_TAB 768
+__device__ __forceinline__ void fill_rcp_table(double *tab)
+{
+    for (int i = threadIdx.x; i < SL3D_RCP_TAB; i += blockDim.x) tab[i] = 1.0 / (double)(i == 0 ? 1 : i);  // IEEE division
+}
+
+__device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp_tab = nullptr)
 {
     const int ay = abs(t1), ax = abs(t2);
     const int lo = min(ay, ax), hi = max(ay, ax);
@@ -168,8 +175,11 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2)
     const bool red = 169 * lo > 70 * hi;  // lo/hi > 0.414201 (just below tan(pi/8))
     const int num = red ? hi - lo : lo, den = red ? hi + lo : hi;
     // correctly rounded num/den (den == 0 only for t1 == t2 == 0, where num == 0 as well: use 0/1)
-    const double n = (double)num, d = (double)(den == 0 ? 1 : den);
-    const double y = recip(d), q0 = n * y;
+    // Markstein: with y = RN(1/d) (table) or y within an ulp of it (rcp + Newton), q0 = n*y, the residual
+    // n - q0*d is exact in one fma and q0 + residual*y rounds to RN(n/d)
+    const int den1 = den == 0 ? 1 : den;  // den <= 255 + 510
+    const double n = (double)num, d = (double)den1;
+    const double y = rcp_tab ? rcp_tab[den1] : recip(d), q0 = n * y;
     const double r = fma(fma(-q0, d, n), y, q0);
     // atan(r) = r + r*z*Q(z), Q of degree 10 in z = r^2.  Horner: one VGPR + one constant per fma (the kernel
     // is VALU-issue bound, the other waves of the SIMD cover the dependency latency; Estrin needed 8 more
@@ -201,10 +211,10 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2)
 }
 
 // (t1,t2) of create_wrapped_phase: 3-step 3/wrapped_phase.cpp:171-172, 4-step :195-196 (exact small integers)
-__device__ __forceinline__ float wrapped_phase(int F, int i0, int i1, int i2, int i3)
+__device__ __forceinline__ float wrapped_phase(int F, int i0, int i1, int i2, int i3, const double *rcp_tab = nullptr)
 {
-    if (F == 3) return atan2_lattice(i0 - i2, 2 * i1 - i0 - i2);
-    return atan2_lattice(i3 - i1, i0 - i2);
+    if (F == 3) return atan2_lattice(i0 - i2, 2 * i1 - i0 - i2, rcp_tab);
+    return atan2_lattice(i3 - i1, i0 - i2, rcp_tab);
 }
 
 // the value wrapped_phi holds after stage 4's in-place `+= Pi` (4/phase_unwrap.cpp:290,308)
@@ -453,6 +463,9 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
 {
     __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
     __shared__ __attribute__((aligned(16))) double s_cam[256 * 8];  // undistorted camera coordinates of the lane's 4 pixels
+    __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_TAB];  // 1/d for the atan2 quotient (saves v_rcp_f64 + 4 fma per atan2)
+    fill_rcp_table(s_rcp);
+    __syncthreads();
     const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -569,8 +582,8 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
                         const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
                         const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
                         // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
-                        float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
-                        float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
+                        float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp);
+                        float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp);
                         wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                         wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                         const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
@@ -591,8 +604,8 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
                     const int sh = 8 * k;
                     const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
                     const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
-                    float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255);
-                    float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255);
+                    float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp);
+                    float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp);
                     wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                     wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                     const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
@@ -788,13 +801,20 @@ __global__ __launch_bounds__(256) void k_tri(const KParams P, const DevCal C, in
 // Exhaustive self-check of atan2_lattice / shift_pi against the host-libm table (see sl3d_create)
 __global__ __launch_bounds__(256) void k_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches)
 {
+    __shared__ double s_rcp[SL3D_RCP_TAB];
+    fill_rcp_table(s_rcp);
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= SL3D_ATAN_T1 * SL3D_ATAN_T2) return;
     const int t1 = i / SL3D_ATAN_T2 - 255, t2 = i % SL3D_ATAN_T2 - 510;
-    const float phi = atan2_lattice(t1, t2);
+    // both reciprocal sources (LDS table: fused kernel; rcp + Newton: per-stage kernel) must reproduce the table
+    const float phi = atan2_lattice(t1, t2, s_rcp), phi2 = atan2_lattice(t1, t2, nullptr);
     const float sh = shift_pi(phi);
     // bit comparison: also catches a wrong sign of zero
-    if (__float_as_uint(phi) != __float_as_uint(tab_phi[i]) || __float_as_uint(sh) != __float_as_uint(tab_shift[i])) atomicAdd(mismatches, 1u);
+    if (__float_as_uint(phi) != __float_as_uint(tab_phi[i]) || __float_as_uint(phi2) != __float_as_uint(tab_phi[i]) ||
+        __float_as_uint(sh) != __float_as_uint(tab_shift[i]) || __float_as_uint(shift_pi_if(phi, true)) != __float_as_uint(tab_shift[i]) ||
+        __float_as_uint(shift_pi_if(phi, false)) != __float_as_uint(phi))
+        atomicAdd(mismatches, 1u);
 }
 
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream)
