@@ -10,7 +10,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   n=$(echo $c | tr " " "_" | cut -c1-30)
