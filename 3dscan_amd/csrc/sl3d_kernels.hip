@@ -458,8 +458,8 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 // through LDS so they leave as three 16-B stores per lane (a wave writes 3 KiB contiguous).
 //
 // FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
-template <bool KEEP, int NMAX, bool FGEN, int OCC, bool PID>
-__global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+template <bool KEEP, int NMAX, bool FGEN, bool EXACT, bool PID>
+__global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
     __shared__ __attribute__((aligned(16))) double s_cam[256 * 8];  // undistorted camera coordinates of the lane's 4 pixels
@@ -495,7 +495,8 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
         PR.p2[j] = Cglobal->Ap[8 + j];
         asm volatile("" : "+v"(PR.c2[j]), "+v"(PR.p2[j]));  // stay in VGPRs (see PinnedRows)
     }
-    const int Nv = P.Nv, Nh = P.Nh;
+    // EXACT: both axes have exactly NMAX Gray planes (the usual case): the plane clamps and the per-plane tests fold away
+    const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
     const int v_begin = first_view + (int)blockIdx.y * vpt;
     const int v_end = min(v_begin + vpt, first_view + n_views);
     for (int view = v_begin; view < v_end; view++) {
@@ -629,18 +630,22 @@ __global__ __launch_bounds__(256, OCC) void k_fused(const KParams P, const DevCa
 }
 
 template <bool KEEP, bool FGEN, bool PID>
-static void launch_fused_n(int nmax, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
+static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
-    if (nmax <= 6)
-        hipLaunchKernelGGL((k_fused<KEEP, 6, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
-    else if (nmax <= 8)
-        hipLaunchKernelGGL((k_fused<KEEP, 8, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
-    else if (nmax <= 10)
-        hipLaunchKernelGGL((k_fused<KEEP, 10, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
-    else if (nmax <= 12)
-        hipLaunchKernelGGL((k_fused<KEEP, 12, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
-    else
-        hipLaunchKernelGGL((k_fused<KEEP, SL3D_MAX_GRAY, FGEN, 4, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt);
+    const int nmax = nv > nh ? nv : nh;
+#define SL3D_LAUNCH(NM)                                                                                                   \
+    do {                                                                                                                  \
+        if (nv == NM && nh == NM)                                                                                         \
+            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, true, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, false, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
+    } while (0)
+    if (nmax <= 6) SL3D_LAUNCH(6);
+    else if (nmax <= 8) SL3D_LAUNCH(8);
+    else if (nmax <= 10) SL3D_LAUNCH(10);
+    else if (nmax <= 12) SL3D_LAUNCH(12);
+    else SL3D_LAUNCH(SL3D_MAX_GRAY);
+#undef SL3D_LAUNCH
 }
 
 // proj_identity: the projector has no distortion and a plain K (host knows; folded at compile time in the timed kernel)
@@ -654,17 +659,16 @@ int launch_fused(const KParams &P, const DevCal *d_cal, bool proj_identity, int 
     while (vpt < 8 && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
     if (getenv("SL3D_VPT")) vpt = atoi(getenv("SL3D_VPT"));
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(256, 1, 1);
-    const int nmax = P.Nv > P.Nh ? P.Nv : P.Nh;
     hipStream_t st = (hipStream_t)stream;
     if (keep) {
-        if (P.F == 3) launch_fused_n<true, false, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<true, true, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (P.F == 3) launch_fused_n<true, false, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<true, true, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (P.F != 3) {
-        launch_fused_n<false, true, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        launch_fused_n<false, true, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (proj_identity) {
-        launch_fused_n<false, false, true>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        launch_fused_n<false, false, true>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        launch_fused_n<false, false, false>(nmax, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        launch_fused_n<false, false, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
     return (int)hipGetLastError();
 }

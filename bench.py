@@ -187,7 +187,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": measured_traffic(px_per_launch) if alg_bytes_px == 60 else None,
-                     "kernel": "sl3d::k_fused<false, 10, false, 4, true>", "algorithmic_bytes_per_pixel": alg_bytes_px,
+                     "kernel": "sl3d::k_fused<false, 10, false, true, true>", "algorithmic_bytes_per_pixel": alg_bytes_px,
                      "pixels_per_launch": px_per_launch, "avg_launch_ms": round(launch_s * 1e3, 4)},
     }
 
