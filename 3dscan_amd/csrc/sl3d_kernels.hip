@@ -167,7 +167,29 @@ __device__ __forceinline__ void fill_rcp_table(double *tab)
     for (int i = threadIdx.x; i < SL3D_RCP_TAB; i += blockDim.x) tab[i] = 1.0 / (double)(i == 0 ? 1 : i);  // IEEE division
 }
 
-__device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp_tab = nullptr)
+// Horner coefficients of Q, highest degree first.  SGPR = true pins each one in a scalar register pair right
+// where it is called: an fp64 FMA can take one scalar operand, so every Horner step is a single v_fma_f64.
+// (Left to itself the compiler hoists the 11 constants into 22 VGPRs for the whole kernel and issues a
+// v_mov_b64 + v_fmac_f64 pair per step.)
+struct AtanK {
+    double c[11];
+};
+template <bool SGPR>
+__device__ __forceinline__ AtanK atan_consts()
+{
+    AtanK K = {{-0x1.3a2b7a07caea9p-6, 0x1.41603647c7a7cp-5, -0x1.a098bb6ba4941p-5, 0x1.dfe61e80903d2p-5, -0x1.10fa75382537fp-4,
+                0x1.3b1262d95579ep-4, -0x1.745d0b26b83e7p-4, 0x1.c71c7185314cbp-4, -0x1.24924924360cbp-3, 0x1.999999999934ap-3,
+                -0x1.5555555555555p-2}};
+    if (SGPR) {
+#pragma unroll
+        for (int j = 0; j < 11; j++) asm volatile("" : "+s"(K.c[j]));
+    }
+    return K;
+}
+
+// TAB: rcp_tab (LDS, SL3D_RCP_TAB entries) supplies the correctly rounded reciprocal; otherwise rcp + Newton
+template <bool TAB>
+__device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp_tab, const AtanK &K)
 {
     const int ay = abs(t1), ax = abs(t2);
     const int lo = min(ay, ax), hi = max(ay, ax);
@@ -179,23 +201,15 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp
     // n - q0*d is exact in one fma and q0 + residual*y rounds to RN(n/d)
     const int den1 = den == 0 ? 1 : den;  // den <= 255 + 510
     const double n = (double)num, d = (double)den1;
-    const double y = rcp_tab ? rcp_tab[den1] : recip(d), q0 = n * y;
+    const double y = TAB ? rcp_tab[den1] : recip(d), q0 = n * y;
     const double r = fma(fma(-q0, d, n), y, q0);
     // atan(r) = r + r*z*Q(z), Q of degree 10 in z = r^2.  Horner: one VGPR + one constant per fma (the kernel
     // is VALU-issue bound, the other waves of the SIMD cover the dependency latency; Estrin needed 8 more
     // instructions for the powers of z and for moving second constants into VGPRs)
     const double z = r * r;
-    double p = -0x1.3a2b7a07caea9p-6;
-    p = fma(p, z, 0x1.41603647c7a7cp-5);
-    p = fma(p, z, -0x1.a098bb6ba4941p-5);
-    p = fma(p, z, 0x1.dfe61e80903d2p-5);
-    p = fma(p, z, -0x1.10fa75382537fp-4);
-    p = fma(p, z, 0x1.3b1262d95579ep-4);
-    p = fma(p, z, -0x1.745d0b26b83e7p-4);
-    p = fma(p, z, 0x1.c71c7185314cbp-4);
-    p = fma(p, z, -0x1.24924924360cbp-3);
-    p = fma(p, z, 0x1.999999999934ap-3);
-    p = fma(p, z, -0x1.5555555555555p-2);
+    double p = K.c[0];
+#pragma unroll
+    for (int j = 1; j < 11; j++) p = fma(p, z, K.c[j]);
     const double a = fma(r, z * p, r);
     // octant / quadrant: phi = C +- a with C in {0, pi/4, pi/2} as hi+lo pairs, then pi - phi, then the sign
     const double PIO4_HI = 0x1.921fb54442d18p-1, PIO4_LO = 0x1.1a62633145c07p-55;
@@ -211,10 +225,11 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp
 }
 
 // (t1,t2) of create_wrapped_phase: 3-step 3/wrapped_phase.cpp:171-172, 4-step :195-196 (exact small integers)
-__device__ __forceinline__ float wrapped_phase(int F, int i0, int i1, int i2, int i3, const double *rcp_tab = nullptr)
+template <bool TAB>
+__device__ __forceinline__ float wrapped_phase(int F, int i0, int i1, int i2, int i3, const double *rcp_tab, const AtanK &K)
 {
-    if (F == 3) return atan2_lattice(i0 - i2, 2 * i1 - i0 - i2, rcp_tab);
-    return atan2_lattice(i3 - i1, i0 - i2, rcp_tab);
+    if (F == 3) return atan2_lattice<TAB>(i0 - i2, 2 * i1 - i0 - i2, rcp_tab, K);
+    return atan2_lattice<TAB>(i3 - i1, i0 - i2, rcp_tab, K);
 }
 
 // the value wrapped_phi holds after stage 4's in-place `+= Pi` (4/phase_unwrap.cpp:290,308)
@@ -377,9 +392,12 @@ __device__ __forceinline__ unsigned opaque_u32(unsigned v)
     asm volatile("" : "+s"(v));
     return v;
 }
-// dword at (wave-uniform base) + (32-bit lane offset): the saddr + voffset form of global_load_dword
+// dword at (wave-uniform base) + (32-bit lane offset): the saddr + voffset form of global_load_dword.
+// The base is hidden behind an empty asm: otherwise the optimiser re-associates (view base + lane offset) + plane
+// offset and spends one 64-bit VALU add per load (46 v_lshl_add_u64 per quad) instead of two SALU adds.
 __device__ __forceinline__ unsigned ldg32(const GLOBAL_AS uint8_t *base, unsigned off)
 {
+    asm volatile("" : "+s"(base));
     return *(const GLOBAL_AS unsigned *)(base + (size_t)off);
 }
 
@@ -401,8 +419,15 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
     // stage 4: the unwrap skips the first/last column (v) or row (h) of the frame; unwrapped stays unset (0 here)
     const bool in_v = gx >= 1 && gx <= P.fullW - 2;  // 4/phase_unwrap.cpp:285
     const bool in_h = gy >= 1 && gy <= P.fullH - 2;  // 4/phase_unwrap.cpp:304
-    const float uv = in_v ? unwrap_value(wv, code_v) : 0.0f;
-    const float uh = in_h ? unwrap_value(wh, code_h) : 0.0f;
+    float uvv = unwrap_value(wv, code_v), uhv = unwrap_value(wh, code_h);
+    if (!KEEP) {
+        // timed mode: keep the two phase chains out of divergent branches (the optimiser would sink each atan2 into
+        // its own `if (in range)` block and serialise them) so that they interleave in one basic block
+        asm volatile("" : "+v"(uvv));
+        asm volatile("" : "+v"(uhv));
+    }
+    const float uv = in_v ? uvv : 0.0f;
+    const float uh = in_h ? uhv : 0.0f;
     long cx, cy;
     double cxd, cyd;
     const bool okx = correspond(uv, P.fwv, P.PW, cx, cxd);
@@ -529,16 +554,20 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
             // planes of a view: vertical axis (fringe F, gray Nv, inverse Nv), then the horizontal axis
             const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
             const unsigned psv = opaque_u32(ps);  // per-view copy: plane offsets are recomputed (SALU), not kept live
+            // instruction selection works per basic block: the zero-extension of the lane offset has to happen in THIS
+            // block for the loads to select the (SGPR base + 32-bit VGPR offset) form
+            unsigned lane_off_v = lane_off;
+            asm volatile("" : "+v"(lane_off_v));
             unsigned f[2][4], g[2][NMAX], iv[2][NMAX];
             // ---- issue every load of the view ----
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
                 // plane offsets are added to the scalar base (SALU); every load uses the same VGPR offset
-                f[a][0] = ldg32(vb + (size_t)p0, lane_off);
-                f[a][1] = ldg32(vb + (size_t)(p0 + psv), lane_off);
-                f[a][2] = ldg32(vb + (size_t)(p0 + 2u * psv), lane_off);
-                f[a][3] = (FGEN && F == 4) ? ldg32(vb + (size_t)(p0 + 3u * psv), lane_off) : 0u;
+                f[a][0] = ldg32(vb + (size_t)p0, lane_off_v);
+                f[a][1] = ldg32(vb + (size_t)(p0 + psv), lane_off_v);
+                f[a][2] = ldg32(vb + (size_t)(p0 + 2u * psv), lane_off_v);
+                f[a][3] = (FGEN && F == 4) ? ldg32(vb + (size_t)(p0 + 3u * psv), lane_off_v) : 0u;
             }
 #pragma unroll
             for (int a = 0; a < 2; a++) {
@@ -547,8 +576,8 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
 #pragma unroll
                 for (int i = 0; i < NMAX; i++) {
                     const unsigned ii = (unsigned)min(i, N - 1);  // clamp: planes beyond N re-read plane N-1 and are ignored below
-                    g[a][i] = ldg32(vb + (size_t)(pg + ii * psv), lane_off);
-                    iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + ii) * psv), lane_off);
+                    g[a][i] = ldg32(vb + (size_t)(pg + ii * psv), lane_off_v);
+                    iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + ii) * psv), lane_off_v);
                 }
             }
             // ---- Gray decode, byte-parallel over the 4 pixels of the lane ----
@@ -583,8 +612,9 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
                         const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
                         const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
                         // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
-                        float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp);
-                        float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp);
+                        const AtanK AK = atan_consts<true>();
+                        float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+                        float wh = wrapped_phase<true>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
                         wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                         wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                         const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
@@ -605,8 +635,9 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
                     const int sh = 8 * k;
                     const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
                     const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
-                    float wv = wrapped_phase(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp);
-                    float wh = wrapped_phase(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp);
+                    const AtanK AK = atan_consts<true>();
+                    float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+                    float wh = wrapped_phase<true>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
                     wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                     wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                     const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
@@ -706,7 +737,7 @@ __global__ __launch_bounds__(256) void k_wrap(const KParams P, int view, int axi
         const int base = axis == 0 ? 0 : (P.F + 2 * P.Nv);
         const int i0 = load_px(P, view, base + 0, row, col), i1 = load_px(P, view, base + 1, row, col);
         const int i2 = load_px(P, view, base + 2, row, col), i3 = P.F == 4 ? load_px(P, view, base + 3, row, col) : 0;
-        phi = wrapped_phase(P.F, i0, i1, i2, i3);  // :175 / :198
+        phi = wrapped_phase<false>(P.F, i0, i1, i2, i3, nullptr, atan_consts<false>());  // :175 / :198
         // t3 = 128.0f+127.0f*(phi/(Pi)) (:178), 4-step 127.0f+128.0f*(...) (:199): double arithmetic, rounded to float, then to uchar
         const float t3 = P.F == 3 ? (float)(128.0f + 127.0f * (phi / (PI_REF))) : (float)(127.0f + 128.0f * (phi / (PI_REF)));
         dbg = (uint8_t)(int)t3;
@@ -812,7 +843,7 @@ __global__ __launch_bounds__(256) void k_atan_selfcheck(const float *tab_phi, co
     if (i >= SL3D_ATAN_T1 * SL3D_ATAN_T2) return;
     const int t1 = i / SL3D_ATAN_T2 - 255, t2 = i % SL3D_ATAN_T2 - 510;
     // both reciprocal sources (LDS table: fused kernel; rcp + Newton: per-stage kernel) must reproduce the table
-    const float phi = atan2_lattice(t1, t2, s_rcp), phi2 = atan2_lattice(t1, t2, nullptr);
+    const float phi = atan2_lattice<true>(t1, t2, s_rcp, atan_consts<true>()), phi2 = atan2_lattice<false>(t1, t2, nullptr, atan_consts<false>());
     const float sh = shift_pi(phi);
     // bit comparison: also catches a wrong sign of zero
     if (__float_as_uint(phi) != __float_as_uint(tab_phi[i]) || __float_as_uint(phi2) != __float_as_uint(tab_phi[i]) ||
