@@ -21,6 +21,12 @@
 #include <stdlib.h>
 
 #include "sl3d_internal.h"
+#include "sl3d_atan_coeffs.h"
+
+// pixels per iteration of the timed pixel loop (tools/ab.sh: 1 -> 73.7, 2 -> 75.9 Gpx/s)
+#ifndef SL3D_PX_UNROLL
+#define SL3D_PX_UNROLL 2
+#endif
 
 namespace sl3d {
 
@@ -152,12 +158,15 @@ __device__ __forceinline__ double recip(double d)
 // Wrapped phase without a table: (float)atan2((double)t1,(double)t2) for the small integers the
 // fringe frames produce (|t1| <= 255, |t2| <= 510), evaluated in fp64 so that, after rounding to
 // float, it equals the double-precision libm atan2 the reference calls (3/wrapped_phase.cpp:175)
-// on EVERY point of that lattice.  That equality is not assumed: sl3d_create() runs
-// k_atan_selfcheck over all 521,731 points against a table built with the host's libm and refuses
-// to create a context if a single value differs (tests/test_gpu_parity.py repeats the check).
-// Method: octant reduction on the integers, a second reduction lo/hi > tan(pi/8) -> (hi-lo)/(hi+lo)
-// (still a quotient of exact integers, so there is exactly one division), atan(r) = r + r*z*Q(z),
-// z = r^2, Q of degree 10 by Horner (|error| < 1e-17 on [0, tan(pi/8)]), pi/4, pi/2, pi as hi+lo pairs.
+// on EVERY point of that lattice.  That equality is not assumed: tests/native/exact_arith_check.c proves it
+// on the CPU with the same constants (sl3d_atan_coeffs.h), and sl3d_create() runs k_atan_selfcheck over all
+// 521,731 points against a table built with the host's libm and refuses to create a context if a single
+// value differs (tests/test_gpu_parity.py repeats the check).
+// Method: octant reduction on the integers, a second reduction lo/hi > 70/169 -> (hi-lo)/(hi+lo) (still a
+// quotient of small integers, so there is exactly one division), atan(r) = r + r*z*Q(z), z = r^2, Horner.
+// Accuracy budget: the true atan2 of a lattice point stays >= 6.7e-14 (relative, ~300 ulp of a double) away
+// from every float rounding boundary, so the quotient needs no correctly rounded division (n * RN(1/d) is
+// within 1 ulp), pi/4 and pi need no low words, and Q needs degree 8, not 10 (sl3d_atan_coeffs.h).
 // A 2 MB gather table costs more than this arithmetic: every wave-level gather pulls 64 separate
 // 128-B lines through the vector L1 for 256 useful bytes (tools/membench.hip, flags=4: -50%).
 // rcp_tab: optional LDS table of correctly rounded 1/d, d = 0..767 (entry 0 holds 1); nullptr = compute it
@@ -169,20 +178,18 @@ __device__ __forceinline__ void fill_rcp_table(double *tab)
 
 // Horner coefficients of Q, highest degree first.  SGPR = true pins each one in a scalar register pair right
 // where it is called: an fp64 FMA can take one scalar operand, so every Horner step is a single v_fma_f64.
-// (Left to itself the compiler hoists the 11 constants into 22 VGPRs for the whole kernel and issues a
+// (Left to itself the compiler hoists the constants into VGPR pairs for the whole kernel and issues a
 // v_mov_b64 + v_fmac_f64 pair per step.)
 struct AtanK {
-    double c[11];
+    double c[SL3D_ATAN_DEG + 1];
 };
 template <bool SGPR>
 __device__ __forceinline__ AtanK atan_consts()
 {
-    AtanK K = {{-0x1.3a2b7a07caea9p-6, 0x1.41603647c7a7cp-5, -0x1.a098bb6ba4941p-5, 0x1.dfe61e80903d2p-5, -0x1.10fa75382537fp-4,
-                0x1.3b1262d95579ep-4, -0x1.745d0b26b83e7p-4, 0x1.c71c7185314cbp-4, -0x1.24924924360cbp-3, 0x1.999999999934ap-3,
-                -0x1.5555555555555p-2}};
+    AtanK K = {SL3D_ATAN_Q};
     if (SGPR) {
 #pragma unroll
-        for (int j = 0; j < 11; j++) asm volatile("" : "+s"(K.c[j]));
+        for (int j = 0; j <= SL3D_ATAN_DEG; j++) asm volatile("" : "+s"(K.c[j]));
     }
     return K;
 }
@@ -196,30 +203,20 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp
     const bool swap = ay > ax;
     const bool red = 169 * lo > 70 * hi;  // lo/hi > 0.414201 (just below tan(pi/8))
     const int num = red ? hi - lo : lo, den = red ? hi + lo : hi;
-    // correctly rounded num/den (den == 0 only for t1 == t2 == 0, where num == 0 as well: use 0/1)
-    // Markstein: with y = RN(1/d) (table) or y within an ulp of it (rcp + Newton), q0 = n*y, the residual
-    // n - q0*d is exact in one fma and q0 + residual*y rounds to RN(n/d)
-    const int den1 = den == 0 ? 1 : den;  // den <= 255 + 510
-    const double n = (double)num, d = (double)den1;
-    const double y = TAB ? rcp_tab[den1] : recip(d), q0 = n * y;
-    const double r = fma(fma(-q0, d, n), y, q0);
-    // atan(r) = r + r*z*Q(z), Q of degree 10 in z = r^2.  Horner: one VGPR + one constant per fma (the kernel
-    // is VALU-issue bound, the other waves of the SIMD cover the dependency latency; Estrin needed 8 more
-    // instructions for the powers of z and for moving second constants into VGPRs)
+    // num/den to 1 ulp (den == 0 only for t1 == t2 == 0, where num == 0 as well: use 0/1); den <= 255 + 510
+    const int den1 = den == 0 ? 1 : den;
+    const double r = (double)num * (TAB ? rcp_tab[den1] : recip((double)den1));
     const double z = r * r;
     double p = K.c[0];
 #pragma unroll
-    for (int j = 1; j < 11; j++) p = fma(p, z, K.c[j]);
+    for (int j = 1; j <= SL3D_ATAN_DEG; j++) p = fma(p, z, K.c[j]);
     const double a = fma(r, z * p, r);
-    // octant / quadrant: phi = C +- a with C in {0, pi/4, pi/2} as hi+lo pairs, then pi - phi, then the sign
-    const double PIO4_HI = 0x1.921fb54442d18p-1, PIO4_LO = 0x1.1a62633145c07p-55;
-    const double PI_HI = 0x1.921fb54442d18p+1, PI_LO = 0x1.1a62633145c07p-53;
     // !swap,!red: a | !swap,red: pi/4 - a | swap,red: pi/4 + a | swap,!red: pi/2 - a
-    // i.e. phi = k*(pi/4) +- a with k = red + 2*(swap & !red) in {0,1,2}; k*PIO4_HI and k*PIO4_LO are exact
+    // i.e. phi = k*(pi/4) +- a with k = red + 2*(swap & !red) in {0,1,2}; then pi - phi, then the sign
     const double kq = (double)((red ? 1 : 0) + ((swap && !red) ? 2 : 0));
     const double sa = (swap != red) ? -a : a;
-    double phi = fma(kq, PIO4_HI, 0.0) + (sa + kq * PIO4_LO);  // chi - (a - clo) == chi + (-a + clo): negation is exact
-    phi = t2 < 0 ? PI_HI - (phi - PI_LO) : phi;
+    double phi = fma(kq, SL3D_PIO4, sa);
+    phi = t2 < 0 ? SL3D_PI - phi : phi;
     phi = t1 < 0 ? -phi : phi;
     return (float)phi;
 }
@@ -630,7 +627,7 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
             } else {
                 // timed mode: no divergent branch inside the pixel body; two pixels per iteration so the scheduler can
                 // interleave two independent fp64 dependency chains (measured: 1 -> 73.7, 2 -> 75.9, 4 -> 70.7 Gpx/s, spills)
-#pragma unroll 2
+#pragma unroll SL3D_PX_UNROLL
                 for (int k = 0; k < 4; k++) {
                     const int sh = 8 * k;
                     const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsl3d.so")
+# SL3D_LIB: another build of the SAME library (kernel A/B experiments, tools/ab.sh); never a fallback
+LIB_PATH = os.environ.get("SL3D_LIB") or os.path.join(_HERE, "libsl3d.so")
 
 SL3D_FLAG_KEEP_STAGES = 1
 AXIS_VERTICAL, AXIS_HORIZONTAL = 0, 1

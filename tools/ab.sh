@@ -1,0 +1,24 @@
+#!/bin/bash
+# Kernel A/B experiments.
+#   here (no GPU):  tools/ab.sh build NAME "-DSL3D_PX_UNROLL=4" [NAME2 "flags2" ...]   -> ab/libsl3d_NAME.so (+ VGPR/scratch report)
+#   on the GPU box: tools/ab.sh run [bench args]        -> one line per variant: value frac ms  (steady-state defaults)
+# ab/ is git-ignored but travels with gpurun.  The default library (3dscan_amd/libsl3d.so) is always measured as "base".
+set -u
+cd "$(dirname "$0")/.."
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+if [ "$1" = build ]; then
+  shift; mkdir -p ab
+  while [ $# -ge 2 ]; do
+    n=$1; f=$2; shift 2
+    hipcc $FLAGS $f -shared -o ab/libsl3d_$n.so 3dscan_amd/csrc/sl3d_kernels.hip 3dscan_amd/csrc/sl3d_capi.cpp -Iinclude \
+      -Rpass-analysis=kernel-resource-usage 2> ab/$n.res || { echo "build $n failed"; tail -5 ab/$n.res; continue; }
+    echo "$n [$f]: $(grep -A12 'k_fusedILb0ELi10ELb0ELb1ELb1' ab/$n.res | grep -E 'VGPRs:|ScratchSize|Occupancy|SGPRs:' | sed 's/.*remark: [^ ]* *//' | tr '\n' ' ')"
+  done
+elif [ "$1" = run ]; then
+  shift
+  for lib in 3dscan_amd/libsl3d.so ab/libsl3d_*.so; do
+    [ -f "$lib" ] || continue
+    r=$(SL3D_LIB=$PWD/$lib python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['frac'], d['ms_per_step'])")
+    echo "$(basename $lib) $r"
+  done
+fi
