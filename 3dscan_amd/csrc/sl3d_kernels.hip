@@ -27,6 +27,23 @@
 #ifndef SL3D_PX_UNROLL
 #define SL3D_PX_UNROLL 2
 #endif
+// 1: the timed mode stores the xyz of each pixel pair straight from registers (dwordx4 + dwordx2); 0: staged through LDS
+#ifndef SL3D_DIRECT_STORE
+#define SL3D_DIRECT_STORE 0
+#endif
+#ifndef SL3D_OCC
+#define SL3D_OCC 4 /* waves per SIMD the fused kernel is compiled for */
+#endif
+// measurement only (tools/ab.sh): 1 = no per-pixel arithmetic (xyz made of the raw decode results), 2 = no mask reads,
+// 4 = no xyz stores.  Results are wrong by construction; never set in a shipped build.
+#ifndef SL3D_MASK_PREFETCH
+#define SL3D_MASK_PREFETCH 1
+#endif
+#ifndef SL3D_ABLATE
+#define SL3D_ABLATE 0
+#endif
+#define SL3D_PRAGMA_(x) _Pragma(#x)
+#define SL3D_UNROLL(n) SL3D_PRAGMA_(unroll n)
 
 namespace sl3d {
 
@@ -99,45 +116,61 @@ __device__ __forceinline__ MaskView mask_view(const KParams &P, int view)
 
 // Valid bits of the 4 pixels (cq*4 .. cq*4+3, row) of a window; bit k = pixel k.
 // Fast path: 3 rows x 3 aligned dwords of 0/1 bytes, byte-parallel logic (all neighbours are
-// interior pixels of the frame, so B == false and interior == true).  Pixels within 3 of the
-// frame border take the generic path.
-__device__ __forceinline__ unsigned quad_valid_bits(const KParams &P, const MaskView &mv, int view, int cq, int row)
+// interior pixels of the frame, so B == false and interior == true).  Quads within 3 pixels of the frame
+// border read the band plane instead: their valid bytes were evaluated by sl3d_set_mask (host, generic
+// closed form).  Loading (MaskQuad) and evaluating are separate so the fused kernel can request the
+// next view's mask while it works on the current one.
+struct MaskQuad {
+    unsigned bP, bC, bN, cP, cC, cN, dP, dC, dN;  // rows y-1, y, y+1 at columns c-4, c, c+4
+    unsigned band;
+};
+
+__device__ __forceinline__ bool quad_is_interior(const KParams &P, int cq, int row)
 {
-    const int c = cq * 4, gx = P.col0 + c, gy = P.row0 + row;
-    unsigned bits = 0;
-    if (gy >= 3 && gy <= P.fullH - 4 && gx >= 4 && gx + 3 <= P.fullW - 5) {
-        const uint8_t *r1 = mv.base + (ptrdiff_t)row * mv.mpitch + c;  // row y, pixel c
-        const uint8_t *r0 = r1 - mv.mpitch, *r2 = r1 + mv.mpitch;
-        const unsigned bP = *(const unsigned *)(r0 - 4), bC = *(const unsigned *)r0, bN = *(const unsigned *)(r0 + 4);
-        const unsigned cP = *(const unsigned *)(r1 - 4), cC = *(const unsigned *)r1, cN = *(const unsigned *)(r1 + 4);
-        const unsigned dP = *(const unsigned *)(r2 - 4), dC = *(const unsigned *)r2, dN = *(const unsigned *)(r2 + 4);
-        // X(d): bytes of row X at columns c+k+d, k=0..3
+    const int gx = P.col0 + cq * 4, gy = P.row0 + row;
+    return gy >= 3 && gy <= P.fullH - 4 && gx >= 4 && gx + 3 <= P.fullW - 5;
+}
+
+// the 9 mask dwords are inside the allocation for every quad of the window (2-row halo, 16-B pads), so they are
+// loaded unconditionally; the band dword only where it is used
+__device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, int cq, int row, bool interior)
+{
+    const uint8_t *mb = P.mask + (size_t)view * P.mask_view_stride + (size_t)SL3D_MASK_HALO * P.mpitch + SL3D_MASK_LPAD;
+    const uint8_t *r1 = mb + (ptrdiff_t)row * P.mpitch + cq * 4;
+    const uint8_t *r0 = r1 - P.mpitch, *r2 = r1 + P.mpitch;
+    MaskQuad m;
+    m.bP = *(const unsigned *)(r0 - 4); m.bC = *(const unsigned *)r0; m.bN = *(const unsigned *)(r0 + 4);
+    m.cP = *(const unsigned *)(r1 - 4); m.cC = *(const unsigned *)r1; m.cN = *(const unsigned *)(r1 + 4);
+    m.dP = *(const unsigned *)(r2 - 4); m.dC = *(const unsigned *)r2; m.dN = *(const unsigned *)(r2 + 4);
+    m.band = 0;
+    if (!interior) m.band = *(const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + cq * 4);
+    return m;
+}
+
+__device__ __forceinline__ unsigned mask_quad_bits(const KParams &P, const MaskQuad &m, int cq, bool interior)
+{
+    // X(d): bytes of row X at columns c+k+d, k=0..3
 #define SHL2(Pw, Cw) __builtin_amdgcn_alignbyte(Cw, Pw, 2)
 #define SHL1(Pw, Cw) __builtin_amdgcn_alignbyte(Cw, Pw, 3)
 #define SHR1(Cw, Nw) __builtin_amdgcn_alignbyte(Nw, Cw, 1)
 #define SHR2(Cw, Nw) __builtin_amdgcn_alignbyte(Nw, Cw, 2)
-        const unsigned ONE = 0x01010101u;
-        const unsigned Bm1 = SHL1(bP, bC), B0 = bC, B1 = SHR1(bC, bN), B2 = SHR2(bC, bN);
-        const unsigned Cm2 = SHL2(cP, cC), Cm1 = SHL1(cP, cC), C0 = cC, C1 = SHR1(cC, cN), C2 = SHR2(cC, cN);
-        const unsigned Dm2 = SHL2(dP, dC), Dm1 = SHL1(dP, dC), D0 = dC, D1 = SHR1(dC, dN);
-        unsigned v = C0 & C1 & Dm1 & D0 & D1;                 // V(p) & !L(p)
-        v &= Bm1 | ((B0 & Cm2 & Cm1) ^ ONE);                   // OK(NW) given the line above
-        v &= B0 | ((B1 & Cm1) ^ ONE);                          // OK(N)
-        v &= B1 | ((B2 & C2) ^ ONE);                           // OK(NE)
-        v &= Cm1 | (Dm2 ^ ONE);                                // OK(W)
+    const unsigned ONE = 0x01010101u;
+    const unsigned Bm1 = SHL1(m.bP, m.bC), B0 = m.bC, B1 = SHR1(m.bC, m.bN), B2 = SHR2(m.bC, m.bN);
+    const unsigned Cm2 = SHL2(m.cP, m.cC), Cm1 = SHL1(m.cP, m.cC), C0 = m.cC, C1 = SHR1(m.cC, m.cN), C2 = SHR2(m.cC, m.cN);
+    const unsigned Dm2 = SHL2(m.dP, m.dC), Dm1 = SHL1(m.dP, m.dC), D0 = m.dC, D1 = SHR1(m.dC, m.dN);
+    unsigned v = C0 & C1 & Dm1 & D0 & D1;                 // V(p) & !L(p)
+    v &= Bm1 | ((B0 & Cm2 & Cm1) ^ ONE);                   // OK(NW) given the line above
+    v &= B0 | ((B1 & Cm1) ^ ONE);                          // OK(N)
+    v &= B1 | ((B2 & C2) ^ ONE);                           // OK(NE)
+    v &= Cm1 | (Dm2 ^ ONE);                                // OK(W)
 #undef SHL2
 #undef SHL1
 #undef SHR1
 #undef SHR2
-        bits = (v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u);
-    } else {
-        // within 3 pixels of the frame border: the valid bytes of these few quads were evaluated by
-        // sl3d_set_mask (host, generic closed form) into the band plane
-        const unsigned w = *(const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + c);
-        bits = (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
-    }
+    const unsigned w = interior ? v : m.band;
+    unsigned bits = (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
     // pixels of the pitch padding are not part of the window
-    const int inside = P.W - c;  // number of window pixels in this quad (may be <= 0 or >= 4)
+    const int inside = P.W - cq * 4;  // number of window pixels in this quad (may be <= 0 or >= 4)
     if (inside < 4) bits &= inside <= 0 ? 0u : ((1u << inside) - 1u);
     return bits;
 }
@@ -211,13 +244,14 @@ __device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp
 #pragma unroll
     for (int j = 1; j <= SL3D_ATAN_DEG; j++) p = fma(p, z, K.c[j]);
     const double a = fma(r, z * p, r);
-    // !swap,!red: a | !swap,red: pi/4 - a | swap,red: pi/4 + a | swap,!red: pi/2 - a
-    // i.e. phi = k*(pi/4) +- a with k = red + 2*(swap & !red) in {0,1,2}; then pi - phi, then the sign
-    const double kq = (double)((red ? 1 : 0) + ((swap && !red) ? 2 : 0));
-    const double sa = (swap != red) ? -a : a;
-    double phi = fma(kq, SL3D_PIO4, sa);
-    phi = t2 < 0 ? SL3D_PI - phi : phi;
-    phi = t1 < 0 ? -phi : phi;
+    // first octant pair:  !swap,!red: a | !swap,red: pi/4 - a | swap,red: pi/4 + a | swap,!red: pi/2 - a
+    // i.e. phi1 = k*(pi/4) + s*a with k = red + 2*(swap & !red) in {0,1,2}, s = -1 iff swap != red;
+    // t2 < 0: phi2 = pi - phi1 = (4-k)*(pi/4) - s*a;  t1 < 0: phi = -phi2.  Round-to-nearest is odd-symmetric, so all
+    // of it is ONE fma on an integer multiplier and a sign-adjusted a (k*pi/4 + a is rounded once instead of twice).
+    const int k1 = (red ? 1 : 0) + ((swap && !red) ? 2 : 0);
+    const int k2 = t2 < 0 ? 4 - k1 : k1;
+    const bool neg = ((swap != red) != (t2 < 0)) != (t1 < 0);
+    const double phi = fma((double)(t1 < 0 ? -k2 : k2), SL3D_PIO4, neg ? -a : a);
     return (float)phi;
 }
 
@@ -481,9 +515,10 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 //
 // FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
 template <bool KEEP, int NMAX, bool FGEN, bool EXACT, bool PID>
-__global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+__global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
-    __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
+    constexpr bool DIRECT = !KEEP && SL3D_DIRECT_STORE;
+    __shared__ __attribute__((aligned(16))) float s_xyz[DIRECT ? 4 : 256 * 12];
     __shared__ __attribute__((aligned(16))) double s_cam[256 * 8];  // undistorted camera coordinates of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_TAB];  // 1/d for the atan2 quotient (saves v_rcp_f64 + 4 fma per atan2)
     fill_rcp_table(s_rcp);
@@ -495,7 +530,7 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
     if (row >= P.H) return;
     const int gx0 = P.col0 + cq * 4, gy = P.row0 + row;
     const float nanv = __builtin_nanf("");
-    float *my_xyz = s_xyz + threadIdx.x * 12;
+    float *my_xyz = s_xyz + (DIRECT ? 0 : threadIdx.x * 12);
     const unsigned lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;  // byte offset of the quad inside any plane
     const unsigned ps = (unsigned)P.plane_stride;
 
@@ -521,10 +556,15 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
     const int v_begin = first_view + (int)blockIdx.y * vpt;
     const int v_end = min(v_begin + vpt, first_view + n_views);
+    // the mask of the NEXT view is requested before the current view's planes, so a wave never waits a full memory
+    // round trip for 36 bytes before it can ask for its 11.5 KB
+    const bool interior = quad_is_interior(P, cq, row);
+    MaskQuad mq = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row, interior);
     for (int view = v_begin; view < v_end; view++) {
-        const MaskView mv = mask_view(P, view);
         // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
-        const unsigned vbits = (FGEN && F == 5) ? 0u : quad_valid_bits(P, mv, view, cq, row);
+        if (!SL3D_MASK_PREFETCH && view > v_begin) mq = load_mask_quad(P, view, cq, row, interior);
+        const unsigned vbits = (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(P, mq, cq, interior);
+        if (SL3D_MASK_PREFETCH && view + 1 < v_end) mq = load_mask_quad(P, view + 1, cq, row, interior);
         const size_t px = (size_t)view * P.px_view_stride + (size_t)lane_off;  // first pixel of the quad
         unsigned vout = 0;
 
@@ -542,7 +582,12 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
                 P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
             }
         }
-        if (KEEP || vbits == 0) {
+        if (DIRECT) {
+            if (vbits == 0) {
+                float4 *o = (float4 *)(P.points + 3 * px);
+                o[0] = o[1] = o[2] = make_float4(nanv, nanv, nanv, nanv);
+            }
+        } else if (KEEP || vbits == 0) {
 #pragma unroll
             for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
         }
@@ -627,32 +672,75 @@ __global__ __launch_bounds__(256, 4) void k_fused(const KParams P, const DevCal 
             } else {
                 // timed mode: no divergent branch inside the pixel body; two pixels per iteration so the scheduler can
                 // interleave two independent fp64 dependency chains (measured: 1 -> 73.7, 2 -> 75.9, 4 -> 70.7 Gpx/s, spills)
-#pragma unroll SL3D_PX_UNROLL
-                for (int k = 0; k < 4; k++) {
+                auto pixel = [&](int k, float &ox, float &oy, float &oz) {
                     const int sh = 8 * k;
+                    if (SL3D_ABLATE & 1) {
+                        ox = __uint_as_float(((accA[0] ^ f[0][0] ^ f[1][1]) >> sh) | 0x3f800000u);
+                        oy = __uint_as_float(((accA[1] ^ f[0][1] ^ f[1][2]) >> sh) | 0x3f800000u);
+                        oz = __uint_as_float(((accB[0] ^ accB[1] ^ f[0][2] ^ f[1][0]) >> sh) | 0x3f800000u);
+                        vout |= 1u << sh;
+                        return;
+                    }
                     const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
                     const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
                     const AtanK AK = atan_consts<true>();
                     float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
                     float wh = wrapped_phase<true>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
-                    wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
-                    wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
+                    // stage 4 shifts by +Pi only inside its loop range (4/phase_unwrap.cpp:285,290,304,308); outside it the
+                    // unwrapped value is 0 whatever the wrapped one is (pixel_chain), and the timed mode does not keep wrapped
+                    wv = shift_pi(wv);
+                    wh = shift_pi(wh);
                     const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
                     const PixelResult R = pixel_chain<false, PID>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
                     const bool okpx = ((vbits >> k) & 1u) && R.valid;
-                    my_xyz[3 * k + 0] = okpx ? R.x : nanv;
-                    my_xyz[3 * k + 1] = okpx ? R.y : nanv;
-                    my_xyz[3 * k + 2] = okpx ? R.z : nanv;
+                    ox = okpx ? R.x : nanv;
+                    oy = okpx ? R.y : nanv;
+                    oz = okpx ? R.z : nanv;
                     vout |= (okpx ? 1u : 0u) << sh;
+                };
+                if (DIRECT && SL3D_DIRECT_STORE == 2) {
+                    // all 4 pixels unrolled (static byte selects), three dwordx4 stores from registers
+                    float o[12];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pixel(k, o[3 * k], o[3 * k + 1], o[3 * k + 2]);
+                    float4 *d = (float4 *)(P.points + 3 * px);
+                    d[0] = make_float4(o[0], o[1], o[2], o[3]);
+                    d[1] = make_float4(o[4], o[5], o[6], o[7]);
+                    d[2] = make_float4(o[8], o[9], o[10], o[11]);
+                } else if (DIRECT) {
+                    // pixel pairs: 24 B of xyz per iteration leave as dwordx4 + dwordx2 (the quad's 48 B start 16-B aligned)
+                    float *o = P.points + 3 * px;
+#pragma unroll 1
+                    for (int j = 0; j < 2; j++) {
+                        float a0, a1, a2, b0, b1, b2;
+                        pixel(2 * j, a0, a1, a2);
+                        pixel(2 * j + 1, b0, b1, b2);
+                        if (j == 0) {
+                            *(float4 *)o = make_float4(a0, a1, a2, b0);
+                            *(float2 *)(o + 4) = make_float2(b1, b2);
+                        } else {
+                            *(float2 *)(o + 6) = make_float2(a0, a1);
+                            *(float4 *)(o + 8) = make_float4(a2, b0, b1, b2);
+                        }
+                    }
+                } else {
+                    SL3D_UNROLL(SL3D_PX_UNROLL)
+                    for (int k = 0; k < 4; k++) pixel(k, my_xyz[3 * k + 0], my_xyz[3 * k + 1], my_xyz[3 * k + 2]);
                 }
             }
+        }
+        if (DIRECT) {
+            *(unsigned *)(P.valid + px) = vout;
+            continue;
         }
         // each lane reads back only what it wrote itself: no barrier needed
         float4 *out_xyz = (float4 *)(P.points + 3 * px);
         const float4 *sx = (const float4 *)my_xyz;
-        out_xyz[0] = sx[0];
-        out_xyz[1] = sx[1];
-        out_xyz[2] = sx[2];
+        if (!(SL3D_ABLATE & 4) || KEEP || sx[0].x == 12345.f) {
+            out_xyz[0] = sx[0];
+            out_xyz[1] = sx[1];
+            out_xyz[2] = sx[2];
+        }
         *(unsigned *)(P.valid + px) = vout;
     }
 }

@@ -31,11 +31,9 @@ static double atan2_lattice(int t1, int t2)
     double z = r * r, p = Q[0];
     for (int i = 1; i <= SL3D_ATAN_DEG; i++) p = fma(p, z, Q[i]);
     double a = fma(r, z * p, r);
-    double kq = (double)((red ? 1 : 0) + ((swap && !red) ? 2 : 0));
-    double sa = (swap != red) ? -a : a;
-    double phi = fma(kq, SL3D_PIO4, sa);
-    phi = t2 < 0 ? SL3D_PI - phi : phi;
-    return t1 < 0 ? -phi : phi;
+    int k1 = (red ? 1 : 0) + ((swap && !red) ? 2 : 0), k2 = t2 < 0 ? 4 - k1 : k1;
+    int neg = ((swap != red) != (t2 < 0)) != (t1 < 0);
+    return fma((double)(t1 < 0 ? -k2 : k2), SL3D_PIO4, neg ? -a : a);
 }
 
 /* relative distance of v to the nearest float rounding boundary */

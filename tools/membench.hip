@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void k_lds(const uint8_t *in, size_t plane, fl
 // incremental model of the fused kernel's data path: feature flags add one element at a time
 //   1: loop over 4 "views" per lane (planes of view v at +v*P*plane)   2: 9 mask dwords first, loads depend on them
 //   4: 8 dependent table gathers (2 MB table)   8: LDS round trip for the 48 B of output   16: ~600 dependent fp64 fma per quad
+//   32: tile-interleaved frame layout [view][tile of 64 quads][plane][256 B]: the P loads of a wave hit ONE contiguous P*256-B region
+//   64: 8 views per lane instead of 4 (with flag 1)
 template <int P, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_steps(const uint8_t *in, size_t plane, size_t view_stride, int nviews, const uint8_t *mask,
                                                     const float *tab, float4 *out, unsigned *outv, size_t nquads, int flags)
@@ -88,9 +90,15 @@ __global__ __launch_bounds__(256, OCC) void k_steps(const uint8_t *in, size_t pl
     __shared__ __attribute__((aligned(16))) float sx[256 * 12];
     size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= nquads) return;
-    const int v0 = (flags & 1) ? blockIdx.y * 4 : blockIdx.y, v1 = (flags & 1) ? v0 + 4 : v0 + 1;
+    const int vpl = (flags & 64) ? 8 : 4;
+    const int v0 = (flags & 1) ? blockIdx.y * vpl : blockIdx.y, v1 = (flags & 1) ? v0 + vpl : v0 + 1;
     for (int view = v0; view < v1 && view < nviews; view++) {
         const uint8_t *base = in + (size_t)view * view_stride + q * 4;
+        size_t pstride = plane;
+        if (flags & 32) {
+            base = in + (size_t)view * view_stride + (q >> 6) * (size_t)(P * 256) + (q & 63) * 4;
+            pstride = 256;
+        }
         unsigned m = 0xf;
         if (flags & 2) {
             const unsigned *mp = (const unsigned *)(mask + (size_t)view * nquads * 4 + q * 4);
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256, OCC) void k_steps(const uint8_t *in, size_t pl
         if (m) {
             unsigned v[P];
 #pragma unroll
-            for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(base + p * plane);
+            for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(base + p * pstride);
             float w = 0;
             if (flags & 4) {
 #pragma unroll
@@ -173,10 +181,10 @@ int main(int argc, char **argv)
         CHK(hipMemset(mk, 1, vpx * nviews + 64)); CHK(hipMemset(tab, 0, 511 * 1021 * 4));
         const double by = (double)vpx * nviews * (P + 14);
         for (int occ = 0; occ < 2; occ++)
-            for (int flags : {0, 1, 3, 7, 15, 31, 4, 16, 2, 8}) {
+            for (int flags : {0, 1, 65, 32, 33, 97, 11, 43, 107, 16, 2, 8}) {
                 float best = 1e9;
                 for (int it = 0; it < 8; it++) {
-                    dim3 grid((nq + 255) / 256, (flags & 1) ? nviews / 4 : nviews);
+                    dim3 grid((nq + 255) / 256, (flags & 1) ? nviews / ((flags & 64) ? 8 : 4) : nviews);
                     CHK(hipEventRecord(e0));
                     if (occ == 0) hipLaunchKernelGGL((k_steps<P, 8>), grid, dim3(256), 0, 0, fr, vpx, vpx * P, nviews, mk + 32, tab, o, ov, nq, flags);
                     else hipLaunchKernelGGL((k_steps<P, 4>), grid, dim3(256), 0, 0, fr, vpx, vpx * P, nviews, mk + 32, tab, o, ov, nq, flags);
