@@ -23,13 +23,9 @@
 #include "sl3d_internal.h"
 #include "sl3d_atan_coeffs.h"
 
-// pixels per iteration of the timed pixel loop (tools/ab.sh: 1 -> 73.7, 2 -> 75.9 Gpx/s)
-#ifndef SL3D_PX_UNROLL
-#define SL3D_PX_UNROLL 2
-#endif
-// 1: the timed mode stores the xyz of each pixel pair straight from registers (dwordx4 + dwordx2); 0: staged through LDS
-#ifndef SL3D_DIRECT_STORE
-#define SL3D_DIRECT_STORE 0
+// the timed pixel loop handles the 4 pixels of a lane as 2 pairs: 1 = rolled pair loop, 2 = both pairs unrolled
+#ifndef SL3D_PAIR_UNROLL
+#define SL3D_PAIR_UNROLL 1
 #endif
 #ifndef SL3D_OCC
 #define SL3D_OCC 4 /* waves per SIMD the fused kernel is compiled for */
@@ -227,40 +223,49 @@ __device__ __forceinline__ AtanK atan_consts()
     return K;
 }
 
-// TAB: rcp_tab (LDS, SL3D_RCP_TAB entries) supplies the correctly rounded reciprocal; otherwise rcp + Newton
+// TAB: rcp_tab (LDS, SL3D_RCP_TAB entries) supplies the correctly rounded reciprocal; otherwise rcp + Newton.
+// The arguments come as differences of small non-negative integers, t1 = a - b, t2 = c - d (a..d < 2^16): the absolute
+// values are one v_sad_u16 each and the signs one compare each.
 template <bool TAB>
-__device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp_tab, const AtanK &K)
+__device__ __forceinline__ float atan2_lattice4(unsigned a, unsigned b, unsigned c, unsigned d, const double *rcp_tab, const AtanK &K)
 {
-    const int ay = abs(t1), ax = abs(t2);
-    const int lo = min(ay, ax), hi = max(ay, ax);
+    const unsigned ay = __builtin_amdgcn_sad_u16(a, b, 0u), ax = __builtin_amdgcn_sad_u16(c, d, 0u);
+    const bool neg1 = a < b, neg2 = c < d;  // t1 < 0, t2 < 0
+    const unsigned lo = min(ay, ax), hi = max(ay, ax);
     const bool swap = ay > ax;
-    const bool red = 169 * lo > 70 * hi;  // lo/hi > 0.414201 (just below tan(pi/8))
-    const int num = red ? hi - lo : lo, den = red ? hi + lo : hi;
+    const bool red = __umul24(169u, lo) > __umul24(70u, hi);  // lo/hi > 0.414201 (just below tan(pi/8)); full-rate 24-bit multiplies
+    const unsigned num = red ? hi - lo : lo, den = red ? hi + lo : hi;
     // num/den to 1 ulp (den == 0 only for t1 == t2 == 0, where num == 0 as well: use 0/1); den <= 255 + 510
-    const int den1 = den == 0 ? 1 : den;
+    const unsigned den1 = max(den, 1u);
     const double r = (double)num * (TAB ? rcp_tab[den1] : recip((double)den1));
     const double z = r * r;
     double p = K.c[0];
 #pragma unroll
     for (int j = 1; j <= SL3D_ATAN_DEG; j++) p = fma(p, z, K.c[j]);
-    const double a = fma(r, z * p, r);
-    // first octant pair:  !swap,!red: a | !swap,red: pi/4 - a | swap,red: pi/4 + a | swap,!red: pi/2 - a
-    // i.e. phi1 = k*(pi/4) + s*a with k = red + 2*(swap & !red) in {0,1,2}, s = -1 iff swap != red;
-    // t2 < 0: phi2 = pi - phi1 = (4-k)*(pi/4) - s*a;  t1 < 0: phi = -phi2.  Round-to-nearest is odd-symmetric, so all
-    // of it is ONE fma on an integer multiplier and a sign-adjusted a (k*pi/4 + a is rounded once instead of twice).
-    const int k1 = (red ? 1 : 0) + ((swap && !red) ? 2 : 0);
-    const int k2 = t2 < 0 ? 4 - k1 : k1;
-    const bool neg = ((swap != red) != (t2 < 0)) != (t1 < 0);
-    const double phi = fma((double)(t1 < 0 ? -k2 : k2), SL3D_PIO4, neg ? -a : a);
-    return (float)phi;
+    const double at = fma(r, z * p, r);
+    // first octant pair:  !swap,!red: at | !swap,red: pi/4 - at | swap,red: pi/4 + at | swap,!red: pi/2 - at
+    // i.e. phi1 = k*(pi/4) + s*at with k = red ? 1 : (swap ? 2 : 0), s = -1 iff swap != red;
+    // t2 < 0: phi2 = pi - phi1 = (4-k)*(pi/4) - s*at, ONE fma on an integer multiplier and a sign-adjusted at
+    // (k*pi/4 + at is rounded once); t1 < 0 flips the sign of the (non-negative) float result.
+    const int k1 = red ? 1 : (swap ? 2 : 0);
+    const int k2 = neg2 ? 4 - k1 : k1;
+    const bool nega = (swap != red) != neg2;
+    const float phi = (float)fma((double)k2, SL3D_PIO4, nega ? -at : at);
+    return neg1 ? -phi : phi;
+}
+
+template <bool TAB>
+__device__ __forceinline__ float atan2_lattice(int t1, int t2, const double *rcp_tab, const AtanK &K)
+{
+    return atan2_lattice4<TAB>((unsigned)max(t1, 0), (unsigned)max(-t1, 0), (unsigned)max(t2, 0), (unsigned)max(-t2, 0), rcp_tab, K);
 }
 
 // (t1,t2) of create_wrapped_phase: 3-step 3/wrapped_phase.cpp:171-172, 4-step :195-196 (exact small integers)
 template <bool TAB>
-__device__ __forceinline__ float wrapped_phase(int F, int i0, int i1, int i2, int i3, const double *rcp_tab, const AtanK &K)
+__device__ __forceinline__ float wrapped_phase(int F, unsigned i0, unsigned i1, unsigned i2, unsigned i3, const double *rcp_tab, const AtanK &K)
 {
-    if (F == 3) return atan2_lattice<TAB>(i0 - i2, 2 * i1 - i0 - i2, rcp_tab, K);
-    return atan2_lattice<TAB>(i3 - i1, i0 - i2, rcp_tab, K);
+    if (F == 3) return atan2_lattice4<TAB>(i0, i2, 2u * i1, i0 + i2, rcp_tab, K);
+    return atan2_lattice4<TAB>(i3, i1, i0, i2, rcp_tab, K);
 }
 
 // the value wrapped_phi holds after stage 4's in-place `+= Pi` (4/phase_unwrap.cpp:290,308)
@@ -295,7 +300,8 @@ __device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, l
     const double a = (double)fw * div_exact((double)unwrapped, c, 1.0 / c);
     const double r = rint(a);  // round-half-even, the default rounding mode lrint runs under
     // FE_INVALID <=> NaN, inf or outside long; those and out-of-range values both clear the pixel
-    const bool ok = (r >= 0.0) && (r <= (double)(limit - 1));
+    // r is an integer-valued finite double (or +-0): the saturating conversion maps r < 0 and r > INT_MAX outside [0, limit)
+    const bool ok = (unsigned)(int)r <= (unsigned)(limit - 1);
     out = ok ? (long)r : 0;
     out_d = r;  // the same integer as a double (exact), for stage 7
     return ok;
@@ -457,8 +463,12 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
         asm volatile("" : "+v"(uvv));
         asm volatile("" : "+v"(uhv));
     }
-    const float uv = in_v ? uvv : 0.0f;
-    const float uh = in_h ? uhv : 0.0f;
+    float uv = in_v ? uvv : 0.0f;
+    float uh = in_h ? uhv : 0.0f;
+    if (!KEEP) {  // select the 32-bit value (the optimiser would move the select behind the conversion to double: 2 ops each)
+        asm volatile("" : "+v"(uv));
+        asm volatile("" : "+v"(uh));
+    }
     long cx, cy;
     double cxd, cyd;
     const bool okx = correspond(uv, P.fwv, P.PW, cx, cxd);
@@ -517,8 +527,7 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 template <bool KEEP, int NMAX, bool FGEN, bool EXACT, bool PID>
 __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
-    constexpr bool DIRECT = !KEEP && SL3D_DIRECT_STORE;
-    __shared__ __attribute__((aligned(16))) float s_xyz[DIRECT ? 4 : 256 * 12];
+    __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
     __shared__ __attribute__((aligned(16))) double s_cam[256 * 8];  // undistorted camera coordinates of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_TAB];  // 1/d for the atan2 quotient (saves v_rcp_f64 + 4 fma per atan2)
     fill_rcp_table(s_rcp);
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     if (row >= P.H) return;
     const int gx0 = P.col0 + cq * 4, gy = P.row0 + row;
     const float nanv = __builtin_nanf("");
-    float *my_xyz = s_xyz + (DIRECT ? 0 : threadIdx.x * 12);
+    float *my_xyz = s_xyz + threadIdx.x * 12;
     const unsigned lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;  // byte offset of the quad inside any plane
     const unsigned ps = (unsigned)P.plane_stride;
 
@@ -556,14 +565,152 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
     const int v_begin = first_view + (int)blockIdx.y * vpt;
     const int v_end = min(v_begin + vpt, first_view + n_views);
-    // the mask of the NEXT view is requested before the current view's planes, so a wave never waits a full memory
-    // round trip for 36 bytes before it can ask for its 11.5 KB
+    // ---- building blocks of one view ------------------------------------------------------------------------------
+    // planes of a view: vertical axis (fringe F, gray Nv, inverse Nv), then the horizontal axis.  Plane offsets are added
+    // to the scalar view base (SALU); every load uses the same 32-bit VGPR offset.  Instruction selection works per basic
+    // block: the zero-extension of the lane offset has to happen in the block of the loads for them to select the
+    // (SGPR base + 32-bit VGPR offset) form, hence the per-call copy behind an empty asm.
+    auto issue_fringe = [&](int view, unsigned (&f)[2][4]) {
+        const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
+        const unsigned psv = opaque_u32(ps);  // per-view copy: plane offsets are recomputed, not kept live
+        unsigned lo = lane_off;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
+            f[a][0] = ldg32(vb + (size_t)p0, lo);
+            f[a][1] = ldg32(vb + (size_t)(p0 + psv), lo);
+            f[a][2] = ldg32(vb + (size_t)(p0 + 2u * psv), lo);
+            f[a][3] = (FGEN && F == 4) ? ldg32(vb + (size_t)(p0 + 3u * psv), lo) : 0u;
+        }
+    };
+    auto issue_gray = [&](int view, unsigned (&g)[2][NMAX], unsigned (&iv)[2][NMAX]) {
+        const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
+        const unsigned psv = opaque_u32(ps);
+        unsigned lo = lane_off;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int N = a == 0 ? Nv : Nh;
+            const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
+#pragma unroll
+            for (int i = 0; i < NMAX; i++) {
+                const unsigned ii = (unsigned)min(i, N - 1);  // clamp: planes beyond N re-read plane N-1 and are ignored by decode
+                g[a][i] = ldg32(vb + (size_t)(pg + ii * psv), lo);
+                iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + ii) * psv), lo);
+            }
+        }
+    };
+    // Gray decode, byte-parallel over the 4 pixels of the lane.
+    // G_i = (gray - inverse >= 0) (4/phase_unwrap.cpp:183) for 4 bytes at once: the low 7 bits are compared by a
+    // borrow-protected subtraction, bit 7 decides unless the top bits are equal (one v_bitop3 on x, y, t).
+    // B_0 = G_0, B_i = B_{i-1} xor G_i (:187-191) is a running xor of the masks; the code sum B_i 2^(N-1-i) (:193) is
+    // accumulated per byte, the LAST 8 planes in `lo`, the ones before them in `hi`, so that the 16-bit code of a pixel
+    // is (hi byte, lo byte) and one v_perm per pixel pair builds it: code[a][j] = codes of pixels 2j (low half), 2j+1.
+    auto decode = [&](const unsigned (&g)[2][NMAX], const unsigned (&iv)[2][NMAX], unsigned (&code)[2][2]) {
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int N = a == 0 ? Nv : Nh;
+            const unsigned H = 0x80808080u;
+            unsigned bacc = 0;  // running binary bit of pixel k at bit 8k+7
+            unsigned hi = 0, lo = 0;
+#pragma unroll
+            for (int i = 0; i < NMAX; i++) {
+                if (i < N) {
+                    const unsigned x = g[a][i], y = iv[a][i];
+                    const unsigned t = (x | H) - (y & ~H);                           // bit 8k+7: (x & 0x7f) >= (y & 0x7f)
+                    const unsigned ge = __builtin_amdgcn_bitop3_b32(x, y, t, 0xB2);  // (x & ~y) | (~(x ^ y) & t): byte x >= byte y
+                    bacc = __builtin_amdgcn_bitop3_b32(bacc, ge, H, 0x78);           // bacc ^ (ge & H)
+                    if (i < N - 8) hi = (hi << 1) | (bacc >> 7);
+                    else lo = (lo << 1) | (bacc >> 7);
+                }
+            }
+            code[a][0] = __builtin_amdgcn_perm(hi, lo, 0x05010400u);  // bytes (lo0, hi0, lo1, hi1); selectors 0-3 = lo, 4-7 = hi
+            code[a][1] = __builtin_amdgcn_perm(hi, lo, 0x07030602u);  // bytes (lo2, hi2, lo3, hi3)
+        }
+    };
+    // one pixel of the timed mode: no divergent branch inside (an invalid pixel's result is replaced by NaN at the end)
+    // `i` (0 or 1, compile-time after inlining) is the pixel's place in the CURRENT pair: the pair loop shifts the fringe
+    // dwords, the code words and the valid bits down after each pair, so every operand sits at a fixed byte / half-word
+    // (static sub-dword selects instead of shifts by a loop counter); k = 2*pair + i only addresses LDS and the frame.
+    auto pixel = [&](int i, int k, size_t px, unsigned vbits, const unsigned (&f)[2][4], const unsigned (&code)[2][2], unsigned &ok,
+                     float &ox, float &oy, float &oz) {
+        const int sh = 8 * i;
+        if (SL3D_ABLATE & 1) {
+            ox = __uint_as_float(((code[0][0] ^ f[0][0] ^ f[1][1]) >> sh) | 0x3f800000u);
+            oy = __uint_as_float(((code[1][0] ^ f[0][1] ^ f[1][2]) >> sh) | 0x3f800000u);
+            oz = __uint_as_float(((code[0][1] ^ code[1][1] ^ f[0][2] ^ f[1][0]) >> sh) | 0x3f800000u);
+            ok = 1u;
+            return;
+        }
+        const int code_v = (int)((code[0][0] >> (16 * i)) & 0xffffu);
+        const int code_h = (int)((code[1][0] >> (16 * i)) & 0xffffu);
+        const AtanK AK = atan_consts<true>();
+        float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+        float wh = wrapped_phase<true>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+        // stage 4 shifts by +Pi only inside its loop range (4/phase_unwrap.cpp:285,290,304,308); outside it the
+        // unwrapped value is 0 whatever the wrapped one is (pixel_chain), and the timed mode does not keep wrapped
+        wv = shift_pi(wv);
+        wh = shift_pi(wh);
+        const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
+        const PixelResult R = pixel_chain<false, PID>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
+        const bool okpx = ((vbits >> i) & 1u) && R.valid;
+        ox = okpx ? R.x : nanv;
+        oy = okpx ? R.y : nanv;
+        oz = okpx ? R.z : nanv;
+        ok = okpx ? 1u : 0u;
+    };
+    // the 4 pixels of a lane as two pairs: two independent fp64 dependency chains per iteration for the scheduler to
+    // interleave (tools/ab.sh: 1 pixel per iteration -3 %, all 4 unrolled +1 % but 12 more VGPRs)
+    auto pixel_pairs = [&](size_t px, unsigned vbits, unsigned (&f)[2][4], unsigned (&code)[2][2]) -> unsigned {
+        unsigned vout = 0;
+        SL3D_UNROLL(SL3D_PAIR_UNROLL)
+        for (int j = 0; j < 2; j++) {
+            unsigned ok0, ok1;
+            pixel(0, 2 * j, px, vbits, f, code, ok0, my_xyz[6 * j + 0], my_xyz[6 * j + 1], my_xyz[6 * j + 2]);
+            pixel(1, 2 * j + 1, px, vbits, f, code, ok1, my_xyz[6 * j + 3], my_xyz[6 * j + 4], my_xyz[6 * j + 5]);
+            vout = (vout >> 16) | (ok0 << 16) | (ok1 << 24);  // after two pairs: valid byte of pixel k at byte k
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) f[a][p] >>= 16;
+                code[a][0] = code[a][1];
+            }
+            vbits >>= 2;
+        }
+        return vout;
+    };
+    // the 48 B of xyz a lane produces are staged in LDS (the rolled pixel loop indexes them) and leave as three 16-B
+    // stores per lane; each lane reads back only what it wrote itself: no barrier needed
+    auto store_quad = [&](size_t px, unsigned vout) {
+        float4 *out_xyz = (float4 *)(P.points + 3 * px);
+        const float4 *sx = (const float4 *)my_xyz;
+        if (!(SL3D_ABLATE & 4) || KEEP || sx[0].x == 12345.f) {
+            out_xyz[0] = sx[0];
+            out_xyz[1] = sx[1];
+            out_xyz[2] = sx[2];
+        }
+        *(unsigned *)(P.valid + px) = vout;
+    };
+    auto fill_nan = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
+    };
+
     const bool interior = quad_is_interior(P, cq, row);
+    // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
+    auto valid_bits = [&](const MaskQuad &m) -> unsigned {
+        return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(P, m, cq, interior);
+    };
+
+    // The mask of the NEXT view is requested before the current view's planes, so a wave never waits a full memory
+    // round trip for 36 bytes before it can ask for its 11.5 KB.  (Going further -- the next view's planes in flight
+    // during the pixel loop, landing in the registers the decode has freed -- was measured: 142 VGPRs, 3 waves/SIMD,
+    // -6 %; squeezed into 128 with spills, -14 %.  Occupancy hides the latency better than in-wave pipelining.)
     MaskQuad mq = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row, interior);
     for (int view = v_begin; view < v_end; view++) {
-        // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
         if (!SL3D_MASK_PREFETCH && view > v_begin) mq = load_mask_quad(P, view, cq, row, interior);
-        const unsigned vbits = (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(P, mq, cq, interior);
+        const unsigned vbits = valid_bits(mq);
         if (SL3D_MASK_PREFETCH && view + 1 < v_end) mq = load_mask_quad(P, view + 1, cq, row, interior);
         const size_t px = (size_t)view * P.px_view_stride + (size_t)lane_off;  // first pixel of the quad
         unsigned vout = 0;
@@ -582,77 +729,21 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
                 P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
             }
         }
-        if (DIRECT) {
-            if (vbits == 0) {
-                float4 *o = (float4 *)(P.points + 3 * px);
-                o[0] = o[1] = o[2] = make_float4(nanv, nanv, nanv, nanv);
-            }
-        } else if (KEEP || vbits == 0) {
-#pragma unroll
-            for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
-        }
+        if (KEEP || vbits == 0) fill_nan();
 
         if (vbits != 0) {
-            // planes of a view: vertical axis (fringe F, gray Nv, inverse Nv), then the horizontal axis
-            const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
-            const unsigned psv = opaque_u32(ps);  // per-view copy: plane offsets are recomputed (SALU), not kept live
-            // instruction selection works per basic block: the zero-extension of the lane offset has to happen in THIS
-            // block for the loads to select the (SGPR base + 32-bit VGPR offset) form
-            unsigned lane_off_v = lane_off;
-            asm volatile("" : "+v"(lane_off_v));
-            unsigned f[2][4], g[2][NMAX], iv[2][NMAX];
-            // ---- issue every load of the view ----
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
-                // plane offsets are added to the scalar base (SALU); every load uses the same VGPR offset
-                f[a][0] = ldg32(vb + (size_t)p0, lane_off_v);
-                f[a][1] = ldg32(vb + (size_t)(p0 + psv), lane_off_v);
-                f[a][2] = ldg32(vb + (size_t)(p0 + 2u * psv), lane_off_v);
-                f[a][3] = (FGEN && F == 4) ? ldg32(vb + (size_t)(p0 + 3u * psv), lane_off_v) : 0u;
-            }
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const int N = a == 0 ? Nv : Nh;
-                const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
-#pragma unroll
-                for (int i = 0; i < NMAX; i++) {
-                    const unsigned ii = (unsigned)min(i, N - 1);  // clamp: planes beyond N re-read plane N-1 and are ignored below
-                    g[a][i] = ldg32(vb + (size_t)(pg + ii * psv), lane_off_v);
-                    iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + ii) * psv), lane_off_v);
-                }
-            }
-            // ---- Gray decode, byte-parallel over the 4 pixels of the lane ----
-            // G_i = (gray - inverse >= 0) (4/phase_unwrap.cpp:183) for 4 bytes at once: the low 7 bits are
-            // compared by a borrow-protected subtraction, bit 7 decides unless the top bits are equal.
-            // B_0 = G_0, B_i = B_{i-1} xor G_i (:187-191) is a running xor of the masks; the code
-            // sum B_i 2^(N-1-i) (:193) is accumulated per byte: planes 0..7 in accA, planes 8..15 in accB.
-            unsigned accA[2] = {0, 0}, accB[2] = {0, 0};
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const int N = a == 0 ? Nv : Nh;
-                const unsigned H = 0x80808080u;
-                unsigned bacc = 0;  // running binary bit of pixel k at bit 8k+7
-#pragma unroll
-                for (int i = 0; i < NMAX; i++) {
-                    if (i < N) {
-                        const unsigned x = g[a][i], y = iv[a][i];
-                        const unsigned t = (x | H) - (y & ~H);               // bit 8k+7: (x & 0x7f) >= (y & 0x7f)
-                        const unsigned ge = (x & ~y) | (~(x ^ y) & t);       // bit 8k+7: byte x >= byte y
-                        bacc ^= ge & H;
-                        if (i < 8) accA[a] = (accA[a] << 1) | (bacc >> 7);
-                        else accB[a] = (accB[a] << 1) | (bacc >> 7);
-                    }
-                }
-            }
-            const int shA_v = Nv > 8 ? Nv - 8 : 0, shA_h = Nh > 8 ? Nh - 8 : 0;
+            unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
+            // every load of the view is issued before the first one is consumed
+            issue_fringe(view, f);
+            issue_gray(view, g, iv);
+            decode(g, iv, code);
             if (KEEP) {
 #pragma unroll 1
                 for (int k = 0; k < 4; k++) {
                     if ((vbits >> k) & 1u) {
                         const int sh = 8 * k;
-                        const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
-                        const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
+                        const int code_v = (int)((code[0][k >> 1] >> (16 * (k & 1))) & 0xffffu);
+                        const int code_h = (int)((code[1][k >> 1] >> (16 * (k & 1))) & 0xffffu);
                         // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
                         const AtanK AK = atan_consts<true>();
                         float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
@@ -670,78 +761,10 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
                     }
                 }
             } else {
-                // timed mode: no divergent branch inside the pixel body; two pixels per iteration so the scheduler can
-                // interleave two independent fp64 dependency chains (measured: 1 -> 73.7, 2 -> 75.9, 4 -> 70.7 Gpx/s, spills)
-                auto pixel = [&](int k, float &ox, float &oy, float &oz) {
-                    const int sh = 8 * k;
-                    if (SL3D_ABLATE & 1) {
-                        ox = __uint_as_float(((accA[0] ^ f[0][0] ^ f[1][1]) >> sh) | 0x3f800000u);
-                        oy = __uint_as_float(((accA[1] ^ f[0][1] ^ f[1][2]) >> sh) | 0x3f800000u);
-                        oz = __uint_as_float(((accB[0] ^ accB[1] ^ f[0][2] ^ f[1][0]) >> sh) | 0x3f800000u);
-                        vout |= 1u << sh;
-                        return;
-                    }
-                    const int code_v = (int)((((accA[0] >> sh) & 255u) << shA_v) | ((accB[0] >> sh) & 255u));
-                    const int code_h = (int)((((accA[1] >> sh) & 255u) << shA_h) | ((accB[1] >> sh) & 255u));
-                    const AtanK AK = atan_consts<true>();
-                    float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
-                    float wh = wrapped_phase<true>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
-                    // stage 4 shifts by +Pi only inside its loop range (4/phase_unwrap.cpp:285,290,304,308); outside it the
-                    // unwrapped value is 0 whatever the wrapped one is (pixel_chain), and the timed mode does not keep wrapped
-                    wv = shift_pi(wv);
-                    wh = shift_pi(wh);
-                    const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
-                    const PixelResult R = pixel_chain<false, PID>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
-                    const bool okpx = ((vbits >> k) & 1u) && R.valid;
-                    ox = okpx ? R.x : nanv;
-                    oy = okpx ? R.y : nanv;
-                    oz = okpx ? R.z : nanv;
-                    vout |= (okpx ? 1u : 0u) << sh;
-                };
-                if (DIRECT && SL3D_DIRECT_STORE == 2) {
-                    // all 4 pixels unrolled (static byte selects), three dwordx4 stores from registers
-                    float o[12];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) pixel(k, o[3 * k], o[3 * k + 1], o[3 * k + 2]);
-                    float4 *d = (float4 *)(P.points + 3 * px);
-                    d[0] = make_float4(o[0], o[1], o[2], o[3]);
-                    d[1] = make_float4(o[4], o[5], o[6], o[7]);
-                    d[2] = make_float4(o[8], o[9], o[10], o[11]);
-                } else if (DIRECT) {
-                    // pixel pairs: 24 B of xyz per iteration leave as dwordx4 + dwordx2 (the quad's 48 B start 16-B aligned)
-                    float *o = P.points + 3 * px;
-#pragma unroll 1
-                    for (int j = 0; j < 2; j++) {
-                        float a0, a1, a2, b0, b1, b2;
-                        pixel(2 * j, a0, a1, a2);
-                        pixel(2 * j + 1, b0, b1, b2);
-                        if (j == 0) {
-                            *(float4 *)o = make_float4(a0, a1, a2, b0);
-                            *(float2 *)(o + 4) = make_float2(b1, b2);
-                        } else {
-                            *(float2 *)(o + 6) = make_float2(a0, a1);
-                            *(float4 *)(o + 8) = make_float4(a2, b0, b1, b2);
-                        }
-                    }
-                } else {
-                    SL3D_UNROLL(SL3D_PX_UNROLL)
-                    for (int k = 0; k < 4; k++) pixel(k, my_xyz[3 * k + 0], my_xyz[3 * k + 1], my_xyz[3 * k + 2]);
-                }
+                vout = pixel_pairs(px, vbits, f, code);
             }
         }
-        if (DIRECT) {
-            *(unsigned *)(P.valid + px) = vout;
-            continue;
-        }
-        // each lane reads back only what it wrote itself: no barrier needed
-        float4 *out_xyz = (float4 *)(P.points + 3 * px);
-        const float4 *sx = (const float4 *)my_xyz;
-        if (!(SL3D_ABLATE & 4) || KEEP || sx[0].x == 12345.f) {
-            out_xyz[0] = sx[0];
-            out_xyz[1] = sx[1];
-            out_xyz[2] = sx[2];
-        }
-        *(unsigned *)(P.valid + px) = vout;
+        store_quad(px, vout);
     }
 }
 

@@ -31,9 +31,11 @@ static double atan2_lattice(int t1, int t2)
     double z = r * r, p = Q[0];
     for (int i = 1; i <= SL3D_ATAN_DEG; i++) p = fma(p, z, Q[i]);
     double a = fma(r, z * p, r);
-    int k1 = (red ? 1 : 0) + ((swap && !red) ? 2 : 0), k2 = t2 < 0 ? 4 - k1 : k1;
-    int neg = ((swap != red) != (t2 < 0)) != (t1 < 0);
-    return fma((double)(t1 < 0 ? -k2 : k2), SL3D_PIO4, neg ? -a : a);
+    int k1 = red ? 1 : (swap ? 2 : 0), k2 = t2 < 0 ? 4 - k1 : k1;
+    int nega = (swap != red) != (t2 < 0);
+    /* the kernel rounds the non-negative value to float and then applies the sign of t1: same float */
+    double phi2 = fma((double)k2, SL3D_PIO4, nega ? -a : a);
+    return t1 < 0 ? -phi2 : phi2;
 }
 
 /* relative distance of v to the nearest float rounding boundary */

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel A/B experiments.
-#   here (no GPU):  tools/ab.sh build NAME "-DSL3D_PX_UNROLL=4" [NAME2 "flags2" ...]   -> ab/libsl3d_NAME.so (+ VGPR/scratch report)
+#   here (no GPU):  tools/ab.sh build NAME "-DSL3D_PAIR_UNROLL=2" [NAME2 "flags2" ...]   -> ab/libsl3d_NAME.so (+ VGPR/scratch report)
 #   on the GPU box: tools/ab.sh run [bench args]        -> one line per variant: value frac ms  (steady-state defaults)
 # ab/ is git-ignored but travels with gpurun.  The default library (3dscan_amd/libsl3d.so) is always measured as "base".
 set -u
