@@ -323,6 +323,26 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     fill_intr(x->C.proj, Kp, dp);
     rodrigues(rc, x->S.Rc);
     rodrigues(rp, x->S.Rp);
+    {   // camera-frame form (DevCal): Apc = [Ap3*Rc^T | ap4 - Ap3*Rc^T*tc], Rct = Rc^T, tcn = -Rc^T*tc
+        DevCal &C = x->C;
+        const double *R = x->S.Rc;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) {
+                double acc = 0;
+                for (int k = 0; k < 3; k++) acc += C.Ap[i * 4 + k] * R[j * 3 + k];  // (Ap3 * Rc^T)[i][j]
+                C.Apc[i * 4 + j] = acc;
+            }
+            double acc = C.Ap[i * 4 + 3];
+            for (int j = 0; j < 3; j++) acc -= C.Apc[i * 4 + j] * tc[j];
+            C.Apc[i * 4 + 3] = acc;
+        }
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) C.Rct[i * 3 + j] = R[j * 3 + i];
+            C.tcn[i] = -(R[0 * 3 + i] * tc[0] + R[1 * 3 + i] * tc[1] + R[2 * 3 + i] * tc[2]);
+        }
+        C.fx2 = Kc[0] * Kc[0];
+        C.fy2 = Kc[4] * Kc[4];
+    }
     memcpy(x->S.tc, tc, sizeof x->S.tc);
     memcpy(x->S.tp, tp, sizeof x->S.tp);
     memcpy(x->S.Kp, Kp, sizeof x->S.Kp);
@@ -520,7 +540,7 @@ extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
-    return launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0, first_view, n_views, x->keep, x->stream));
+    return launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0 && x->C.cam.plain != 0, first_view, n_views, x->keep, x->stream));
 }
 
 extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
@@ -530,7 +550,7 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
-    rc = launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0, first_view, n_views, x->keep, x->stream));
+    rc = launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0 && x->C.cam.plain != 0, first_view, n_views, x->keep, x->stream));
     if (rc) return rc;
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));

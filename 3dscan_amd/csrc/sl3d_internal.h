@@ -28,6 +28,13 @@ struct Intr {
 struct DevCal {
     double Ac[12], Ap[12];
     Intr cam, proj;
+    // Camera-frame form of the same least-squares problem (fast path of the fused kernel; valid when the camera matrix
+    // is plain, K = [fx 0 cx; 0 fy cy; 0 0 1]).  With Y = Rc*X + tc the two camera rows of P become fx*(1,0,-xn) and
+    // fy*(0,1,-yn) with a zero right-hand side ((xn,yn) = undistorted normalised coordinates), so their part of
+    // P^T P is 4 flops instead of 26; the rigid change of variables leaves the minimiser unchanged.
+    double Apc[12];       // Ap * [Rc tc; 0 1]^-1 : projector projection matrix acting on camera-frame points
+    double Rct[9], tcn[3];  // X = Rct*Y + tcn  (Rct = Rc^T, tcn = -Rc^T tc)
+    double fx2, fy2;      // Kc[0]^2, Kc[4]^2
 };
 
 // Scene + camera model of the synthetic-capture generator (k_synth).
@@ -76,7 +83,7 @@ struct KParams {
 };
 
 // launchers (sl3d_kernels.hip); `stream` is a hipStream_t
-int launch_fused(const KParams &P, const DevCal *d_cal, bool proj_identity, int first_view, int n_views, bool keep, void *stream);
+int launch_fused(const KParams &P, const DevCal *d_cal, bool fast_rig, int first_view, int n_views, bool keep, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);
 int launch_corr(const KParams &P, int view, void *stream);

@@ -32,6 +32,10 @@
 #endif
 // measurement only (tools/ab.sh): 1 = no per-pixel arithmetic (xyz made of the raw decode results), 2 = no mask reads,
 // 4 = no xyz stores.  Results are wrong by construction; never set in a shipped build.
+// 1: the fused kernel reads 1/d of the atan2 quotient from an LDS table (6 KB per block); 0: v_rcp_f64 + one Newton step
+#ifndef SL3D_RCP_LDS
+#define SL3D_RCP_LDS 1
+#endif
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
@@ -135,9 +139,12 @@ __device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, i
     const uint8_t *r1 = mb + (ptrdiff_t)row * P.mpitch + cq * 4;
     const uint8_t *r0 = r1 - P.mpitch, *r2 = r1 + P.mpitch;
     MaskQuad m;
-    m.bP = *(const unsigned *)(r0 - 4); m.bC = *(const unsigned *)r0; m.bN = *(const unsigned *)(r0 + 4);
-    m.cP = *(const unsigned *)(r1 - 4); m.cC = *(const unsigned *)r1; m.cN = *(const unsigned *)(r1 + 4);
-    m.dP = *(const unsigned *)(r2 - 4); m.dC = *(const unsigned *)r2; m.dN = *(const unsigned *)(r2 + 4);
+    // 12 contiguous bytes per row: one dwordx3 load (dword alignment is all it needs) instead of three dword loads
+    typedef unsigned u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+    const u32x3 b = *(const u32x3 *)(r0 - 4), c = *(const u32x3 *)(r1 - 4), d = *(const u32x3 *)(r2 - 4);
+    m.bP = b.x; m.bC = b.y; m.bN = b.z;
+    m.cP = c.x; m.cC = c.y; m.cN = c.z;
+    m.dP = d.x; m.dC = d.y; m.dN = d.z;
     m.band = 0;
     if (!interior) m.band = *(const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + cq * 4);
     return m;
@@ -182,6 +189,14 @@ __device__ __forceinline__ double recip(double d)
     r = fma(r, e, r);
     e = fma(-d, r, 1.0);
     return fma(r, e, r);
+}
+
+// 1/d for the tolerance path (stage 7): v_rcp_f64 is good to ~2^-26 (tools/valubench prints the measured bound), one
+// Newton step squares that
+__device__ __forceinline__ double recip1(double d)
+{
+    const double r = __builtin_amdgcn_rcp(d);
+    return fma(r, fma(-d, r, 1.0), r);
 }
 
 // Wrapped phase without a table: (float)atan2((double)t1,(double)t2) for the small integers the
@@ -237,7 +252,7 @@ __device__ __forceinline__ float atan2_lattice4(unsigned a, unsigned b, unsigned
     const unsigned num = red ? hi - lo : lo, den = red ? hi + lo : hi;
     // num/den to 1 ulp (den == 0 only for t1 == t2 == 0, where num == 0 as well: use 0/1); den <= 255 + 510
     const unsigned den1 = max(den, 1u);
-    const double r = (double)num * (TAB ? rcp_tab[den1] : recip((double)den1));
+    const double r = (double)num * (TAB ? rcp_tab[den1] : recip1((double)den1));
     const double z = r * r;
     double p = K.c[0];
 #pragma unroll
@@ -314,8 +329,9 @@ __device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, l
 //     7/triangulation.cpp:290-307 (camera), :363-378 (projector)
 // Terms whose coefficient is exactly zero are skipped through wave-uniform flags; each skipped term is
 // an exact zero in the reference's arithmetic, so the value is unchanged.
+// the 5 fixed-point iterations of cvUndistortPoints on normalised coordinates
 template <typename IntrT>
-__device__ __forceinline__ void undistort_reproject(double px, double py, const IntrT &I, double &u, double &v)
+__device__ __forceinline__ void undistort_normalized(double px, double py, const IntrT &I, double &xo, double &yo)
 {
     const double x0 = (px - I.cx) * I.ifx, y0 = (py - I.cy) * I.ify;
     double x = x0, y = y0;
@@ -340,6 +356,15 @@ __device__ __forceinline__ void undistort_reproject(double px, double py, const 
             }
         }
     }
+    xo = x;
+    yo = y;
+}
+
+template <typename IntrT>
+__device__ __forceinline__ void undistort_reproject(double px, double py, const IntrT &I, double &u, double &v)
+{
+    double x, y;
+    undistort_normalized(px, py, I, x, y);
     double uh, vh;
     if (I.plain) {  // K = [fx 0 cx; 0 fy cy; 0 0 1]
         uh = fma(I.K[0], x, I.K[2]);
@@ -364,6 +389,7 @@ __device__ __forceinline__ void undistort_reproject(double px, double py, const 
 // v_mov_b64; the kernel therefore keeps these 8 doubles in VGPRs (PinnedRows), loaded once per lane.
 struct PinnedRows {
     double c2[4], p2[4];  // A_cam[2][0..3], A_proj[2][0..3]
+    double t[3];          // fast rig only: tcn (an addend the compiler would otherwise copy into a VGPR pair per use)
 };
 
 template <typename AP>
@@ -398,6 +424,35 @@ __device__ __forceinline__ void triangulate_px(const CalT &C, const PinnedRows &
     X[0] = fma(c00, g0, fma(c01, g1, c02 * g2)) * rdet;
     X[1] = fma(c01, g0, fma(c11, g1, c12 * g2)) * rdet;
     X[2] = fma(c02, g0, fma(c12, g1, c22 * g2)) * rdet;
+}
+
+// The same least-squares problem in the camera frame (DevCal::Apc): the camera rows fx*(1,0,-xn), fy*(0,1,-yn) have a
+// closed-form normal matrix, only the two projector rows are accumulated, and the solution is rotated back to world
+// coordinates with the numerator (X = Rct*(adj*g)/det + tcn).  69 fp64 operations instead of 84, and the camera's third
+// row needs no pinned registers.  det == 0 (cvInvert's zero matrix, V = 0) is reported through `singular`.
+template <typename CalT>
+__device__ __forceinline__ void triangulate_camframe(const CalT &C, const PinnedRows &R, double xn, double yn, double up, double vp, double X[3],
+                                                     bool &singular)
+{
+    const double a = C.fx2 * xn, b = C.fy2 * yn;
+    double m00 = C.fx2, m01 = 0, m02 = -a, m11 = C.fy2, m12 = -b, m22 = fma(a, xn, b * yn), g0 = 0, g1 = 0, g2 = 0;
+    tri_row(C.Apc, R.p2, up, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
+    tri_row(C.Apc, R.p2, vp, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
+    const double c00 = fma(m11, m22, -m12 * m12);
+    const double c01 = fma(m02, m12, -m01 * m22);
+    const double c02 = fma(m01, m12, -m02 * m11);
+    const double c11 = fma(m00, m22, -m02 * m02);
+    const double c12 = fma(m01, m02, -m00 * m12);
+    const double c22 = fma(m00, m11, -m01 * m01);
+    const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
+    singular = det == 0.0;
+    const double rdet = recip1(det);
+    const double n0 = fma(c00, g0, fma(c01, g1, c02 * g2));
+    const double n1 = fma(c01, g0, fma(c11, g1, c12 * g2));
+    const double n2 = fma(c02, g0, fma(c12, g1, c22 * g2));
+    X[0] = fma(fma(C.Rct[0], n0, fma(C.Rct[1], n1, C.Rct[2] * n2)), rdet, R.t[0]);
+    X[1] = fma(fma(C.Rct[3], n0, fma(C.Rct[4], n1, C.Rct[5] * n2)), rdet, R.t[1]);
+    X[2] = fma(fma(C.Rct[6], n0, fma(C.Rct[7], n1, C.Rct[8] * n2)), rdet, R.t[2]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,19 +542,26 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
     }
     if (KEEP ? R.valid : true) {  // timed mode: branch-free (an invalid pixel's result is discarded by the caller)
         double up, vp, X[3];
+        bool singular = false;
         const auto &C = *Cp;
-        if (PID || C.proj.identity) {
-            // no projector distortion and K = [fx 0 cx; 0 fy cy; 0 0 1]: the reference's undistort +
-            // re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px): use x
-            up = cxd;
-            vp = cyd;
+        if (PID) {
+            // fast rig (no projector distortion, plain K for both devices; the reference's own calibration is one):
+            // the projector's undistort + re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px),
+            // and (cu,cv) are the camera's undistorted NORMALISED coordinates for the camera-frame solve
+            triangulate_camframe(C, PR, cu, cv, cxd, cyd, X, singular);
         } else {
-            undistort_reproject(cxd, cyd, C.proj, up, vp);
+            if (C.proj.identity) {
+                up = cxd;
+                vp = cyd;
+            } else {
+                undistort_reproject(cxd, cyd, C.proj, up, vp);
+            }
+            triangulate_px(C, PR, cu, cv, up, vp, X);
         }
-        triangulate_px(C, PR, cu, cv, up, vp, X);
         R.x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
         R.y = (float)X[1];
         R.z = (float)X[2];
+        if (PID && singular) R.x = R.y = R.z = 0.0f;  // cvInvert's zero matrix: V = 0
         if (KEEP) {
             P.ipoints[3 * keep_off + 0] = X[0];
             P.ipoints[3 * keep_off + 1] = X[1];
@@ -529,9 +591,11 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
 {
     __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
     __shared__ __attribute__((aligned(16))) double s_cam[256 * 8];  // undistorted camera coordinates of the lane's 4 pixels
-    __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_TAB];  // 1/d for the atan2 quotient (saves v_rcp_f64 + 4 fma per atan2)
-    fill_rcp_table(s_rcp);
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_LDS ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
+    if (SL3D_RCP_LDS) {
+        fill_rcp_table(s_rcp);
+        __syncthreads();
+    }
     const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -549,7 +613,10 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
 #pragma unroll 1
     for (int k = 0; k < 4; k++) {
         double cu = 0.0, cv = 0.0;
-        if (cq * 4 < P.W && !(P.ablate & 4)) undistort_reproject((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);
+        if (cq * 4 < P.W && !(P.ablate & 4)) {
+            if (PID) undistort_normalized((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);  // camera-frame solve
+            else undistort_reproject((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);
+        }
         my_cam[2 * k] = cu;
         my_cam[2 * k + 1] = cv;
     }
@@ -557,9 +624,14 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     PinnedRows PR;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        PR.c2[j] = Cglobal->Ac[8 + j];
-        PR.p2[j] = Cglobal->Ap[8 + j];
-        asm volatile("" : "+v"(PR.c2[j]), "+v"(PR.p2[j]));  // stay in VGPRs (see PinnedRows)
+        PR.c2[j] = PID ? 0.0 : Cglobal->Ac[8 + j];
+        PR.p2[j] = PID ? Cglobal->Apc[8 + j] : Cglobal->Ap[8 + j];
+        if (!PID) asm volatile("" : "+v"(PR.c2[j]));
+        asm volatile("" : "+v"(PR.p2[j]));  // stay in VGPRs (see PinnedRows)
+        if (j < 3) {
+            PR.t[j] = PID ? Cglobal->tcn[j] : 0.0;
+            if (PID) asm volatile("" : "+v"(PR.t[j]));
+        }
     }
     // EXACT: both axes have exactly NMAX Gray planes (the usual case): the plane clamps and the per-plane tests fold away
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
@@ -646,8 +718,8 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
         const int code_v = (int)((code[0][0] >> (16 * i)) & 0xffffu);
         const int code_h = (int)((code[1][0] >> (16 * i)) & 0xffffu);
         const AtanK AK = atan_consts<true>();
-        float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
-        float wh = wrapped_phase<true>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+        float wv = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+        float wh = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
         // stage 4 shifts by +Pi only inside its loop range (4/phase_unwrap.cpp:285,290,304,308); outside it the
         // unwrapped value is 0 whatever the wrapped one is (pixel_chain), and the timed mode does not keep wrapped
         wv = shift_pi(wv);
@@ -746,8 +818,8 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
                         const int code_h = (int)((code[1][k >> 1] >> (16 * (k & 1))) & 0xffffu);
                         // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
                         const AtanK AK = atan_consts<true>();
-                        float wv = wrapped_phase<true>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
-                        float wh = wrapped_phase<true>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+                        float wv = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+                        float wh = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
                         wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                         wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                         const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
@@ -787,8 +859,8 @@ static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st
 #undef SL3D_LAUNCH
 }
 
-// proj_identity: the projector has no distortion and a plain K (host knows; folded at compile time in the timed kernel)
-int launch_fused(const KParams &P, const DevCal *d_cal, bool proj_identity, int first_view, int n_views, bool keep, void *stream)
+// fast_rig: no projector distortion and a plain K for both devices (host knows; folded at compile time in the timed kernel)
+int launch_fused(const KParams &P, const DevCal *d_cal, bool fast_rig, int first_view, int n_views, bool keep, void *stream)
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = (unsigned)((quads + 255) / 256);
@@ -804,7 +876,7 @@ int launch_fused(const KParams &P, const DevCal *d_cal, bool proj_identity, int 
         else launch_fused_n<true, true, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (P.F != 3) {
         launch_fused_n<false, true, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (proj_identity) {
+    } else if (fast_rig) {
         launch_fused_n<false, false, true>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
         launch_fused_n<false, false, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel A/B experiments.
 #   here (no GPU):  tools/ab.sh build NAME "-DSL3D_PAIR_UNROLL=2" [NAME2 "flags2" ...]   -> ab/libsl3d_NAME.so (+ VGPR/scratch report)
+#                   tools/ab.sh buildrev NAME REV ["flags"]   -> ab/libsl3d_NAME.so built from git revision REV
 #   on the GPU box: tools/ab.sh run [bench args]        -> one line per variant: value frac ms  (steady-state defaults)
 # ab/ is git-ignored but travels with gpurun.  The default library (3dscan_amd/libsl3d.so) is always measured as "base".
 set -u
@@ -14,6 +15,12 @@ if [ "$1" = build ]; then
       -Rpass-analysis=kernel-resource-usage 2> ab/$n.res || { echo "build $n failed"; tail -5 ab/$n.res; continue; }
     echo "$n [$f]: $(grep -A12 'k_fusedILb0ELi10ELb0ELb1ELb1' ab/$n.res | grep -E 'VGPRs:|ScratchSize|Occupancy|SGPRs:' | sed 's/.*remark: [^ ]* *//' | tr '\n' ' ')"
   done
+elif [ "$1" = buildrev ]; then
+  # tools/ab.sh buildrev NAME REV [flags] : the library as of git revision REV (baseline for the working tree)
+  n=$2; rev=$3; f=${4:-}; mkdir -p ab /tmp/ab_$n/3dscan_amd/csrc /tmp/ab_$n/include
+  for x in sl3d_kernels.hip sl3d_capi.cpp sl3d_internal.h sl3d_atan_coeffs.h; do git show $rev:3dscan_amd/csrc/$x > /tmp/ab_$n/3dscan_amd/csrc/$x 2>/dev/null; done
+  git show $rev:include/sl3d.h > /tmp/ab_$n/include/sl3d.h
+  hipcc $FLAGS $f -shared -o ab/libsl3d_$n.so /tmp/ab_$n/3dscan_amd/csrc/sl3d_kernels.hip /tmp/ab_$n/3dscan_amd/csrc/sl3d_capi.cpp && echo "built ab/libsl3d_$n.so from $rev"
 elif [ "$1" = run ]; then
   shift
   for lib in 3dscan_amd/libsl3d.so ab/libsl3d_*.so; do
