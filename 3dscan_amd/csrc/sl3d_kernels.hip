@@ -191,8 +191,9 @@ __device__ __forceinline__ double recip(double d)
     return fma(r, e, r);
 }
 
-// 1/d for the tolerance path (stage 7): v_rcp_f64 is good to ~2^-26 (tools/valubench prints the measured bound), one
-// Newton step squares that
+// 1/d for the tolerance path (stage 7) and for the lattice atan2 without the LDS table: v_rcp_f64 is good to 2^-24.4,
+// one Newton step brings it to 2.2e-15 (tools/valubench measures both over 2^26 doubles), the second one (recip) to
+// the correctly rounded value
 __device__ __forceinline__ double recip1(double d)
 {
     const double r = __builtin_amdgcn_rcp(d);

@@ -2,6 +2,7 @@
 // instruction per SIMD), measured with 8 independent chains per lane and 4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 constexpr int ITER = 4096, CH = 8;
 
@@ -31,8 +32,36 @@ __global__ __launch_bounds__(256) void k(double *out, int n)
     out[1 + blockIdx.x * 256 + threadIdx.x] = s + t + g;
 }
 
+// accuracy of v_rcp_f64 alone, with one Newton step (recip1 of the kernels) and with two (recip): max relative error
+// against the IEEE division over 2^26 doubles spread over [2^-20, 2^20) (splitmix-style hash per element)
+__global__ void k_rcp_accuracy(double *maxerr)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    const double m = 1.0 + (double)(z >> 12) * 0x1p-52;                 // [1, 2)
+    const double d = ldexp(m, (int)(z & 63u) % 40 - 20) * ((z & 64u) ? -1.0 : 1.0);
+    const double ref = 1.0 / d;
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double r1 = fma(r0, fma(-d, r0, 1.0), r0);
+    const double r2 = fma(r1, fma(-d, r1, 1.0), r1);
+    const double e[3] = {fabs(r0 - ref) / fabs(ref), fabs(r1 - ref) / fabs(ref), fabs(r2 - ref) / fabs(ref)};
+    for (int j = 0; j < 3; j++) {
+        double v = e[j];
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&maxerr[j], (unsigned long long)__double_as_longlong(v));  // non-negative doubles order as integers
+    }
+}
+
 int main()
 {
+    {
+        double *me; CHK(hipMalloc(&me, 24)); CHK(hipMemset(me, 0, 24));
+        hipLaunchKernelGGL(k_rcp_accuracy, dim3(1 << 18), dim3(256), 0, 0, me);
+        double h[3]; CHK(hipMemcpy(h, me, 24, hipMemcpyDeviceToHost));
+        printf("max relative error over 2^26 doubles: v_rcp_f64 %.3e (2^%.1f), + 1 Newton step %.3e, + 2 steps %.3e\n", h[0], log2(h[0]), h[1], h[2]);
+        CHK(hipFree(me));
+    }
     double *out; CHK(hipMalloc(&out, (1 + 1024 * 256) * 8)); CHK(hipMemset(out, 0, 8));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     int clk = 0; CHK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
