@@ -40,6 +40,8 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
+    size_t pattern_pitch = 0;
     DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
     size_t mask_rows = 0;
 };
@@ -727,6 +729,73 @@ extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, flo
         HIPCHK(x, hipMemcpyAsync(xyz, x->d_reg, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         HIPCHK(x, hipStreamSynchronize(x->stream));
     }
+    return SL3D_OK;
+}
+
+// ---- N1: projector patterns (1/pattern_generator.cpp) ---------------------------------------------------------------
+#define PI_REF 22.0 / 7.0 /* PROJECT_GLOBAL/global_cv.h:62: unparenthesised on purpose */
+
+extern "C" int sl3d_pattern_counts(int proj_extent, int fringe_width, int *n_codes, int *n_planes)
+{
+    if (proj_extent < 1 || fringe_width < 1 || !n_codes || !n_planes) return SL3D_E_INVALID_ARG;
+    *n_codes = (int)ceil((float)proj_extent / (float)fringe_width);                 // :224 / :228
+    *n_planes = (int)ceil((logf((float)*n_codes) / logf(2.0)));                     // :226 / :229
+    return SL3D_OK;
+}
+
+// the values of one pattern along its varying axis, with the reference's expressions and the host libm it calls
+static void pattern_profile(int kind, int F, int index, int extent, int fw, int nplanes, uint8_t *out)
+{
+    memset(out, 0, (size_t)extent);
+    if (kind == SL3D_PATTERN_FRINGE) {
+        for (int p = 0; p < extent; p++) {
+            float t = 0.0;
+            if (F == 3) t = 127.0f + 128.0f * cosf(((float)p / (float)fw) * 2.0 * PI_REF - PI_REF - ((PI_REF) / 2.0) + (PI_REF / 2.0) * (float)index);  // :302
+            else if (F == 4) t = 127.0 + 128.0 * cosf(((float)p / (float)fw) * (2.0 * PI_REF) - PI_REF + (PI_REF / 2.0) * (float)index);               // :340
+            else t = 127.0f + 128.0f * cosf(((float)p / (float)fw) * (2.0 * PI_REF) - PI_REF - 2.0 * ((PI_REF) / 2) + ((PI_REF) / 2) * (float)index);   // :369
+            out[p] = (uint8_t)(int)t;  // a float in [-1, 255] through int, as the x86 build of `(unsigned char)t` does (-1 -> 255)
+        }
+    } else if (index < nplanes && (kind == SL3D_PATTERN_GRAY || kind == SL3D_PATTERN_INVERSE_GRAY)) {
+        for (int c = 0, code = 0; c < extent; c += fw, code++) {
+            // bit `index` (MSB first, nplanes bits) of the Gray code of `code`: B_{i-1} xor B_i  (:83-101)
+            const int sh = nplanes - 1 - index;
+            const int b = (code >> sh) & 1, bp = index == 0 ? 0 : (code >> (sh + 1)) & 1;
+            const uint8_t g = (uint8_t)((b ^ bp) * 255);
+            for (int o = 0; o < fw && c + o < extent; o++) out[c + o] = kind == SL3D_PATTERN_GRAY ? g : (uint8_t)(255 - g);
+        }
+    } else if (index < nplanes && kind == SL3D_PATTERN_BINARY) {
+        for (int p = 0; p < extent; p++) out[p] = ((int)(p / (pow(2, index) * fw)) % 2) == 1 ? 255 : 0;  // :275-283
+    }
+}
+
+extern "C" int sl3d_generate_pattern(sl3d_ctx *x, int kind, int axis, int index, uint8_t *host_dst, size_t stride,
+                                     const uint8_t **device_ptr, size_t *device_pitch)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    const int PW = x->cfg.proj_width, PH = x->cfg.proj_height, F = x->cfg.n_fringe;
+    if (kind < SL3D_PATTERN_FRINGE || kind > SL3D_PATTERN_BINARY || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "pattern: kind or axis");
+    const int nplanes = axis == 0 ? x->cfg.n_gray_v : x->cfg.n_gray_h, fw = axis == 0 ? x->cfg.fringe_width_v : x->cfg.fringe_width_h;
+    if (index < 0 || index >= (kind == SL3D_PATTERN_FRINGE ? F : nplanes + 1)) return fail(x, SL3D_E_INVALID_ARG, "pattern: index out of range");
+    if (host_dst && stride < (size_t)PW) return fail(x, SL3D_E_INVALID_ARG, "pattern: stride < proj_width");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const size_t pitch = ((size_t)PW + 15) / 16 * 16, extent_max = (size_t)std::max(PW, PH) + 16;
+    if (!x->d_pattern) {
+        HIPCHK(x, hipMalloc((void **)&x->d_pattern, pitch * (size_t)PH));
+        x->allocs.push_back(x->d_pattern);
+        HIPCHK(x, hipMalloc((void **)&x->d_profile, extent_max));
+        x->allocs.push_back(x->d_profile);
+        x->pattern_pitch = pitch;
+    }
+    std::vector<uint8_t> prof(extent_max, 0);
+    pattern_profile(kind, F, index, axis == 0 ? PW : PH, fw, nplanes, prof.data());
+    HIPCHK(x, hipStreamSynchronize(x->stream));  // the previous pattern may still be in flight
+    HIPCHK(x, hipMemcpy(x->d_profile, prof.data(), extent_max, hipMemcpyHostToDevice));
+    int rc = launched(x, launch_pattern(x->d_pattern, pitch, PW, PH, axis, x->d_profile, x->stream));
+    if (rc) return rc;
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    if (host_dst) HIPCHK(x, hipMemcpy2D(host_dst, stride, x->d_pattern, pitch, (size_t)PW, (size_t)PH, hipMemcpyDeviceToHost));
+    if (device_ptr) *device_ptr = x->d_pattern;
+    if (device_pitch) *device_pitch = pitch;
     return SL3D_OK;
 }
 

@@ -92,6 +92,7 @@ int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned 
                    float *cloud, void *stream);
 int launch_register(const float *in, float *out, long n, const float R4[4], float tx, float ty, float tz, void *stream);
 int launch_synth(const KParams &P, const DevCal &C, const SynthParams &S, int view, void *stream);
+int launch_pattern(uint8_t *dst, size_t pitch, int PW, int PH, int axis, const uint8_t *profile, void *stream);
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 
 }  // namespace sl3d

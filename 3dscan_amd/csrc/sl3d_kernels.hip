@@ -1014,6 +1014,32 @@ __global__ __launch_bounds__(256) void k_tri(const KParams P, const DevCal C, in
     P.points[3 * px + 2] = z;
 }
 
+// N1: one projector pattern (1/pattern_generator.cpp).  Every pattern is constant along one axis, so the host evaluates
+// the reference's expression once per column (or row) with the libm the reference calls (cosf, pow: sl3d_generate_pattern)
+// and this kernel replicates the profile: 16 bytes per lane, write-only, HBM bound (PW*PH bytes per pattern).
+__global__ __launch_bounds__(256) void k_pattern(uint8_t *__restrict__ dst, size_t pitch, int PW, int PH, int axis,
+                                                 const uint8_t *__restrict__ profile)
+{
+    const int c16 = blockIdx.x * blockDim.x + threadIdx.x;  // 16-byte column group
+    const int r = blockIdx.y;
+    if (c16 * 16 >= PW) return;
+    uint4 v;
+    if (axis == 0) {
+        v = *(const uint4 *)(profile + (size_t)c16 * 16);  // the profile buffer is padded to a multiple of 16
+    } else {
+        const unsigned b = profile[r] * 0x01010101u;
+        v = make_uint4(b, b, b, b);
+    }
+    *(uint4 *)(dst + (size_t)r * pitch + (size_t)c16 * 16) = v;  // pitch is a multiple of 16: the padding takes the spill-over
+}
+
+int launch_pattern(uint8_t *dst, size_t pitch, int PW, int PH, int axis, const uint8_t *profile, void *stream)
+{
+    const int groups = (PW + 15) / 16;
+    hipLaunchKernelGGL(k_pattern, dim3((groups + 255) / 256, PH), dim3(256), 0, (hipStream_t)stream, dst, pitch, PW, PH, axis, profile);
+    return (int)hipGetLastError();
+}
+
 // Exhaustive self-check of atan2_lattice / shift_pi against the host-libm table (see sl3d_create)
 __global__ __launch_bounds__(256) void k_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches)
 {

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sys/stat.h>
 #include <vector>
 
 #include "../../include/sl3d.h"
@@ -95,20 +96,23 @@ bool read_bmp_gray(const std::string &path, std::vector<uint8_t> &out)
     return true;
 }
 
-bool write_bmp_gray(const std::string &path, const uint8_t *img)
+// 8-bit palettised BMP exactly as the reference's cvSaveImage (OpenCV 2.4 BMP encoder) writes a 1-channel image:
+// 14 + 40 byte headers with biSizeImage = biClrUsed = 0, 256 grey palette entries, bottom-up rows padded to 4 bytes.
+// (tests/test_gpu_shim.py compares whole files with the SHA-256 of the reference's own pattern images.)
+bool write_bmp_gray(const std::string &path, const uint8_t *img, int w = W, int h = H)
 {
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) return false;
-    const uint32_t rowbytes = ((uint32_t)W + 3) & ~3u, off = 54 + 1024, size = off + rowbytes * H;
+    const uint32_t rowbytes = ((uint32_t)w + 3) & ~3u, off = 54 + 1024, size = off + rowbytes * h;
     uint8_t hdr[54] = {0};
     auto put32 = [&](int o, uint32_t v) { hdr[o] = v & 255; hdr[o + 1] = (v >> 8) & 255; hdr[o + 2] = (v >> 16) & 255; hdr[o + 3] = v >> 24; };
     hdr[0] = 'B'; hdr[1] = 'M';
-    put32(2, size); put32(10, off); put32(14, 40); put32(18, W); put32(22, H);
-    hdr[26] = 1; hdr[28] = 8; put32(34, rowbytes * H); put32(46, 256);
+    put32(2, size); put32(10, off); put32(14, 40); put32(18, w); put32(22, h);
+    hdr[26] = 1; hdr[28] = 8;
     fwrite(hdr, 1, 54, f);
     for (int i = 0; i < 256; i++) { uint8_t q[4] = {(uint8_t)i, (uint8_t)i, (uint8_t)i, 0}; fwrite(q, 1, 4, f); }
     std::vector<uint8_t> row(rowbytes, 0);
-    for (int y = H - 1; y >= 0; y--) { memcpy(row.data(), img + (size_t)y * W, W); fwrite(row.data(), 1, rowbytes, f); }
+    for (int y = h - 1; y >= 0; y--) { memcpy(row.data(), img + (size_t)y * w, w); fwrite(row.data(), 1, rowbytes, f); }
     fclose(f);
     return true;
 }
@@ -194,6 +198,44 @@ extern "C" void sl3d_shim_reset(void)
 {
     if (g.ctx) sl3d_destroy(g.ctx);
     g.ctx = nullptr;
+}
+
+// ---- stage 1: generate_pattern() ----------------------------------------------------------------------
+// 1/pattern_generator.cpp:513-544.  The reference's allocate_memory() asks for the number of fringe patterns and the two
+// fringe widths with scanf (:204-222); the shim takes them from the globals number_of_patterns_fringe and
+// fringe_width_pixels_{vertical,horizontal}, derives number_of_codes_* / number_of_patterns_binary_* exactly as
+// :224-229 does (and stores them in the globals, as the reference does), generates every pattern on the device and
+// saves the same files save_pattern_images() writes (:414-470) below <data root>/Generated_patterns/.
+void generate_pattern()
+{
+    g.status = SL3D_OK;
+    if (number_of_patterns_fringe < 3 || number_of_patterns_fringe > 5) { fail(SL3D_E_INVALID_ARG, "generate_pattern: 3, 4 or 5 fringe patterns"); return; }
+    if (!ok(sl3d_pattern_counts(Projector_imagewidth, fringe_width_pixels_vertical, &number_of_codes_vertical, &number_of_patterns_binary_vertical), "sl3d_pattern_counts")) return;
+    if (!ok(sl3d_pattern_counts(Projector_imageheight, fringe_width_pixels_horizontal, &number_of_codes_horizontal, &number_of_patterns_binary_horizontal), "sl3d_pattern_counts")) return;
+    if (!ensure_ctx()) return;
+    const int PWs = Projector_imagewidth, PHs = Projector_imageheight;
+    std::vector<uint8_t> img((size_t)PWs * PHs);
+    const std::string root = data_root() + "/Generated_patterns";
+    auto emit = [&](int kind, int axis, int index, const std::string &rel) {
+        if (!ok(sl3d_generate_pattern(g.ctx, kind, axis, index, img.data(), (size_t)PWs, nullptr, nullptr), "sl3d_generate_pattern")) return false;
+        const std::string path = root + "/" + rel;
+        const std::string dir = path.substr(0, path.rfind('/'));
+        for (size_t i = 1; i <= dir.size(); i++)
+            if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0777);
+        if (!write_bmp_gray(path, img.data(), PWs, PHs)) return fail(SL3D_E_INVALID_ARG, "cannot write " + path);
+        return true;
+    };
+    for (int axis = 0; axis < 2; axis++) {
+        const std::string ax = axis_dir(axis);
+        const int N = axis == 0 ? number_of_patterns_binary_vertical : number_of_patterns_binary_horizontal;
+        for (int i = 0; i < number_of_patterns_fringe; i++)  // :419-431
+            if (!emit(SL3D_PATTERN_FRINGE, axis, i, "Fringe_patterns/" + ax + "/Pattern_" + std::to_string(i) + ".bmp")) return;
+        for (int j = 0; j < N + 1; j++) {  // :433-465: one image more than there are bit planes
+            if (!emit(SL3D_PATTERN_BINARY, axis, j, "Coded_patterns/Binary_coded/" + ax + "/Pattern_" + std::to_string(j) + ".bmp")) return;
+            if (!emit(SL3D_PATTERN_GRAY, axis, j, "Coded_patterns/Gray_coded/" + ax + "/Pattern_" + std::to_string(j) + ".bmp")) return;
+            if (!emit(SL3D_PATTERN_INVERSE_GRAY, axis, j, "Coded_patterns/Gray_coded/" + ax + "/inverse_Pattern_" + std::to_string(j) + ".bmp")) return;
+        }
+    }
 }
 
 // ---- stage 3 ----------------------------------------------------------------------------------------

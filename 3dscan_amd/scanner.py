@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SL3D_LIB") or os.path.join(_HERE, "libsl3d.so")
 
 SL3D_FLAG_KEEP_STAGES = 1
 AXIS_VERTICAL, AXIS_HORIZONTAL = 0, 1
+PATTERN_FRINGE, PATTERN_GRAY, PATTERN_INVERSE_GRAY, PATTERN_BINARY = 0, 1, 2, 3
 VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
 
 # every symbol include/sl3d.h declares (tests check the library exports all of them)
@@ -23,7 +24,8 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_compact", "sl3d_register_views", "sl3d_get_device_buffers",
+    "sl3d_get_cloud", "sl3d_compact", "sl3d_register_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
+    "sl3d_get_device_buffers",
 )
 
 
@@ -94,10 +96,22 @@ def load_library(path=None):
     L.sl3d_get_cloud.argtypes = [vp, i, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_compact.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.sl3d_register_views.argtypes = [vp, i, i, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sl3d_pattern_counts.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
+    L.sl3d_generate_pattern.argtypes = [vp, i, i, i, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
     if path is None:
         _lib = L
     return L
+
+
+def pattern_counts(proj_extent, fringe_width):
+    """(number of codes, number of bit planes) of 1/pattern_generator.cpp:224-229."""
+    L = load_library()
+    nc, npl = C.c_int(), C.c_int()
+    rc = L.sl3d_pattern_counts(proj_extent, fringe_width, C.byref(nc), C.byref(npl))
+    if rc != 0:
+        raise Sl3dError("sl3d_pattern_counts: " + L.sl3d_strerror(rc).decode())
+    return nc.value, npl.value
 
 
 class Scanner:
@@ -264,6 +278,12 @@ class Scanner:
         out = np.empty((n.value, 3), dtype=np.float32)
         self._chk(self.L.sl3d_register_views(self._h, first_view, n_views, tx, ty, tz, rot_step, out.ctypes.data, n.value, C.byref(n)),
                   "sl3d_register_views")
+        return out
+
+    def generate_pattern(self, kind, axis, index):
+        """One projector pattern of generate_pattern() (1/pattern_generator.cpp): (proj_height, proj_width) uint8."""
+        out = np.empty((self.cfg.proj_height, self.cfg.proj_width), dtype=np.uint8)
+        self._chk(self.L.sl3d_generate_pattern(self._h, kind, axis, index, out.ctypes.data, out.strides[0], None, None), "sl3d_generate_pattern")
         return out
 
     def device_buffers(self):

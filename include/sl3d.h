@@ -204,6 +204,24 @@ int sl3d_compact(sl3d_ctx *ctx, int view, const float **device_xyz, int64_t *cou
 int sl3d_register_views(sl3d_ctx *ctx, int first_view, int n_views, float tx, float ty, float tz, float rot_step,
                         float *xyz, int64_t capacity, int64_t *total);
 
+/* ---- projector patterns (1/pattern_generator.cpp) ------------------------------------------- */
+/* allocate_memory() 1/pattern_generator.cpp:224-229: number of codes = ceil(extent / fringe_width) and number of
+ * Gray / binary bit planes = ceil(logf(codes) / logf(2)) (float arithmetic, as the reference writes it). Host only. */
+int sl3d_pattern_counts(int proj_extent, int fringe_width, int *n_codes, int *n_planes);
+
+#define SL3D_PATTERN_FRINGE 0        /* fringe_pattern_generate_3/_4/_5   :291-383  (index = phase step 0..F-1) */
+#define SL3D_PATTERN_GRAY 1          /* generate_gray_coded_patterns      :56-197   (index = bit plane, MSB first) */
+#define SL3D_PATTERN_INVERSE_GRAY 2  /* generate_inverse_gray_coded_patterns :490-507 */
+#define SL3D_PATTERN_BINARY 3        /* binary_pattern_generate           :386-412 */
+
+/* One projector pattern of generate_pattern() (1/pattern_generator.cpp:513), proj_width x proj_height 8-bit, generated
+ * on the device from the context's configuration (n_fringe, fringe widths, n_gray_v / n_gray_h bit planes).
+ * axis: SL3D_AXIS_VERTICAL = the pattern varies with the column.  index == n_gray (the extra image the reference
+ * saves, :433-465, and never fills) is all zeros.  host_dst (may be NULL) receives the image, `stride` bytes per row;
+ * device_ptr / device_pitch (may be NULL) return the HBM copy, valid until the next call on this context. */
+int sl3d_generate_pattern(sl3d_ctx *ctx, int kind, int axis, int index, uint8_t *host_dst, size_t stride,
+                          const uint8_t **device_ptr, size_t *device_pitch);
+
 /* ---- device-resident access ---------------------------------------------------------------- */
 int sl3d_get_device_buffers(sl3d_ctx *ctx, sl3d_device_buffers *out);
 /* normalise a mask written directly into the device buffer to 0/1 bytes is the caller's duty */

@@ -48,7 +48,9 @@ extern float (*unwrapped_phi_vertical)[Camera_imageheight];
 extern float (*unwrapped_phi_horizontal)[Camera_imageheight];
 extern double (*intersection_points)[Camera_imageheight][3];
 
-/* ---- the four entry points (C++ linkage, as in the reference) ---- */
+/* ---- the entry points (C++ linkage, as in the reference) ---- */
+void generate_pattern();                      /* 1/pattern_generator.cpp:513; the scanf answers come from number_of_patterns_fringe
+                                                 and fringe_width_pixels_*; files go to <data root>/Generated_patterns/... */
 void compute_wrapped_phase(int pattern_type); /* 3/wrapped_phase.cpp:402 */
 void unwrap_phase(int pattern_type);          /* 4/phase_unwrap.cpp:367 (declared int at intermodule_dependencies.h:13, defined void) */
 void compute_c_p_map();                       /* 5/compute_correspondance.cpp:630 */

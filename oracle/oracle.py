@@ -54,6 +54,9 @@ def _load():
         L.orc_get_projection_matrices.argtypes = [vp, vp, vp]
         L.orc_get_undist_point.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.orc_run_scan.argtypes = [vp, vp, vp, C.c_size_t]
+        L.orc_pattern_counts.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_pattern_profile.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_pattern_image.argtypes = [C.c_int] * 8 + [vp]
         L.orc_register_point_clouds.argtypes = [C.c_uint, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
         _lib = L
     return _lib
@@ -182,6 +185,32 @@ class Oracle:
         out = np.empty((n, 3), dtype=np.float32)
         L.orc_save_point_cloud(self._s, out.ctypes.data, n)
         return out
+
+
+def pattern_counts(proj_extent, fringe_width):
+    """1/pattern_generator.cpp:224-229 -> (number of codes, number of bit planes)."""
+    L = _load()
+    nc, npl = C.c_int(), C.c_int()
+    L.orc_pattern_counts(int(proj_extent), int(fringe_width), C.byref(nc), C.byref(npl))
+    return nc.value, npl.value
+
+
+PATTERN_FRINGE, PATTERN_GRAY, PATTERN_INVERSE_GRAY, PATTERN_BINARY = 0, 1, 2, 3
+
+
+def pattern_profile(kind, index, extent, fringe_width, nplanes, F=3):
+    """The values of a projector pattern along its varying axis (1/pattern_generator.cpp; see orc_pattern_profile)."""
+    L = _load()
+    out = np.zeros(extent, dtype=np.uint8)
+    L.orc_pattern_profile(int(kind), int(F), int(index), int(extent), int(fringe_width), int(nplanes), out.ctypes.data)
+    return out
+
+
+def pattern_image(kind, axis, index, PW, PH, fringe_width, nplanes, F=3):
+    L = _load()
+    out = np.zeros((PH, PW), dtype=np.uint8)
+    L.orc_pattern_image(int(kind), int(axis), int(F), int(index), int(PW), int(PH), int(fringe_width), int(nplanes), out.ctypes.data)
+    return out
 
 
 def register_point_clouds(clouds, tx, ty, tz, rot_step):

@@ -18,6 +18,8 @@
  *                              reference tree (un-vendored dependency, opencv 2.4.0 per
  *                              M_tech_project_console.cbp:55-58); they are restated here from
  *                              their published algorithms.
+ *   N1 pattern generator     : PINNED  by Generated_patterns/... (every pixel of the 1280x720 fringe, Gray,
+ *                              inverse-Gray and binary-coded pattern images)
  *   (tests/golden/make_golden.py replays the two pinned stages on the full
  *    1600x1200 captures and writes the committed crops under tests/golden/.)
  *
@@ -687,6 +689,78 @@ void orc_register_point_clouds(unsigned num_point_clouds, const float *const *cl
         theta += rot_step; /* :145 */
         prev_last_point_id += counts[i];
     }
+}
+
+/* ------------------------------------------------------------------------- */
+/* N1: projector pattern generator, 1/pattern_generator.cpp                  */
+/* PINNED by the reference's own pattern images                              */
+/* M_tech_project_console/Generated_patterns/... (1280x720, 3 fringes,       */
+/* fringe width 32 on both axes): tests/golden/make_golden.py requires every  */
+/* pixel of every fringe / Gray / inverse-Gray / binary pattern to be equal.  */
+/* ------------------------------------------------------------------------- */
+/* allocate_memory(), :224-229: number of codes and of bit planes from the fringe width (float log, as written) */
+void orc_pattern_counts(int proj_extent, int fringe_width, int *ncodes, int *nplanes)
+{
+    *ncodes = (int)ceil((float)proj_extent / (float)fringe_width);
+    *nplanes = (int)ceil((logf((float)*ncodes) / logf(2.0)));
+}
+
+/* One pattern is constant along the other axis (vertical patterns vary with the column, horizontal ones with the
+   row): orc_pattern_profile writes the `extent` values along the varying axis.
+   kind 0: fringe k of F (fringe_pattern_generate_3/_4/_5, :291-383)    kind 1: Gray bit plane (:56-197)
+   kind 2: inverse Gray (:490-507)   kind 3: binary-coded (give_code_bit :264-283, binary_pattern_generate :386-412)
+   index == nplanes (the extra image save_pattern_images writes, :433-465) is never filled by the reference: zeros.
+   The vertical and horizontal loops of the reference use the same expressions with (col, fw_v) / (row, fw_h). */
+void orc_pattern_profile(int kind, int F, int index, int extent, int fringe_width, int nplanes, unsigned char *out)
+{
+    memset(out, 0, (size_t)extent);
+    if (kind == 0) {
+        for (int p = 0; p < extent; p++) {
+            float t = 0.0;
+            if (F == 3) /* :302 / :313 */
+                t = 127.0f + 128.0f * cosf(((float)p / (float)fringe_width) * 2.0 * Pi - Pi - ((Pi) / 2.0) + (Pi / 2.0) * (float)index);
+            else if (F == 4) /* :340 / :349 */
+                t = 127.0 + 128.0 * cosf(((float)p / (float)fringe_width) * (2.0 * Pi) - Pi + (Pi / 2.0) * (float)index);
+            else if (F == 5) /* :369 / :378 */
+                t = 127.0f + 128.0f * cosf(((float)p / (float)fringe_width) * (2.0 * Pi) - Pi - 2.0 * ((Pi) / 2) + ((Pi) / 2) * (float)index);
+            out[p] = (unsigned char)(int)t; /* (unsigned char)t of a float in [-1, 255]: x86 converts through int, -1 -> 255 */
+        }
+        return;
+    }
+    if (index >= nplanes) return;
+    if (kind == 1 || kind == 2) {
+        for (int c = 0, code_number = 0; c < extent; c += fringe_width, code_number++) {
+            /* B: binary digits of the code, MSB first (:83-89); G_0 = B_0, G_i = B_{i-1} != B_i (:95-101) */
+            unsigned temp = (unsigned)code_number;
+            int B_prev = 0, B_cur = 0;
+            for (int i = nplanes - 1; i >= 0; i--) {
+                if (i == index) B_cur = (temp % 2) ? 1 : 0;
+                if (i == index - 1) B_prev = (temp % 2) ? 1 : 0;
+                temp /= 2;
+            }
+            const int G = index == 0 ? B_cur : ((B_prev != B_cur) ? 1 : 0);
+            for (int offset = 0; offset < fringe_width && c + offset < extent; offset++)
+                out[c + offset] = kind == 1 ? (unsigned char)(G * 255) : (unsigned char)(255 - (unsigned char)(G * 255));
+        }
+        return;
+    }
+    if (kind == 3) {
+        for (int p = 0; p < extent; p++) {
+            int t = (int)(p / (pow(2, index) * fringe_width)); /* :275-279 */
+            out[p] = (t % 2) == 1 ? 255 : 0;
+        }
+    }
+}
+
+/* the full image: `axis` 0 = vertical pattern (varies with the column), 1 = horizontal (varies with the row) */
+void orc_pattern_image(int kind, int axis, int F, int index, int PW, int PH, int fringe_width, int nplanes, unsigned char *out /* [PH][PW] */)
+{
+    const int extent = axis == 0 ? PW : PH;
+    unsigned char *prof = (unsigned char *)malloc((size_t)extent);
+    orc_pattern_profile(kind, F, index, extent, fringe_width, nplanes, prof);
+    for (int r = 0; r < PH; r++)
+        for (int c = 0; c < PW; c++) out[(size_t)r * PW + c] = prof[axis == 0 ? c : r];
+    free(prof);
 }
 
 /* One whole scan in main()'s order, m_tech_project_console.cpp:366-395:

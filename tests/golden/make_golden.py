@@ -14,6 +14,9 @@ What it does
     (unpinned stages: these outputs are regression goldens, not reference answers).
  4. Writes small crops (inputs + expected outputs) to tests/golden/*.npz and the calibration
     to tests/golden/calibration.json.  Only derived data is written: no reference source.
+ 5. PINS THE PATTERN GENERATOR (N1): the oracle's fringe / Gray / inverse-Gray / binary patterns must equal the 45
+    pattern images the reference generated (Generated_patterns/**) on every pixel; their 1-D profiles go to
+    tests/golden/patterns_ref.npz  (`python tests/golden/make_golden.py patterns` runs this step alone).
 """
 import json
 import os
@@ -181,5 +184,53 @@ def main():
     print("golden fixtures written to", HERE)
 
 
+def patterns():
+    """N1: pins the oracle's pattern generator on the reference's own pattern images
+    (M_tech_project_console/Generated_patterns, written by 1/pattern_generator.cpp:414-470 for 1280x720, 3 fringe
+    patterns, fringe width 32 on both axes) and writes tests/golden/patterns_ref.npz: every pattern is constant along
+    one axis (checked here), so its 1-D profile is the whole image; plus the 1078-byte BMP header + palette the
+    reference's cvSaveImage wrote and the SHA-256 of every file (the shim's generate_pattern() reproduces the files)."""
+    import hashlib
+    from oracle import oracle as O
+    root = REF + "Generated_patterns/"
+    fw, F = FW, 3
+    out = {"config": np.array([PW, PH, F, fw, fw])}
+    names, hashes = [], []
+    header = None
+    n_files = 0
+    for axis, ax_name, extent in ((0, "Vertical", PW), (1, "Horizontal", PH)):
+        ncodes, nplanes = O.pattern_counts(extent, fw)
+        assert (ncodes, nplanes) == ((NCODES_V, N_V) if axis == 0 else (NCODES_H, N_H))
+        for kind, key, fmt, count in ((O.PATTERN_FRINGE, "fringe", "Fringe_patterns/%s/Pattern_%d.bmp", F),
+                                      (O.PATTERN_GRAY, "gray", "Coded_patterns/Gray_coded/%s/Pattern_%d.bmp", nplanes + 1),
+                                      (O.PATTERN_INVERSE_GRAY, "inverse", "Coded_patterns/Gray_coded/%s/inverse_Pattern_%d.bmp", nplanes + 1),
+                                      (O.PATTERN_BINARY, "binary", "Coded_patterns/Binary_coded/%s/Pattern_%d.bmp", nplanes + 1)):
+            for i in range(count):
+                rel = fmt % (ax_name, i)
+                raw = open(root + rel, "rb").read()
+                im = Image.open(root + rel)
+                assert im.mode == "L" and im.size == (PW, PH), (rel, im.mode, im.size)
+                kat = np.array(im)
+                prof = kat[0, :] if axis == 0 else kat[:, 0]
+                assert np.array_equal(kat, np.broadcast_to(prof[None, :] if axis == 0 else prof[:, None], kat.shape)), rel
+                got = O.pattern_image(kind, axis, i, PW, PH, fw, nplanes, F)
+                assert np.array_equal(got, kat), f"oracle pattern differs from the reference's {rel}: {(got != kat).sum()} px"
+                out[f"{key}_{'vh'[axis]}_{i}"] = prof.copy()
+                names.append(rel)
+                hashes.append(hashlib.sha256(raw).hexdigest())
+                header = raw[:1078] if header is None else header
+                assert raw[:1078] == header and len(raw) == 1078 + PW * PH
+                n_files += 1
+    out["bmp_header"] = np.frombuffer(header, dtype=np.uint8)
+    out["file_names"] = np.array(names)
+    out["file_sha256"] = np.array(hashes)
+    np.savez_compressed(os.path.join(HERE, "patterns_ref.npz"), **out)
+    print(f"pattern generator pinned on {n_files} reference images (every pixel equal); patterns_ref.npz written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "patterns":
+        patterns()
+    else:
+        main()
+        patterns()

@@ -2,6 +2,7 @@
 // and selected_region, calls the four stage functions in main()'s order through the drop-in shim, and dumps
 // the reference-layout global arrays to a binary file for the Python test to compare with the oracle.
 //   shim_driver <data_root> <out.bin> Nv Nh fwv fwh ncv nch
+//   shim_driver patterns <data_root> F fwv fwh      : generate_pattern() only (1/pattern_generator.cpp:513); prints the counts
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -11,6 +12,16 @@
 
 int main(int argc, char **argv)
 {
+    if (argc >= 6 && std::string(argv[1]) == "patterns") {
+        sl3d_shim_set_data_root(argv[2]);
+        number_of_patterns_fringe = atoi(argv[3]);
+        fringe_width_pixels_vertical = atoi(argv[4]);
+        fringe_width_pixels_horizontal = atoi(argv[5]);
+        generate_pattern();
+        if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 20; }
+        printf("%d %d %d %d\n", number_of_codes_vertical, number_of_patterns_binary_vertical, number_of_codes_horizontal, number_of_patterns_binary_horizontal);
+        return 0;
+    }
     if (argc < 9) return 2;
     sl3d_shim_set_data_root(argv[1]);
     sl3d_shim_write_debug_images(1);

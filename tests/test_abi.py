@@ -61,3 +61,13 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "sl3d_kernels.hip" and "tests/test_oracle.py" in txt, f
+
+
+def test_pattern_counts_host_function():
+    """sl3d_pattern_counts is host-only (no GPU needed): equal to the oracle's restatement of allocate_memory()'s float
+    arithmetic, including the exact powers of two where logf/logf decides the count."""
+    from oracle import oracle as O
+    scm = pkg("scanner")
+    for extent in (1, 2, 255, 256, 257, 720, 1024, 1280, 1920, 4096, 8192):
+        for fw in (1, 2, 3, 4, 8, 32, 100):
+            assert scm.pattern_counts(extent, fw) == O.pattern_counts(extent, fw), (extent, fw)

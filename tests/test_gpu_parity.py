@@ -398,3 +398,36 @@ def test_device_synthetic_capture():
         assert np.array_equal(sc.valid_map(2) == 1, v)
         assert np.array_equal(sc.c_p_map()[v], o.c_p_map()[v])
         assert_points_close(sc.points()[0], o.intersection_points(), v)
+
+
+def test_projector_patterns_match_oracle_and_reference():
+    """N1: sl3d_generate_pattern against the oracle (pinned on the reference's pattern images) -- the reference's own
+    configuration against the committed profiles of those images, then other sizes / fringe counts / widths, including
+    widths that do not divide the extent and a projector width that is not a multiple of 16."""
+    import os
+    from conftest import ROOT
+    from oracle import oracle as O
+    S = _scanner()
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "patterns_ref.npz"))
+    PWr, PHr, F, fwv, fwh = (int(v) for v in fx["config"])
+    with S.Scanner(64, 48, PWr, PHr, 6, 5, fwv, fwh, n_fringe=F) as sc:
+        for axis in (0, 1):
+            N = 6 if axis == 0 else 5
+            for kind, key, count in ((S.PATTERN_FRINGE, "fringe", F), (S.PATTERN_GRAY, "gray", N + 1),
+                                     (S.PATTERN_INVERSE_GRAY, "inverse", N + 1), (S.PATTERN_BINARY, "binary", N + 1)):
+                for i in range(count):
+                    prof = fx[f"{key}_{'vh'[axis]}_{i}"]
+                    ref = np.broadcast_to(prof[None, :] if axis == 0 else prof[:, None], (PHr, PWr))
+                    assert np.array_equal(sc.generate_pattern(kind, axis, i), ref), (key, axis, i)
+        with pytest.raises(S.Sl3dError):
+            sc.generate_pattern(S.PATTERN_GRAY, 0, 8)
+        with pytest.raises(S.Sl3dError):
+            sc.generate_pattern(S.PATTERN_FRINGE, 0, 3)
+    for PW, PH, Fx, fw_v, fw_h in ((1920, 1080, 3, 2, 2), (1000, 700, 4, 7, 5), (1366, 768, 5, 3, 16)):
+        (_, Nv), (_, Nh) = S.pattern_counts(PW, fw_v), S.pattern_counts(PH, fw_h)
+        with S.Scanner(64, 48, PW, PH, Nv, Nh, fw_v, fw_h, n_fringe=Fx) as sc:
+            for axis, N, fw in ((0, Nv, fw_v), (1, Nh, fw_h)):
+                for kind, count in ((S.PATTERN_FRINGE, Fx), (S.PATTERN_GRAY, N + 1), (S.PATTERN_INVERSE_GRAY, N + 1), (S.PATTERN_BINARY, N + 1)):
+                    for i in sorted({0, 1, count // 2, count - 2, count - 1}):
+                        if 0 <= i < count:
+                            assert np.array_equal(sc.generate_pattern(kind, axis, i), O.pattern_image(kind, axis, i, PW, PH, fw, N, Fx)), (PW, kind, axis, i)

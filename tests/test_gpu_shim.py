@@ -107,3 +107,29 @@ def test_shim_matches_oracle(tmp_path):
         assert np.array_equal(d3, o.debug_image(3, a))
     d4 = np.array(Image.open(f"{root}/Unwrapped_phase_images/Gray_coded/Vertical/Unwrapped_phase_vertical.bmp"))
     assert np.array_equal(d4, o.debug_image(4, 0))
+
+
+def test_shim_generate_pattern_reproduces_reference_files(tmp_path):
+    """generate_pattern() through the shim at the reference's own configuration (1280x720 projector, 3 fringe patterns,
+    fringe width 32): every file it writes is byte-for-byte the file the reference wrote (SHA-256 of the 45 pattern
+    images in M_tech_project_console/Generated_patterns, recorded by tests/golden/make_golden.py)."""
+    import hashlib
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "patterns_ref.npz"))
+    PWr, PHr, F, fwv, fwh = (int(v) for v in fx["config"])
+    root = str(tmp_path)
+    exe = f"{root}/shim_driver"
+    csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
+    defs = [f"-DProjector_imagewidth={PWr}", f"-DProjector_imageheight={PHr}", "-DCamera_imagewidth=64", "-DCamera_imageheight=48"]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *defs, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "shim_driver.cpp"), os.path.join(csrc, "sl3d_shim.cpp"),
+                           os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"), "-lsl3d",
+                           "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
+    r = subprocess.run([exe, "patterns", root, str(F), str(fwv), str(fwh)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.split()[-4:] == ["40", "6", "23", "5"]  # the counts allocate_memory() derives (common_variables.h:6-9,23-24)
+    names, hashes = list(fx["file_names"]), list(fx["file_sha256"])
+    assert len(names) == 45
+    for rel, h in zip(names, hashes):
+        raw = open(f"{root}/Generated_patterns/{rel}", "rb").read()
+        assert raw[:1078] == fx["bmp_header"].tobytes(), rel
+        assert hashlib.sha256(raw).hexdigest() == h, rel

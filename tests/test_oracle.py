@@ -192,3 +192,51 @@ def test_registration_oracle_matches_numpy():
         theta = np.float32(theta + step)
     assert np.allclose(out, np.concatenate(parts), rtol=1e-6, atol=1e-5)
     assert out.shape == (318, 3)
+
+
+# ---- N1: projector pattern generator (1/pattern_generator.cpp), pinned by the reference's own pattern images -------
+def _pattern_fixture():
+    import os
+    from conftest import ROOT
+    return np.load(os.path.join(ROOT, "tests", "golden", "patterns_ref.npz"))
+
+
+def test_pattern_generator_matches_reference_images():
+    """The 1-D profiles of the 45 pattern images the reference generated (1280x720, F=3, fringe width 32; each image
+    is that profile replicated along the other axis: make_golden.py checks it on every pixel)."""
+    from oracle import oracle as O
+    fx = _pattern_fixture()
+    PW, PH, F, fwv, fwh = (int(v) for v in fx["config"])
+    n = 0
+    for axis, extent, fw in ((0, PW, fwv), (1, PH, fwh)):
+        ncodes, nplanes = O.pattern_counts(extent, fw)
+        assert (ncodes, nplanes) == ((40, 6) if axis == 0 else (23, 5))  # common_variables.h:6-9,23-24
+        for kind, key, count in ((O.PATTERN_FRINGE, "fringe", F), (O.PATTERN_GRAY, "gray", nplanes + 1),
+                                 (O.PATTERN_INVERSE_GRAY, "inverse", nplanes + 1), (O.PATTERN_BINARY, "binary", nplanes + 1)):
+            for i in range(count):
+                ref = fx[f"{key}_{'vh'[axis]}_{i}"]
+                assert np.array_equal(O.pattern_profile(kind, i, extent, fw, nplanes, F), ref), (key, axis, i)
+                n += 1
+    assert n == 45
+    img = O.pattern_image(O.PATTERN_GRAY, 1, 2, PW, PH, fwh, 5, F)
+    assert np.array_equal(img, np.broadcast_to(fx["gray_h_2"][:, None], (PH, PW)))
+
+
+def test_pattern_gray_code_properties():
+    """Size-independent properties: consecutive codes differ in exactly one Gray bit, the Gray -> binary decode of
+    stage 4 (running xor, MSB first) returns column // fringe_width, inverse = 255 - pattern."""
+    from oracle import oracle as O
+    for extent, fw in ((1920, 2), (1280, 32), (1000, 7), (4096, 4)):
+        ncodes, N = O.pattern_counts(extent, fw)
+        assert ncodes == -(-extent // fw) and (1 << N) >= ncodes
+        planes = np.stack([O.pattern_profile(O.PATTERN_GRAY, i, extent, fw, N) for i in range(N)]) // 255
+        inv = np.stack([O.pattern_profile(O.PATTERN_INVERSE_GRAY, i, extent, fw, N) for i in range(N)])
+        assert np.array_equal(inv, 255 - planes * 255)
+        b = np.zeros(extent, dtype=np.int64)
+        code = np.zeros(extent, dtype=np.int64)
+        for i in range(N):
+            b ^= planes[i]
+            code = code * 2 + b
+        assert np.array_equal(code, np.arange(extent) // fw)
+        per_code = planes[:, ::fw]
+        assert np.all(np.abs(np.diff(per_code.astype(int), axis=1)).sum(axis=0) == 1)
