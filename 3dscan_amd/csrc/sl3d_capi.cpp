@@ -27,6 +27,7 @@ struct sl3d_ctx {
     DevCal C{};
     SynthParams S{};  // extrinsics kept for the synthetic-capture generator
     bool have_cal = false;
+    int rig = 0;
     bool keep = false;
     bool own_stream = false;
     hipStream_t stream = nullptr;
@@ -40,6 +41,7 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    float2 *d_proj_disp = nullptr;            // RIG 2: projector undistortion table (allocated when a distorted projector is set)
     uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
     size_t pattern_pitch = 0;
     DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
@@ -351,6 +353,20 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     HIPCHK(x, hipSetDevice(x->cfg.device));
     HIPCHK(x, hipStreamSynchronize(x->stream));  // no launch may still be reading the previous constants
     HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
+    // rig class of the timed fused kernel (pixel_chain): 1 = the reference's kind of calibration, 2 = distorted projector
+    // behind a per-calibration undistortion table, 0 = everything else, evaluated in the kernel
+    x->rig = !x->C.cam.plain ? 0 : x->C.proj.identity ? 1 : 2;
+    x->P.proj_disp = nullptr;
+    if (x->rig == 2) {
+        if (!x->d_proj_disp) {
+            HIPCHK(x, hipMalloc((void **)&x->d_proj_disp, (size_t)x->cfg.proj_width * x->cfg.proj_height * sizeof(float2)));
+            x->allocs.push_back(x->d_proj_disp);
+        }
+        const int rc = launch_proj_table(x->d_cal, x->cfg.proj_width, x->cfg.proj_height, x->d_proj_disp, x->stream);
+        if (rc) return fail(x, SL3D_E_HIP, std::string("k_proj_table: ") + hipGetErrorString((hipError_t)rc));
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+        x->P.proj_disp = x->d_proj_disp;
+    }
     x->have_cal = true;
     return SL3D_OK;
 }
@@ -542,7 +558,7 @@ extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
-    return launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0 && x->C.cam.plain != 0, first_view, n_views, x->keep, x->stream));
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, x->stream));
 }
 
 extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
@@ -552,7 +568,7 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     HIPCHK(x, hipSetDevice(x->cfg.device));
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
-    rc = launched(x, launch_fused(x->P, x->d_cal, x->C.proj.identity != 0 && x->C.cam.plain != 0, first_view, n_views, x->keep, x->stream));
+    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, x->stream));
     if (rc) return rc;
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));

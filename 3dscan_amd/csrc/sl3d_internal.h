@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <hip/hip_vector_types.h>  // float2
+
 #define SL3D_MASK_HALO 2        // rows / columns of selection mask kept around the window
 #define SL3D_MASK_LPAD 16       // bytes in front of window column 0 in every mask row
 #define SL3D_ATAN_T1 511        // t1 = I0 - I2        in [-255, 255]
@@ -67,6 +69,7 @@ struct KParams {
     const uint8_t *frames;
     const uint8_t *mask;       // 0/1 bytes, halo included
     const uint8_t *band;       // [view][row][pitch]: final valid bytes of the quads within 3 px of the frame border (set_mask)
+    const float2 *proj_disp;   // [PH][PW] undistorted-minus-raw projector point (set_calibration; NULL unless the projector is distorted)
     // dense results
     float *points;             // [view][row][pitch][3] f32
     uint8_t *valid;            // [view][row][pitch]    merged valid map
@@ -83,7 +86,8 @@ struct KParams {
 };
 
 // launchers (sl3d_kernels.hip); `stream` is a hipStream_t
-int launch_fused(const KParams &P, const DevCal *d_cal, bool fast_rig, int first_view, int n_views, bool keep, void *stream);
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, void *stream);
+int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);
 int launch_corr(const KParams &P, int view, void *stream);

@@ -502,7 +502,15 @@ struct PixelResult {
     bool valid;
 };
 
-template <bool KEEP, bool PID, typename CalP>
+// RIG (stage 7 of the timed fused kernel, chosen by launch_fused from the calibration):
+//   0  general: any K, any distortion, everything evaluated in the kernel with the reference's operation order
+//      (also what the parity mode and the per-stage kernels run)
+//   1  camera K plain, projector without distortion and with a plain K (the reference's own calibration): camera-frame
+//      least squares, the projector point is the correspondence itself
+//   2  camera K plain, projector distorted: camera-frame least squares; the undistorted projector point comes from the
+//      per-calibration table KParams::proj_disp (one float2 displacement per projector pixel, built by k_proj_table with
+//      the same 5-iteration undistortion) -- the reference also tabulates it (7/triangulation.cpp:363-378), per scan
+template <bool KEEP, int RIG, typename CalP>
 __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, const PinnedRows &PR, int gx, int gy, double cu, double cv,
                                                    float wv, float wh, int code_v, int code_h, size_t keep_off)
 {
@@ -545,11 +553,15 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
         double up, vp, X[3];
         bool singular = false;
         const auto &C = *Cp;
-        if (PID) {
-            // fast rig (no projector distortion, plain K for both devices; the reference's own calibration is one):
+        if (RIG == 1) {
             // the projector's undistort + re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px),
             // and (cu,cv) are the camera's undistorted NORMALISED coordinates for the camera-frame solve
             triangulate_camframe(C, PR, cu, cv, cxd, cyd, X, singular);
+        } else if (RIG == 2) {
+            // neighbouring camera pixels see neighbouring projector pixels: the gather stays within a few cache lines
+            // per wave (cx, cy are 0 for a rejected pixel, whose result is discarded)
+            const float2 d = P.proj_disp[(size_t)(int)cy * (size_t)P.PW + (size_t)(int)cx];
+            triangulate_camframe(C, PR, cu, cv, cxd + (double)d.x, cyd + (double)d.y, X, singular);
         } else {
             if (C.proj.identity) {
                 up = cxd;
@@ -562,7 +574,7 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
         R.x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
         R.y = (float)X[1];
         R.z = (float)X[2];
-        if (PID && singular) R.x = R.y = R.z = 0.0f;  // cvInvert's zero matrix: V = 0
+        if (RIG != 0 && singular) R.x = R.y = R.z = 0.0f;  // cvInvert's zero matrix: V = 0
         if (KEEP) {
             P.ipoints[3 * keep_off + 0] = X[0];
             P.ipoints[3 * keep_off + 1] = X[1];
@@ -587,7 +599,7 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 // through LDS so they leave as three 16-B stores per lane (a wave writes 3 KiB contiguous).
 //
 // FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
-template <bool KEEP, int NMAX, bool FGEN, bool EXACT, bool PID>
+template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG>
 __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     for (int k = 0; k < 4; k++) {
         double cu = 0.0, cv = 0.0;
         if (cq * 4 < P.W && !(P.ablate & 4)) {
-            if (PID) undistort_normalized((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);  // camera-frame solve
+            if (RIG != 0) undistort_normalized((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);  // camera-frame solve
             else undistort_reproject((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);
         }
         my_cam[2 * k] = cu;
@@ -625,13 +637,13 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     PinnedRows PR;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        PR.c2[j] = PID ? 0.0 : Cglobal->Ac[8 + j];
-        PR.p2[j] = PID ? Cglobal->Apc[8 + j] : Cglobal->Ap[8 + j];
-        if (!PID) asm volatile("" : "+v"(PR.c2[j]));
+        PR.c2[j] = RIG != 0 ? 0.0 : Cglobal->Ac[8 + j];
+        PR.p2[j] = RIG != 0 ? Cglobal->Apc[8 + j] : Cglobal->Ap[8 + j];
+        if (RIG == 0) asm volatile("" : "+v"(PR.c2[j]));
         asm volatile("" : "+v"(PR.p2[j]));  // stay in VGPRs (see PinnedRows)
         if (j < 3) {
-            PR.t[j] = PID ? Cglobal->tcn[j] : 0.0;
-            if (PID) asm volatile("" : "+v"(PR.t[j]));
+            PR.t[j] = RIG != 0 ? Cglobal->tcn[j] : 0.0;
+            if (RIG != 0) asm volatile("" : "+v"(PR.t[j]));
         }
     }
     // EXACT: both axes have exactly NMAX Gray planes (the usual case): the plane clamps and the per-plane tests fold away
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
         wv = shift_pi(wv);
         wh = shift_pi(wh);
         const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
-        const PixelResult R = pixel_chain<false, PID>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
+        const PixelResult R = pixel_chain<false, RIG>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
         const bool okpx = ((vbits >> i) & 1u) && R.valid;
         ox = okpx ? R.x : nanv;
         oy = okpx ? R.y : nanv;
@@ -824,7 +836,7 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
                         wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                         wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                         const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
-                        const PixelResult R = pixel_chain<true, false>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
+                        const PixelResult R = pixel_chain<true, 0>(P, opaque_const(Cglobal), PR, gx0 + k, gy, cu, cv, wv, wh, code_v, code_h, px + k);
                         if (R.valid) {
                             my_xyz[3 * k + 0] = R.x;
                             my_xyz[3 * k + 1] = R.y;
@@ -841,16 +853,16 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     }
 }
 
-template <bool KEEP, bool FGEN, bool PID>
+template <bool KEEP, bool FGEN, int RIG>
 static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     const int nmax = nv > nh ? nv : nh;
 #define SL3D_LAUNCH(NM)                                                                                                   \
     do {                                                                                                                  \
         if (nv == NM && nh == NM)                                                                                         \
-            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, true, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
+            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, true, RIG>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
         else                                                                                                              \
-            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, false, PID>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
+            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, false, RIG>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
     } while (0)
     if (nmax <= 6) SL3D_LAUNCH(6);
     else if (nmax <= 8) SL3D_LAUNCH(8);
@@ -860,8 +872,8 @@ static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st
 #undef SL3D_LAUNCH
 }
 
-// fast_rig: no projector distortion and a plain K for both devices (host knows; folded at compile time in the timed kernel)
-int launch_fused(const KParams &P, const DevCal *d_cal, bool fast_rig, int first_view, int n_views, bool keep, void *stream)
+// rig: 0 / 1 / 2, see pixel_chain (the host knows the calibration; folded at compile time in the timed 3-step kernel)
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, void *stream)
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = (unsigned)((quads + 255) / 256);
@@ -873,14 +885,16 @@ int launch_fused(const KParams &P, const DevCal *d_cal, bool fast_rig, int first
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(256, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     if (keep) {
-        if (P.F == 3) launch_fused_n<true, false, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<true, true, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (P.F == 3) launch_fused_n<true, false, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<true, true, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (P.F != 3) {
-        launch_fused_n<false, true, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (fast_rig) {
-        launch_fused_n<false, false, true>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        launch_fused_n<false, true, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (rig == 1) {
+        launch_fused_n<false, false, 1>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (rig == 2 && P.proj_disp) {
+        launch_fused_n<false, false, 2>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        launch_fused_n<false, false, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        launch_fused_n<false, false, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
     return (int)hipGetLastError();
 }
@@ -1012,6 +1026,24 @@ __global__ __launch_bounds__(256) void k_tri(const KParams P, const DevCal C, in
     P.points[3 * px + 0] = x;
     P.points[3 * px + 1] = y;
     P.points[3 * px + 2] = z;
+}
+
+// T1 for the projector as a table (RIG 2): displacement of the undistorted + re-projected point from the projector pixel
+// itself, for every projector pixel (7/triangulation.cpp:363-378 builds the same table, per scan).  float2: the
+// displacement is a few tens of pixels, so its float rounding is ~3e-6 px (1e-9 relative in the 3-D point).
+__global__ __launch_bounds__(256) void k_proj_table(const DevCal *__restrict__ C, int PW, int PH, float2 *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= PW) return;
+    double u, v;
+    undistort_reproject((double)x, (double)y, C->proj, u, v);
+    out[(size_t)y * PW + x] = make_float2((float)(u - (double)x), (float)(v - (double)y));
+}
+
+int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream)
+{
+    hipLaunchKernelGGL(k_proj_table, dim3((PW + 255) / 256, PH), dim3(256), 0, (hipStream_t)stream, d_cal, PW, PH, out);
+    return (int)hipGetLastError();
 }
 
 // N1: one projector pattern (1/pattern_generator.cpp).  Every pattern is constant along one axis, so the host evaluates

@@ -208,6 +208,36 @@ def test_projector_distortion_and_skew():
     _run_both(W, H, PW, PH, N, N, fw, fw, cap, cap["mask"])
 
 
+def test_distorted_projector_table_path_and_recalibration():
+    """Plain camera K + distorted projector: the timed kernel takes the projector's undistorted point from the
+    per-calibration table (rig class 2).  Then the same context is re-calibrated to the reference's kind of rig (class 1)
+    and back: the table is rebuilt, results follow the calibration."""
+    syn = pkg("synth")
+    S = _scanner()
+    W, H, PW, PH, N, fw = 320, 200, 512, 384, 7, 4
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw, noise=1)
+    cal_a = {k: np.array(v, dtype=np.float64).copy() for k, v in cap["cal"].items()}
+    cal_a["dp"] = np.array([0.05, -0.02, 0.001, -0.0005, 0.01])
+    cal_a["dc"] = np.array([0.0813, -0.1102, 0.0007, -0.0003, 0.02])
+    cal_b = {k: np.array(v, dtype=np.float64).copy() for k, v in cap["cal"].items()}
+    cal_c = {k: v.copy() for k, v in cal_a.items()}
+    cal_c["dp"] = np.array([-0.08, 0.03, 0.0, 0.0, 0.0])
+    cap_a = dict(cap, cal=cal_a)
+    _run_both(W, H, PW, PH, N, N, fw, fw, cap_a, cap["mask"])
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw) as sc:
+        sc.set_mask(cap["mask"])
+        sc.set_frames(0, cap["planes_v"])
+        sc.set_frames(1, cap["planes_h"])
+        for cal in (cal_a, cal_b, cal_c, cal_a):
+            o = _oracle_for(dict(cap, cal=cal), W, H, PW, PH, N, N, fw, fw, cap["mask"])
+            sc.set_calibration(*syn.cal_tuple(cal))
+            sc.run()
+            xyz, valid = sc.points()
+            v = o.valid_map(2) == 1
+            assert np.array_equal(valid == 1, v)
+            assert_points_close(xyz, o.intersection_points(), v)
+
+
 # ---- size-independent properties at full size --------------------------------------------------------
 def test_12mp_fused_equals_staged_and_row_shards():
     """configs[2] (4096x3000): the oracle would take minutes, so use properties: (a) the fused kernel equals the

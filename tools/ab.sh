@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
     n=$1; f=$2; shift 2
     hipcc $FLAGS $f -shared -o ab/libsl3d_$n.so 3dscan_amd/csrc/sl3d_kernels.hip 3dscan_amd/csrc/sl3d_capi.cpp -Iinclude \
       -Rpass-analysis=kernel-resource-usage 2> ab/$n.res || { echo "build $n failed"; tail -5 ab/$n.res; continue; }
-    echo "$n [$f]: $(grep -A12 'k_fusedILb0ELi10ELb0ELb1ELb1' ab/$n.res | grep -E 'VGPRs:|ScratchSize|Occupancy|SGPRs:' | sed 's/.*remark: [^ ]* *//' | tr '\n' ' ')"
+    echo "$n [$f]: $(grep -A12 'k_fusedILb0ELi10ELb0ELb1ELi1' ab/$n.res | grep -E 'VGPRs:|ScratchSize|Occupancy|SGPRs:' | sed 's/.*remark: [^ ]* *//' | tr '\n' ' ')"
   done
 elif [ "$1" = buildrev ]; then
   # tools/ab.sh buildrev NAME REV [flags] : the library as of git revision REV (baseline for the working tree)

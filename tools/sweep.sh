@@ -9,3 +9,5 @@ run --width 4096 --height 3000 --fringe-width 4 --views 3 --steps 1200 --warmup 
 run --width 8192 --height 768 --ngray 12 --views 8 --steps 1200 --warmup 200
 run --width 1600 --height 1200 --views 16
 run --ngray 8 --fringe-width 8 --views 16
+run --ngray 9 --fringe-width 4 --views 16
+run --rig distorted --views 16
