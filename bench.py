@@ -209,6 +209,19 @@ def main():
         try:
             cap0 = {"planes_v": sc.frames(0, 0), "planes_h": sc.frames(1, 0)}  # the very bytes the GPU processed
             out["cpu_baseline"] = cpu_baseline(args, cap0, cal, valid, xyz, None)
+            # what the C ABI delivers when the boundary hands over HOST buffers (never `value`): upload of the 46 frames of
+            # one view, one launch, download of xyz + valid, pageable numpy memory, median of 5
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                sc.set_frames(0, cap0["planes_v"], view=0)
+                sc.set_frames(1, cap0["planes_h"], view=0)
+                sc.run(0, 1)
+                sc.points(0)
+                ts.append(time.perf_counter() - t0)
+            t = sorted(ts)[2]
+            out["host_buffers_one_view"] = {"value": round(W * rows / t / 1e6, 1), "unit": "Mpixels/s", "ms": round(t * 1e3, 2),
+                                            "note": "H2D of 46 frames + launch + D2H of xyz and valid for ONE view, pageable host memory"}
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"error": repr(e)}
     sc.close()
