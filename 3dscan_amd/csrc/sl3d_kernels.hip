@@ -36,6 +36,14 @@
 #ifndef SL3D_RCP_LDS
 #define SL3D_RCP_LDS 1
 #endif
+// non-temporal hints (tools/ab.sh): the planes are read exactly once by exactly one CU (nt loads: +1.1 %); the results are
+// written once too, but nt stores lose the L2's merging of the three partial-line stores of a wave (-11 %)
+#ifndef SL3D_NT_LOADS
+#define SL3D_NT_LOADS 1
+#endif
+#ifndef SL3D_NT_STORES
+#define SL3D_NT_STORES 0
+#endif
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
@@ -491,6 +499,7 @@ __device__ __forceinline__ unsigned opaque_u32(unsigned v)
 __device__ __forceinline__ unsigned ldg32(const GLOBAL_AS uint8_t *base, unsigned off)
 {
     asm volatile("" : "+s"(base));
+    if (SL3D_NT_LOADS) return __builtin_nontemporal_load((const GLOBAL_AS unsigned *)(base + (size_t)off));
     return *(const GLOBAL_AS unsigned *)(base + (size_t)off);
 }
 
@@ -771,11 +780,21 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
         float4 *out_xyz = (float4 *)(P.points + 3 * px);
         const float4 *sx = (const float4 *)my_xyz;
         if (!(SL3D_ABLATE & 4) || KEEP || sx[0].x == 12345.f) {
-            out_xyz[0] = sx[0];
-            out_xyz[1] = sx[1];
-            out_xyz[2] = sx[2];
+            if (SL3D_NT_STORES && !KEEP) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 *sv = (const f32x4 *)my_xyz;
+                f32x4 *ov = (f32x4 *)out_xyz;
+                __builtin_nontemporal_store(sv[0], ov);
+                __builtin_nontemporal_store(sv[1], ov + 1);
+                __builtin_nontemporal_store(sv[2], ov + 2);
+            } else {
+                out_xyz[0] = sx[0];
+                out_xyz[1] = sx[1];
+                out_xyz[2] = sx[2];
+            }
         }
-        *(unsigned *)(P.valid + px) = vout;
+        if (SL3D_NT_STORES && !KEEP) __builtin_nontemporal_store(vout, (unsigned *)(P.valid + px));
+        else *(unsigned *)(P.valid + px) = vout;
     };
     auto fill_nan = [&]() {
 #pragma unroll
