@@ -44,6 +44,15 @@
 #ifndef SL3D_NT_STORES
 #define SL3D_NT_STORES 0
 #endif
+// 1: XCD-banded tile order.  Workgroups go round-robin to the 8 XCDs (each with its own L2); with the natural order the
+// three tiles that share a mask row (vertical neighbours are 1.9 tiles apart) land on three different L2s, and the mask
+// is what the measured 1.046x traffic over the algorithmic bytes consists of.  With 1, XCD x walks the x-th eighth of
+// the window top to bottom, so vertically adjacent tiles share an L2 -- but HBM then sees 8 distant streams per plane
+// instead of one: measured -4 % (4 x 4000 launches, alternating).  The natural order stays: for a streaming kernel
+// with 2 % of shared bytes, DRAM locality across XCDs is worth more than L2 locality inside one.
+#ifndef SL3D_XCD_BANDS
+#define SL3D_XCD_BANDS 0
+#endif
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
@@ -620,7 +629,9 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     }
     const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    // gridDim.x is a multiple of 8 (launch_fused), so blockIdx.x % 8 is the XCD whatever blockIdx.y is
+    const unsigned tile = SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const long q = (long)tile * 256 + threadIdx.x;
     const int row = (int)(q / qpr), cq = (int)(q - (long)row * qpr);
     if (row >= P.H) return;
     const int gx0 = P.col0 + cq * 4, gy = P.row0 + row;
@@ -897,7 +908,7 @@ static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st
 int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, void *stream)
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
-    const unsigned bx = (unsigned)((quads + 255) / 256);
+    const unsigned bx = ((unsigned)((quads + 255) / 256) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
     // views per lane: as many as possible (amortises the camera undistortion) while the grid still
     // has >= ~8 blocks per CU to balance the tail
     int vpt = 1;
