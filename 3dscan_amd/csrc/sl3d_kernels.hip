@@ -169,6 +169,15 @@ __device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, i
 
 __device__ __forceinline__ unsigned mask_quad_bits(const KParams &P, const MaskQuad &m, int cq, bool interior)
 {
+    // Inside a selected region every one of the 36 bytes is 1 and all 4 pixels are valid: when that holds for the whole
+    // wave (the usual case away from the region's outline) the closed form below is skipped (4 v_bitop3 + a compare
+    // instead of ~45 instructions per quad).  Wave-uniform branch, same result.
+    {
+        const unsigned a = __builtin_amdgcn_bitop3_b32(m.bP, m.bC, m.bN, 0x80), b = __builtin_amdgcn_bitop3_b32(m.cP, m.cC, m.cN, 0x80),
+                       c = __builtin_amdgcn_bitop3_b32(m.dP, m.dC, m.dN, 0x80);
+        const bool all_selected = interior && __builtin_amdgcn_bitop3_b32(a, b, c, 0x80) == 0x01010101u && P.W - cq * 4 >= 4;
+        if (__all(all_selected)) return 0xfu;
+    }
     // X(d): bytes of row X at columns c+k+d, k=0..3
 #define SHL2(Pw, Cw) __builtin_amdgcn_alignbyte(Cw, Pw, 2)
 #define SHL1(Pw, Cw) __builtin_amdgcn_alignbyte(Cw, Pw, 3)
