@@ -41,6 +41,9 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)
+    uint8_t *d_cloud_rgb = nullptr;           // r,g,b of the compacted cloud of one view
+    std::vector<char> have_texture;
     float2 *d_proj_disp = nullptr;            // RIG 2: projector undistortion table (allocated when a distorted projector is set)
     uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
     size_t pattern_pitch = 0;
@@ -683,7 +686,9 @@ extern "C" int sl3d_compact(sl3d_ctx *x, int view, const float **device_xyz, int
     if (rc) return rc;
     if (!count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     HIPCHK(x, hipSetDevice(x->cfg.device));
-    rc = launched(x, launch_compact(x->P, view, x->d_blk_cnt, x->d_blk_off, x->d_total, x->d_cloud, x->stream));
+    const bool tex = x->d_texture && view < (int)x->have_texture.size() && x->have_texture[view];
+    rc = launched(x, launch_compact(x->P, view, x->d_blk_cnt, x->d_blk_off, x->d_total, x->d_cloud,
+                                    tex ? x->d_texture + (size_t)view * x->P.px_view_stride * 3 : nullptr, x->d_cloud_rgb, x->stream));
     if (rc) return rc;
     unsigned long long n = 0;
     HIPCHK(x, hipMemcpyAsync(&n, x->d_total, sizeof n, hipMemcpyDeviceToHost, x->stream));
@@ -703,6 +708,46 @@ extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacit
     const int64_t n = *count < capacity ? *count : capacity;
     if (xyz && n > 0) {
         HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+    }
+    return SL3D_OK;
+}
+
+// the colour image save_point_cloud() takes the r,g,b of every valid pixel from (8/save_point_cloud.cpp:46-52: cvLoadImage
+// of Point_cloud/texture.bmp, split into blue / green / red planes)
+extern "C" int sl3d_set_texture(sl3d_ctx *x, int view, const uint8_t *bgr, size_t stride)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    const KParams &P = x->P;
+    if (!bgr || stride < (size_t)P.W * 3) return fail(x, SL3D_E_INVALID_ARG, "texture: null or stride < 3*width");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    if (!x->d_texture) {
+        rc = dev_alloc(x, &x->d_texture, (size_t)x->cfg.max_views * P.px_view_stride * 3);
+        if (rc) return rc;
+        rc = dev_alloc(x, &x->d_cloud_rgb, P.px_view_stride * 3);
+        if (rc) return rc;
+        x->have_texture.assign((size_t)x->cfg.max_views, 0);
+    }
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    HIPCHK(x, hipMemcpy2D(x->d_texture + (size_t)view * P.px_view_stride * 3, (size_t)P.pitch * 3, bgr, stride, (size_t)P.W * 3, (size_t)P.H,
+                          hipMemcpyHostToDevice));
+    x->have_texture[view] = 1;
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_get_cloud_rgb(sl3d_ctx *x, int view, float *xyz, uint8_t *rgb, int64_t capacity, int64_t *count)
+{
+    if (!x || !count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    if (!x->d_texture || view < 0 || view >= (int)x->have_texture.size() || !x->have_texture[view])
+        return fail(x, SL3D_E_INVALID_ARG, "no texture set for this view (sl3d_set_texture)");
+    const float *dev = nullptr;
+    int rc = sl3d_compact(x, view, &dev, count);
+    if (rc) return rc;
+    const int64_t n = *count < capacity ? *count : capacity;
+    if (n > 0) {
+        if (xyz) HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        if (rgb) HIPCHK(x, hipMemcpyAsync(rgb, x->d_cloud_rgb, (size_t)n * 3, hipMemcpyDeviceToHost, x->stream));
         HIPCHK(x, hipStreamSynchronize(x->stream));
     }
     return SL3D_OK;

@@ -1178,8 +1178,11 @@ __global__ __launch_bounds__(1024) void k_compact_scan(const unsigned *counts, u
     if (threadIdx.x == 1023) *total = s_part[1023];
 }
 
+// texture (may be NULL): the BGR camera image save_point_cloud() colours the cloud with (8/save_point_cloud.cpp:46-52,
+// 70-72), [row][pitch][3] bytes; rgb_out receives r,g,b per compacted point
 __global__ __launch_bounds__(256) void k_compact_scatter(const uint8_t *valid, const float *points, size_t n_px,
-                                                         const unsigned long long *block_offsets, float *cloud)
+                                                         const unsigned long long *block_offsets, float *cloud, const uint8_t *texture,
+                                                         uint8_t *rgb_out)
 {
     __shared__ unsigned s_wave[4];
     const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
@@ -1200,13 +1203,19 @@ __global__ __launch_bounds__(256) void k_compact_scatter(const uint8_t *valid, c
     for (int k = 0; k < 4; k++)
         if ((w >> (8 * k)) & 1u) {
             const float *p = points + 3 * (base + k);
-            float *q = cloud + 3 * dst++;
+            float *q = cloud + 3 * dst;
             q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+            if (texture) {
+                const uint8_t *t = texture + 3 * (base + k);  // b, g, r
+                uint8_t *c = rgb_out + 3 * dst;
+                c[0] = t[2]; c[1] = t[1]; c[2] = t[0];
+            }
+            dst++;
         }
 }
 
 int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned long long *block_offsets, unsigned long long *total,
-                   float *cloud, void *stream)
+                   float *cloud, const uint8_t *texture, uint8_t *rgb_out, void *stream)
 {
     const size_t n_px = P.px_view_stride;
     const int nb = (int)((n_px + 1023) / 1024);
@@ -1215,7 +1224,7 @@ int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, st, valid, n_px, block_counts);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_counts, block_offsets, nb, total);
-    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(256), 0, st, valid, points, n_px, block_offsets, cloud);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(256), 0, st, valid, points, n_px, block_offsets, cloud, texture, rgb_out);
     return (int)hipGetLastError();
 }
 

@@ -96,6 +96,46 @@ bool read_bmp_gray(const std::string &path, std::vector<uint8_t> &out)
     return true;
 }
 
+// B,G,R interleaved, top-down: what cvLoadImage(path) (colour) yields (8/save_point_cloud.cpp:46); 8-bit files go through
+// their palette, 24-bit files are copied
+bool read_bmp_bgr(const std::string &path, std::vector<uint8_t> &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t hdr[54];
+    if (fread(hdr, 1, 54, f) != 54 || hdr[0] != 'B' || hdr[1] != 'M') { fclose(f); return false; }
+    auto u32 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8) | ((uint32_t)hdr[o + 2] << 16) | ((uint32_t)hdr[o + 3] << 24); };
+    const uint32_t data_off = u32(10), dib = u32(14);
+    const int32_t w = (int32_t)u32(18), hgt = (int32_t)u32(22);
+    const int bpp = hdr[28] | (hdr[29] << 8);
+    uint32_t ncolors = u32(46);
+    if (w != W || (hgt != H && hgt != -H) || u32(30) != 0 || (bpp != 8 && bpp != 24)) { fclose(f); return false; }
+    uint8_t pal[256][3];
+    for (int i = 0; i < 256; i++) pal[i][0] = pal[i][1] = pal[i][2] = (uint8_t)i;
+    if (bpp == 8) {
+        if (ncolors == 0) ncolors = 256;
+        fseek(f, 14 + dib, SEEK_SET);
+        for (uint32_t i = 0; i < ncolors && i < 256; i++) {
+            uint8_t q[4];
+            if (fread(q, 1, 4, f) != 4) { fclose(f); return false; }
+            pal[i][0] = q[0]; pal[i][1] = q[1]; pal[i][2] = q[2];
+        }
+    }
+    const size_t rowbytes = (((size_t)w * bpp + 31) / 32) * 4;
+    std::vector<uint8_t> row(rowbytes);
+    out.assign((size_t)W * H * 3, 0);
+    fseek(f, data_off, SEEK_SET);
+    for (int i = 0; i < H; i++) {
+        if (fread(row.data(), 1, rowbytes, f) != rowbytes) { fclose(f); return false; }
+        uint8_t *dst = out.data() + (size_t)(hgt > 0 ? H - 1 - i : i) * W * 3;
+        if (bpp == 24) memcpy(dst, row.data(), (size_t)W * 3);
+        else
+            for (int x = 0; x < W; x++) memcpy(dst + 3 * x, pal[row[x]], 3);
+    }
+    fclose(f);
+    return true;
+}
+
 // 8-bit palettised BMP exactly as the reference's cvSaveImage (OpenCV 2.4 BMP encoder) writes a 1-channel image:
 // 14 + 40 byte headers with biSizeImage = biClrUsed = 0, 256 grey palette entries, bottom-up rows padded to 4 bytes.
 // (tests/test_gpu_shim.py compares whole files with the SHA-256 of the reference's own pattern images.)
@@ -383,4 +423,46 @@ void triangulate()
     if (!ok(sl3d_get_intersection_points(g.ctx, 0, pts.data()), "sl3d_get_intersection_points")) return;
     for (int r = 0; r < H; r++)
         for (int c = 0; c < W; c++) memcpy(intersection_points[c][r], &pts[3 * ((size_t)r * W + c)], 3 * sizeof(double));
+}
+
+// ---- stage 8: save_point_cloud() ------------------------------------------------------------------------
+// 8/save_point_cloud.cpp:19-217: the valid pixels in row-major scan order (:85-104) as float xyz with the r,g,b of
+// Point_cloud/texture.bmp (:46-52,70-72), saved as Point_cloud/point_cloud_<i>.pcd (ASCII) and .ply.  Compaction and
+// colour gather run on the device on the result of the last triangulate().  The reference writes the two files with
+// PCL 1.6 (pcl::io::savePCDFileASCII / savePLYFile); PCL is not available here, so the files are standard PCD v0.7 ASCII
+// (fields x y z rgb, rgb as the packed 0x00RRGGBB integer) and PLY ASCII (x y z red green blue) that PCL, MeshLab and
+// CloudCompare read -- the same points, colours and order, not PCL's exact text (unpinned).
+void save_point_cloud(unsigned cloud_index)
+{
+    g.status = SL3D_OK;
+    if (!g.ctx) { fail(SL3D_E_STATE, "save_point_cloud before triangulate"); return; }
+    std::vector<uint8_t> tex;
+    if (!read_bmp_bgr(data_root() + "/Point_cloud/texture.bmp", tex)) {
+        fail(SL3D_E_INVALID_ARG, "cannot read " + data_root() + "/Point_cloud/texture.bmp (8/24-bit BMP of the camera size)");
+        return;
+    }
+    if (!ok(sl3d_set_texture(g.ctx, 0, tex.data(), (size_t)W * 3), "sl3d_set_texture")) return;
+    int64_t n = 0;
+    if (!ok(sl3d_get_cloud_rgb(g.ctx, 0, nullptr, nullptr, 0, &n), "sl3d_get_cloud_rgb")) return;
+    std::vector<float> xyz((size_t)n * 3);
+    std::vector<uint8_t> rgb((size_t)n * 3);
+    if (!ok(sl3d_get_cloud_rgb(g.ctx, 0, xyz.data(), rgb.data(), n, &n), "sl3d_get_cloud_rgb")) return;
+    mkdir((data_root() + "/Point_cloud").c_str(), 0777);
+    const std::string base = data_root() + "/Point_cloud/point_cloud_" + std::to_string(cloud_index);
+    FILE *f = fopen((base + ".pcd").c_str(), "w");
+    if (!f) { fail(SL3D_E_INVALID_ARG, "cannot write " + base + ".pcd"); return; }
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+               "WIDTH %lld\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %lld\nDATA ascii\n", (long long)n, (long long)n);
+    for (int64_t i = 0; i < n; i++)
+        fprintf(f, "%.9g %.9g %.9g %u\n", xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2],
+                ((unsigned)rgb[3 * i] << 16) | ((unsigned)rgb[3 * i + 1] << 8) | (unsigned)rgb[3 * i + 2]);
+    fclose(f);
+    f = fopen((base + ".ply").c_str(), "w");
+    if (!f) { fail(SL3D_E_INVALID_ARG, "cannot write " + base + ".ply"); return; }
+    fprintf(f, "ply\nformat ascii 1.0\ncomment generated by sl3d (3dscan_amd)\nelement vertex %lld\nproperty float x\nproperty float y\n"
+               "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", (long long)n);
+    for (int64_t i = 0; i < n; i++)
+        fprintf(f, "%.9g %.9g %.9g %u %u %u\n", xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    fclose(f);
+    fprintf(stderr, "Saved %lld data points to %s.pcd / .ply\n", (long long)n, base.c_str());
 }

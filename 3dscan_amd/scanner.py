@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_compact", "sl3d_register_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
+    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_register_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
     "sl3d_get_device_buffers",
 )
 
@@ -94,6 +94,8 @@ def load_library(path=None):
     L.sl3d_get_intersection_points.argtypes = [vp, i, vp]
     L.sl3d_get_points.argtypes = [vp, i, vp, vp]
     L.sl3d_get_cloud.argtypes = [vp, i, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sl3d_set_texture.argtypes = [vp, i, vp, C.c_size_t]
+    L.sl3d_get_cloud_rgb.argtypes = [vp, i, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_compact.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.sl3d_register_views.argtypes = [vp, i, i, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_pattern_counts.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
@@ -270,6 +272,21 @@ class Scanner:
         out = np.empty((n.value, 3), dtype=np.float32)
         self._chk(self.L.sl3d_get_cloud(self._h, view, out.ctypes.data, n.value, C.byref(n)), "sl3d_get_cloud")
         return out
+
+    def set_texture(self, bgr, view=0):
+        """The colour image save_point_cloud() takes r,g,b from: (H, W, 3) uint8, B,G,R order (cvLoadImage)."""
+        t = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert t.shape == (self.H, self.W, 3), t.shape
+        self._chk(self.L.sl3d_set_texture(self._h, view, t.ctypes.data, t.strides[0]), "sl3d_set_texture")
+
+    def cloud_rgb(self, view=0):
+        """(n,3) float32 xyz and (n,3) uint8 r,g,b of the valid pixels in the reference's scan order."""
+        n = C.c_int64(0)
+        self._chk(self.L.sl3d_get_cloud_rgb(self._h, view, None, None, 0, C.byref(n)), "sl3d_get_cloud_rgb")
+        xyz = np.empty((n.value, 3), dtype=np.float32)
+        rgb = np.empty((n.value, 3), dtype=np.uint8)
+        self._chk(self.L.sl3d_get_cloud_rgb(self._h, view, xyz.ctypes.data, rgb.ctypes.data, n.value, C.byref(n)), "sl3d_get_cloud_rgb")
+        return xyz, rgb
 
     def register_views(self, first_view, n_views, tx, ty, tz, rot_step):
         """register_point_clouds(): rotate view k by k*rot_step degrees about Y through (tx,ty,tz), concatenate."""

@@ -193,6 +193,13 @@ int sl3d_get_points(sl3d_ctx *ctx, int view, float *xyz, uint8_t *valid);
  * writes at most `capacity` points, always returns the total count in *count */
 int sl3d_get_cloud(sl3d_ctx *ctx, int view, float *xyz, int64_t capacity, int64_t *count);
 
+/* save_point_cloud() colours every point with the pixel of a camera image (cvLoadImage("Point_cloud/texture.bmp"), split
+ * into blue/green/red, 8/save_point_cloud.cpp:46-52,70-72): sl3d_set_texture uploads that image for a view (window-sized,
+ * B,G,R interleaved as cvLoadImage returns it, `stride` bytes per row); sl3d_get_cloud_rgb returns the compacted cloud and
+ * r,g,b per point, gathered on the device in the same scan order. */
+int sl3d_set_texture(sl3d_ctx *ctx, int view, const uint8_t *bgr, size_t stride);
+int sl3d_get_cloud_rgb(sl3d_ctx *ctx, int view, float *xyz, uint8_t *rgb, int64_t capacity, int64_t *count);
+
 /* the same compaction left on the device (valid until the next sl3d_compact / sl3d_get_cloud on this context):
  * *device_xyz points at count*3 floats in HBM; the count comes back to the host */
 int sl3d_compact(sl3d_ctx *ctx, int view, const float **device_xyz, int64_t *count);

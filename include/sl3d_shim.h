@@ -55,6 +55,9 @@ void compute_wrapped_phase(int pattern_type); /* 3/wrapped_phase.cpp:402 */
 void unwrap_phase(int pattern_type);          /* 4/phase_unwrap.cpp:367 (declared int at intermodule_dependencies.h:13, defined void) */
 void compute_c_p_map();                       /* 5/compute_correspondance.cpp:630 */
 void triangulate();                           /* 7/triangulation.cpp:1444 */
+void save_point_cloud(unsigned cloud_index);  /* 8/save_point_cloud.cpp:19: Point_cloud/texture.bmp -> point_cloud_<i>.pcd / .ply
+                                                 (device compaction + colour gather of the last triangulate(); standard PCD / PLY
+                                                 ASCII text, not PCL 1.6's exact bytes) */
 
 /* ---- shim configuration (not in the reference) ----
  * The reference reads its inputs from hard-coded paths: absolute /home/pranav/Desktop/M_tech_project_console/...

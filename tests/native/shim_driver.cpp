@@ -53,6 +53,11 @@ int main(int argc, char **argv)
     if (sl3d_shim_last_status()) return 14;
     triangulate();
     if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 15; }
+    if (FILE *t = fopen((std::string(argv[1]) + "/Point_cloud/texture.bmp").c_str(), "rb")) {  // main() calls it after triangulate()
+        fclose(t);
+        save_point_cloud(3);
+        if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 16; }
+    }
 
     FILE *o = fopen(argv[2], "wb");
     const size_t n = (size_t)Camera_imagewidth * Camera_imageheight;

@@ -313,6 +313,42 @@ def test_batch_of_views_matches_single_views():
     assert not np.array_equal(batch[0][0][batch[0][1] == 1][:100], batch[1][0][batch[1][1] == 1][:100])
 
 
+def test_coloured_cloud_gather():
+    """N2: save_point_cloud()'s colour gather on the device: r,g,b of the texture pixel of every valid point, in the
+    reference's scan order (8/save_point_cloud.cpp:46-52,70-72,85-104); views keep separate textures."""
+    syn = pkg("synth")
+    S = _scanner()
+    W, H, PW, PH, N, fw = 200, 120, 256, 192, 6, 8   # W is not a multiple of 16: the texture has a pitch too
+    rng = np.random.default_rng(11)
+    with S.Scanner(W, H, PW, PH, N, 5, fw, fw, max_views=2) as sc:
+        caps, texs = [], []
+        for view in range(2):
+            cap = syn.make_capture(W, H, PW, PH, N, 5, fw, fw, plane=(3.0 * view, 0.05, 0.04), view=view, noise=1)
+            mask = cap["mask"].copy()
+            mask[rng.random((H, W)) < 0.05] = 0
+            tex = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)  # B,G,R
+            sc.set_calibration(*syn.cal_tuple(cap["cal"]))
+            sc.set_mask(mask, view=view)
+            sc.set_frames(0, cap["planes_v"], view=view)
+            sc.set_frames(1, cap["planes_h"], view=view)
+            sc.set_texture(tex, view=view)
+            caps.append((cap, mask))
+            texs.append(tex)
+        with pytest.raises(S.Sl3dError):
+            sc.set_texture(texs[0], view=2)
+        sc.run(0, 2)
+        for view in range(2):
+            xyz, valid = sc.points(view)
+            v = valid == 1
+            cx, crgb = sc.cloud_rgb(view)
+            assert np.array_equal(cx, xyz[v])
+            assert np.array_equal(crgb, texs[view][v][:, ::-1])   # b,g,r -> r,g,b
+            assert np.array_equal(sc.cloud(view), cx)
+    with S.Scanner(W, H, PW, PH, N, 5, fw, fw) as sc:
+        with pytest.raises(S.Sl3dError):
+            sc.cloud_rgb(0)   # no texture set
+
+
 def test_turntable_registration():
     """N3 (9/register_point_clouds.cpp): per-view rotation about Y with Pi = 22/7, float accumulation of theta,
     float GEMM with double accumulator -- bit exact against the oracle, clouds in the reference's scan order."""

@@ -48,6 +48,10 @@ def test_shim_matches_oracle(tmp_path):
             else:
                 Image.fromarray(inv).save(f"{d2}/inverse_Captured_image_{i}.bmp")
     mask.tofile(f"{root}/mask.raw")
+    # save_point_cloud()'s colour source, a 24-bit BMP of the camera size (8/save_point_cloud.cpp:46)
+    os.makedirs(f"{root}/Point_cloud")
+    texture = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)  # R,G,B
+    Image.fromarray(texture).save(f"{root}/Point_cloud/texture.bmp")
     Kc, dc, rc, tc, Kp, dp, rp, tp = cal
     _xml(f"{root}/Camera_calibration/Matrices/cam_intrinsic_mat.xml", "cam_intrinsic_mat", 3, 3, Kc)
     _xml(f"{root}/Camera_calibration/Matrices/cam_distortion_vect.xml", "cam_distortion_vect", 5, 1, dc)
@@ -107,6 +111,24 @@ def test_shim_matches_oracle(tmp_path):
         assert np.array_equal(d3, o.debug_image(3, a))
     d4 = np.array(Image.open(f"{root}/Unwrapped_phase_images/Gray_coded/Vertical/Unwrapped_phase_vertical.bmp"))
     assert np.array_equal(d4, o.debug_image(4, 0))
+    # save_point_cloud(3): valid pixels in row-major scan order, float xyz, r,g,b of the texture (8/save_point_cloud.cpp:85-104)
+    exp_xyz = o.intersection_points()[v].astype(np.float32)
+    exp_rgb = texture[v]
+    pcd = open(f"{root}/Point_cloud/point_cloud_3.pcd").read().split("\n")
+    k = pcd.index("DATA ascii")
+    assert f"POINTS {len(exp_xyz)}" in pcd[:k] and "FIELDS x y z rgb" in pcd[:k]
+    rows = np.array([ln.split() for ln in pcd[k + 1:] if ln])
+    got_xyz = rows[:, :3].astype(np.float32)
+    packed = rows[:, 3].astype(np.uint32)
+    got_rgb = np.stack([(packed >> 16) & 255, (packed >> 8) & 255, packed & 255], axis=1).astype(np.uint8)
+    assert len(got_xyz) == len(exp_xyz)
+    assert_points_close(got_xyz[None], exp_xyz[None].astype(np.float64), np.ones((1, len(exp_xyz)), dtype=bool))
+    assert np.array_equal(got_rgb, exp_rgb)
+    ply = open(f"{root}/Point_cloud/point_cloud_3.ply").read().split("\n")
+    k = ply.index("end_header")
+    assert f"element vertex {len(exp_xyz)}" in ply[:k]
+    rows = np.array([ln.split() for ln in ply[k + 1:] if ln])
+    assert np.array_equal(rows[:, :3].astype(np.float32), got_xyz) and np.array_equal(rows[:, 3:].astype(np.uint8), exp_rgb)
 
 
 def test_shim_generate_pattern_reproduces_reference_files(tmp_path):
