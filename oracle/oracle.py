@@ -54,6 +54,7 @@ def _load():
         L.orc_get_projection_matrices.argtypes = [vp, vp, vp]
         L.orc_get_undist_point.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.orc_run_scan.argtypes = [vp, vp, vp, C.c_size_t]
+        L.orc_run_scan_rowmajor.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, vp]
         L.orc_pattern_counts.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_pattern_profile.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.orc_pattern_image.argtypes = [C.c_int] * 8 + [vp]
@@ -131,6 +132,20 @@ class Oracle:
         ph, st2, k2 = _planes(planes_h)
         assert st == st2
         _load().orc_run_scan(self._s, pv, ph, st)
+
+    def run_scan_rowmajor(self, planes_v, planes_h, threads=0):
+        """CPU baseline (b) of SURVEY 8d: the same maths fused, row-major, OpenMP over rows.
+        Returns (xyz float32 [H,W,3] with NaN where invalid, valid uint8 [H,W], threads used)."""
+        pv, st, k1 = _planes(planes_v)
+        ph, st2, k2 = _planes(planes_h)
+        assert st == st2
+        W, H = self.W, self.H
+        xyz = np.empty((H, W, 3), dtype=np.float32)
+        valid = np.empty((H, W), dtype=np.uint8)
+        n = _load().orc_run_scan_rowmajor(self._s, pv, ph, st, int(threads), xyz.ctypes.data, valid.ctypes.data)
+        if n < 0:
+            raise ValueError("orc_run_scan_rowmajor: 3 or 4 fringe patterns only")
+        return xyz, valid, n
 
     def invalidate_tables(self):
         """Force stage 7 to redo assign_3d_coordinates, as the reference does on every triangulate()."""

@@ -763,6 +763,139 @@ void orc_pattern_image(int kind, int axis, int F, int index, int PW, int PH, int
     free(prof);
 }
 
+/* ------------------------------------------------------------------------- */
+/* The same maths, row-major, OpenMP over rows (CPU baseline b). */
+/* Per pixel it performs exactly the operations of the stage functions above   */
+/* (so its results are bit-identical to orc_run_scan's: tests/test_oracle.py), */
+/* but fused, without the [col][row] arrays, without the per-scan stage-7      */
+/* tables (T1 is evaluated for the two points a pixel needs) and with shifts   */
+/* for the powers of two.  The boundary removal stays the literal sequential   */
+/* scan (it is scan-order dependent).  xyz: [H][W][3] float, NaN where invalid;*/
+/* valid: [H][W].  threads <= 0: all cores.                                    */
+/* ------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static void undist_reproject_point(double px, double py, const double *K, const double *d, double *u, double *v)
+{
+    double x, y;
+    undistort_point(px, py, K, d, &x, &y);                      /* :290 / :363 */
+    double vec[3] = {x, y, 1.0}, o[3];
+    for (int i = 0; i < 3; i++) {                               /* cvMatMul(K, mat, mat) :302 */
+        double acc = 0;
+        for (int q = 0; q < 3; q++) acc += K[i * 3 + q] * vec[q];
+        o[i] = acc;
+    }
+    *u = o[0] / o[2];                                           /* Homogenize :305-307 */
+    *v = o[1] / o[2];
+}
+
+int orc_run_scan_rowmajor(orc_state *s, const unsigned char *const *planes_v, const unsigned char *const *planes_h, size_t stride,
+                          int threads, float *xyz, unsigned char *valid)
+{
+    const int W = s->c.W, H = s->c.H, F = s->c.F, PW = s->c.PW, PH = s->c.PH;
+    if (F != 3 && F != 4) return -1;
+    /* S3b + S3d once (both axes start from the same selection): literal scan on a row-major copy */
+    unsigned char *vm = (unsigned char *)malloc((size_t)W * H), *visited = (unsigned char *)calloc((size_t)W * H, 1);
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++) vm[(size_t)r * W + c] = s->selected_region[IDX(s, c, r)] == 1;
+#define VM(u, y) vm[(size_t)(y) * W + (u)]
+#define VS(u, y) visited[(size_t)(y) * W + (u)]
+    for (int y = 1; y < H - 1; y++)
+        for (int u = 1; u < W - 1; u++)
+            if ((!VM(u - 1, y - 1) && !VS(u - 1, y - 1)) || (!VM(u, y - 1) && !VS(u, y - 1)) || (!VM(u + 1, y - 1) && !VS(u + 1, y - 1)) ||
+                (!VM(u - 1, y) && !VS(u - 1, y)) || (!VM(u + 1, y) && !VS(u + 1, y)) || (!VM(u - 1, y + 1) && !VS(u - 1, y + 1)) ||
+                (!VM(u, y + 1) && !VS(u, y + 1)) || (!VM(u + 1, y + 1) && !VS(u + 1, y + 1))) {
+                VM(u, y) = 0;
+                VS(u, y) = 1;
+            }
+#undef VM
+#undef VS
+    free(visited);
+    double A_cam[12], A_proj[12];
+    compute_A(s->Kc, s->rc, s->tc, A_cam);
+    compute_A(s->Kp, s->rp, s->tp, A_proj);
+    const unsigned char *const *gv = planes_v + F, *const *iv = planes_v + F + s->c.N_v;
+    const unsigned char *const *gh = planes_h + F, *const *ih = planes_h + F + s->c.N_h;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    const float nanf_ = nanf("");
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int r = 0; r < H; r++) {
+        for (int c = 0; c < W; c++) {
+            const size_t o = (size_t)r * W + c;
+            xyz[3 * o] = xyz[3 * o + 1] = xyz[3 * o + 2] = nanf_;
+            valid[o] = 0;
+            if (!vm[o]) continue;
+            float wrapped[2], unwrapped[2] = {0.0f, 0.0f};
+            for (int a = 0; a < 2; a++) {
+                const unsigned char *const *fr = a == 0 ? planes_v : planes_h;
+                const unsigned char *const *g = a == 0 ? gv : gh, *const *iv_ = a == 0 ? iv : ih;
+                const int N = a == 0 ? s->c.N_v : s->c.N_h;
+                float t1, t2;
+                if (F == 3) { /* 3/wrapped_phase.cpp:171-175 */
+                    t1 = (float)(PX(fr[0], stride, r, c)) - (float)(PX(fr[2], stride, r, c));
+                    t2 = 2.0 * ((float)(PX(fr[1], stride, r, c))) - (float)(PX(fr[0], stride, r, c)) - (float)(PX(fr[2], stride, r, c));
+                } else {      /* :195-198 */
+                    t1 = (float)(PX(fr[3], stride, r, c)) - (float)(PX(fr[1], stride, r, c));
+                    t2 = (float)(PX(fr[0], stride, r, c)) - (float)(PX(fr[2], stride, r, c));
+                }
+                wrapped[a] = atan2(t1, t2);
+                int code = 0, B = 0; /* 4/phase_unwrap.cpp:183-193 */
+                for (int i = 0; i < N; i++) {
+                    const int G = (PX(g[i], stride, r, c) - PX(iv_[i], stride, r, c)) >= THRESH;
+                    B = i == 0 ? G : (B != G);
+                    code += B << (N - 1 - i);
+                }
+                const int in_range = a == 0 ? (c >= 1 && c <= W - 2) : (r >= 1 && r <= H - 2); /* :285 / :304 */
+                if (in_range) {
+                    wrapped[a] += Pi;                                 /* :290 / :308 */
+                    unwrapped[a] = wrapped[a] + code * 2.0 * Pi;      /* :291 / :309 */
+                }
+            }
+            /* 5/compute_correspondance.cpp:648-675 */
+            feclearexcept(FE_ALL_EXCEPT);
+            const long cx = lrint(s->c.fw_v * (unwrapped[0] / (2.0 * Pi)));
+            if (fetestexcept(FE_INVALID) != 0) continue;
+            feclearexcept(FE_ALL_EXCEPT);
+            const long cy = lrint(s->c.fw_h * (unwrapped[1] / (2.0 * Pi)));
+            if (fetestexcept(FE_INVALID) != 0) continue;
+            if (cx > PW - 1 || cy > PH - 1 || cx < 0 || cy < 0) continue;
+            /* 7/triangulation.cpp: T1 for the two points of this pixel, then compute_P / compute_F / compute_X_Y_Z */
+            double cu, cv, pu, pv;
+            undist_reproject_point((double)(c + s->c.col0), (double)(r + s->c.row0), s->Kc, s->dc, &cu, &cv);
+            undist_reproject_point((double)(cx + s->c.pcol0), (double)(cy + s->c.prow0), s->Kp, s->dp, &pu, &pv);
+            double P[12], Fv[4], P_trans[12], I1[9], I2[12], V[3];
+            for (int q = 0; q < 3; q++) {
+                P[0 * 3 + q] = A_cam[0 * 4 + q] - cu * A_cam[2 * 4 + q];
+                P[1 * 3 + q] = A_cam[1 * 4 + q] - cv * A_cam[2 * 4 + q];
+                P[2 * 3 + q] = A_proj[0 * 4 + q] - pu * A_proj[2 * 4 + q];
+                P[3 * 3 + q] = A_proj[1 * 4 + q] - pv * A_proj[2 * 4 + q];
+            }
+            Fv[0] = A_cam[2 * 4 + 3] * cu - A_cam[0 * 4 + 3];
+            Fv[1] = A_cam[2 * 4 + 3] * cv - A_cam[1 * 4 + 3];
+            Fv[2] = A_proj[2 * 4 + 3] * pu - A_proj[0 * 4 + 3];
+            Fv[3] = A_proj[2 * 4 + 3] * pv - A_proj[1 * 4 + 3];
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 3; b++) P_trans[b * 4 + a] = P[a * 3 + b];
+            mat_mul(P_trans, P, I1, 3, 4, 3);
+            invert3(I1, I1);
+            mat_mul(I1, P_trans, I2, 3, 3, 4);
+            mat_mul(I2, Fv, V, 3, 4, 1);
+            xyz[3 * o] = (float)V[0]; xyz[3 * o + 1] = (float)V[1]; xyz[3 * o + 2] = (float)V[2]; /* 8/save_point_cloud.cpp:100-102 */
+            valid[o] = 1;
+        }
+    }
+    free(vm);
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* One whole scan in main()'s order, m_tech_project_console.cpp:366-395:
    S3(v), S3(h), S4(v), S4(h), S5, S7.  planes_v / planes_h hold F fringe, then N gray,
    then N inverse-gray row-major planes.  This is what bench.py's cpu_baseline times. */

@@ -240,3 +240,30 @@ def test_pattern_gray_code_properties():
         assert np.array_equal(code, np.arange(extent) // fw)
         per_code = planes[:, ::fw]
         assert np.all(np.abs(np.diff(per_code.astype(int), axis=1)).sum(axis=0) == 1)
+
+
+def test_rowmajor_openmp_baseline_is_bit_identical():
+    """CPU baseline (b): the fused row-major OpenMP restatement gives exactly the sequential oracle's valid map and
+    float points (same per-pixel operations), for 1 and for all threads, with distortion on both devices, F = 3 and 4."""
+    from conftest import pkg
+    syn = pkg("synth")
+    W, H, PW, PH, N, fw = 200, 120, 256, 192, 6, 8
+    for F in (3, 4):
+        cap = syn.make_capture(W, H, PW, PH, N, 5, fw, fw, noise=2, n_fringe=F)
+        cal = {k: np.array(v, dtype=np.float64).copy() for k, v in cap["cal"].items()}
+        cal["dp"] = np.array([0.05, -0.02, 0.001, -0.0005, 0.01])
+        mask = cap["mask"].copy()
+        mask[30:50, 40:90] = 0
+        mask[np.random.default_rng(3).random((H, W)) < 0.02] = 0
+        o = Oracle(W, H, PW, PH, N, 5, fw, fw, F=F)
+        o.set_mask(mask)
+        o.set_calibration(*syn.cal_tuple(cal))
+        o.run_scan(cap["planes_v"], cap["planes_h"])
+        v = o.valid_map(2) == 1
+        ref = o.intersection_points().astype(np.float32)
+        for threads in (1, 0):
+            xyz, valid, n = o.run_scan_rowmajor(cap["planes_v"], cap["planes_h"], threads=threads)
+            assert n >= 1
+            assert np.array_equal(valid == 1, v)
+            assert np.array_equal(xyz[v], ref[v])
+            assert np.isnan(xyz[~v]).all()
