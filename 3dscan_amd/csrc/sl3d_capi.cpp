@@ -41,6 +41,9 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
+    unsigned *d_blk_cnt_all = nullptr;
+    unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
     uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)
     uint8_t *d_cloud_rgb = nullptr;           // r,g,b of the compacted cloud of one view
     std::vector<char> have_texture;
@@ -710,6 +713,52 @@ extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacit
         HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         HIPCHK(x, hipStreamSynchronize(x->stream));
     }
+    return SL3D_OK;
+}
+
+// The compaction of a whole batch of views in three launches and one read-back: what a pipeline that goes from
+// device-resident frames to compacted clouds runs after sl3d_run (bench.py reports it as `to_compacted_clouds`).
+extern "C" int sl3d_compact_views(sl3d_ctx *x, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const KParams &P = x->P;
+    const size_t nb = (P.px_view_stride + 1023) / 1024, mv = (size_t)x->cfg.max_views;
+    if (!x->d_clouds) {
+        rc = dev_alloc(x, &x->d_clouds, mv * P.px_view_stride * 3);
+        if (!rc) rc = dev_alloc(x, &x->d_blk_cnt_all, mv * nb);
+        if (!rc) rc = dev_alloc(x, &x->d_blk_off_all, mv * nb);
+        if (!rc) rc = dev_alloc(x, &x->d_totals, mv);
+        if (rc) return rc;
+    }
+    rc = launched(x, launch_compact_views(P, first_view, n_views, x->d_blk_cnt_all, x->d_blk_off_all, x->d_totals,
+                                          x->d_clouds + 3 * (size_t)first_view * P.px_view_stride, x->stream));
+    if (rc) return rc;
+    std::vector<unsigned long long> t((size_t)n_views);
+    HIPCHK(x, hipMemcpyAsync(t.data(), x->d_totals, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[(size_t)v];
+    if (device_xyz) *device_xyz = x->d_clouds + 3 * (size_t)first_view * P.px_view_stride;
+    if (view_stride_points) *view_stride_points = P.px_view_stride;
+    return SL3D_OK;
+}
+
+// host copy of the batched compaction: the clouds of the views back to back in xyz (at most `capacity` points in all)
+extern "C" int sl3d_get_clouds(sl3d_ctx *x, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts)
+{
+    const float *dev = nullptr;
+    size_t stride = 0;
+    int rc = sl3d_compact_views(x, first_view, n_views, &dev, &stride, counts);
+    if (rc) return rc;
+    int64_t off = 0;
+    for (int v = 0; v < n_views && xyz; v++) {
+        const int64_t n = counts[v] < capacity - off ? counts[v] : capacity - off;
+        if (n > 0) HIPCHK(x, hipMemcpyAsync(xyz + 3 * off, dev + 3 * (size_t)v * stride, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        off += n > 0 ? n : 0;
+    }
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 

@@ -94,6 +94,8 @@ int launch_corr(const KParams &P, int view, void *stream);
 int launch_tri(const KParams &P, const DevCal &C, int view, void *stream);
 int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned long long *block_offsets, unsigned long long *total,
                    float *cloud, const uint8_t *texture, uint8_t *rgb_out, void *stream);
+int launch_compact_views(const KParams &P, int first_view, int n_views, unsigned *block_counts, unsigned long long *block_offsets,
+                         unsigned long long *totals, float *clouds, void *stream);
 int launch_register(const float *in, float *out, long n, const float R4[4], float tx, float ty, float tz, void *stream);
 int launch_synth(const KParams &P, const DevCal &C, const SynthParams &S, int view, void *stream);
 int launch_pattern(uint8_t *dst, size_t pitch, int PW, int PH, int axis, const uint8_t *profile, void *stream);

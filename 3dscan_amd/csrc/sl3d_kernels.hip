@@ -1146,8 +1146,11 @@ int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned
 // and the scatter.  A block covers 1024 consecutive pixels of the pitch-padded plane; padding pixels are
 // never valid, so the scan order of the valid pixels is exactly the reference's.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact_count(const uint8_t *valid, size_t n_px, unsigned *block_counts)
+// blockIdx.y = view of a batch (strides in elements; 0 strides for a single view)
+__global__ __launch_bounds__(256) void k_compact_count(const uint8_t *valid, size_t n_px, unsigned *block_counts, size_t valid_stride, int nb)
 {
+    valid += (size_t)blockIdx.y * valid_stride;
+    block_counts += (size_t)blockIdx.y * nb;
     __shared__ unsigned s_cnt[4];
     const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
     unsigned w = base < n_px ? *(const unsigned *)(valid + base) : 0u;  // 4 valid bytes (0/1)
@@ -1161,6 +1164,9 @@ __global__ __launch_bounds__(256) void k_compact_count(const uint8_t *valid, siz
 // exclusive scan of n counts by a single 1024-thread block (n is a few thousand .. tens of thousands)
 __global__ __launch_bounds__(1024) void k_compact_scan(const unsigned *counts, unsigned long long *offsets, int n, unsigned long long *total)
 {
+    counts += (size_t)blockIdx.x * n;   // one block per view of a batch
+    offsets += (size_t)blockIdx.x * n;
+    total += blockIdx.x;
     __shared__ unsigned long long s_part[1024];
     const int per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, n);
     unsigned long long sum = 0;
@@ -1182,9 +1188,14 @@ __global__ __launch_bounds__(1024) void k_compact_scan(const unsigned *counts, u
 // 70-72), [row][pitch][3] bytes; rgb_out receives r,g,b per compacted point
 __global__ __launch_bounds__(256) void k_compact_scatter(const uint8_t *valid, const float *points, size_t n_px,
                                                          const unsigned long long *block_offsets, float *cloud, const uint8_t *texture,
-                                                         uint8_t *rgb_out)
+                                                         uint8_t *rgb_out, size_t view_stride, int nb)
 {
+    valid += (size_t)blockIdx.y * view_stride;
+    points += 3 * (size_t)blockIdx.y * view_stride;
+    cloud += 3 * (size_t)blockIdx.y * view_stride;
+    block_offsets += (size_t)blockIdx.y * nb;
     __shared__ unsigned s_wave[4];
+    __shared__ __attribute__((aligned(16))) float s_pts[1024 * 3];  // the block's valid points, compacted
     const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
     const unsigned w = base < n_px ? (*(const unsigned *)(valid + base) & 0x01010101u) : 0u;
     const unsigned c = __popc(w);
@@ -1198,20 +1209,32 @@ __global__ __launch_bounds__(256) void k_compact_scatter(const uint8_t *valid, c
     __syncthreads();
     unsigned wave_base = 0;
     for (int i = 0; i < (int)(threadIdx.x >> 6); i++) wave_base += s_wave[i];
-    unsigned long long dst = block_offsets[blockIdx.x] + wave_base + (incl - c);
+    const unsigned block_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    unsigned local = wave_base + (incl - c);
+    const unsigned long long block_off = block_offsets[blockIdx.x];
+    if (w) {
+        // the 4 pixels of a lane are 48 contiguous bytes: three 16-B loads, then the valid ones go to LDS in scan order
+        const float4 *p4 = (const float4 *)(points + 3 * base);
+        const float4 a = p4[0], b = p4[1], d = p4[2];
+        const float q[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        if ((w >> (8 * k)) & 1u) {
-            const float *p = points + 3 * (base + k);
-            float *q = cloud + 3 * dst;
-            q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
-            if (texture) {
-                const uint8_t *t = texture + 3 * (base + k);  // b, g, r
-                uint8_t *c = rgb_out + 3 * dst;
-                c[0] = t[2]; c[1] = t[1]; c[2] = t[0];
+        for (int k = 0; k < 4; k++)
+            if ((w >> (8 * k)) & 1u) {
+                s_pts[3 * local + 0] = q[3 * k + 0];
+                s_pts[3 * local + 1] = q[3 * k + 1];
+                s_pts[3 * local + 2] = q[3 * k + 2];
+                if (texture) {
+                    const uint8_t *t = texture + 3 * (base + k);  // b, g, r
+                    uint8_t *o = rgb_out + 3 * (block_off + local);
+                    o[0] = t[2]; o[1] = t[1]; o[2] = t[0];
+                }
+                local++;
             }
-            dst++;
-        }
+    }
+    __syncthreads();
+    // the block's segment of the cloud is contiguous: coalesced dword stores
+    float *dst = cloud + 3 * block_off;
+    for (unsigned i = threadIdx.x; i < 3 * block_total; i += 256) dst[i] = s_pts[i];
 }
 
 int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned long long *block_offsets, unsigned long long *total,
@@ -1222,9 +1245,25 @@ int launch_compact(const KParams &P, int view, unsigned *block_counts, unsigned 
     const uint8_t *valid = P.valid + (size_t)view * P.px_view_stride;
     const float *points = P.points + 3 * (size_t)view * P.px_view_stride;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, st, valid, n_px, block_counts);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, st, valid, n_px, block_counts, (size_t)0, nb);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_counts, block_offsets, nb, total);
-    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(256), 0, st, valid, points, n_px, block_offsets, cloud, texture, rgb_out);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(256), 0, st, valid, points, n_px, block_offsets, cloud, texture, rgb_out, (size_t)0, nb);
+    return (int)hipGetLastError();
+}
+
+// the same three kernels over a batch of views: view v's compacted cloud starts at clouds + 3*v*px_view_stride
+int launch_compact_views(const KParams &P, int first_view, int n_views, unsigned *block_counts, unsigned long long *block_offsets,
+                         unsigned long long *totals, float *clouds, void *stream)
+{
+    const size_t n_px = P.px_view_stride;
+    const int nb = (int)((n_px + 1023) / 1024);
+    const uint8_t *valid = P.valid + (size_t)first_view * P.px_view_stride;
+    const float *points = P.points + 3 * (size_t)first_view * P.px_view_stride;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_compact_count, dim3(nb, n_views), dim3(256), 0, st, valid, n_px, block_counts, n_px, nb);
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_views), dim3(1024), 0, st, block_counts, block_offsets, nb, totals);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb, n_views), dim3(256), 0, st, valid, points, n_px, block_offsets, clouds, (const uint8_t *)nullptr,
+                       (uint8_t *)nullptr, n_px, nb);
     return (int)hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_register_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
+    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
     "sl3d_get_device_buffers",
 )
 
@@ -94,6 +94,8 @@ def load_library(path=None):
     L.sl3d_get_intersection_points.argtypes = [vp, i, vp]
     L.sl3d_get_points.argtypes = [vp, i, vp, vp]
     L.sl3d_get_cloud.argtypes = [vp, i, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sl3d_compact_views.argtypes = [vp, i, i, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
+    L.sl3d_get_clouds.argtypes = [vp, i, i, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_set_texture.argtypes = [vp, i, vp, C.c_size_t]
     L.sl3d_get_cloud_rgb.argtypes = [vp, i, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_compact.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_int64)]
@@ -271,6 +273,25 @@ class Scanner:
         self._chk(self.L.sl3d_get_cloud(self._h, view, None, 0, C.byref(n)), "sl3d_get_cloud")
         out = np.empty((n.value, 3), dtype=np.float32)
         self._chk(self.L.sl3d_get_cloud(self._h, view, out.ctypes.data, n.value, C.byref(n)), "sl3d_get_cloud")
+        return out
+
+    def compact_views(self, first_view, n_views):
+        """Batched device compaction (three launches for all views); returns the per-view counts, clouds stay in HBM."""
+        counts = (C.c_int64 * n_views)()
+        self._chk(self.L.sl3d_compact_views(self._h, first_view, n_views, None, None, counts), "sl3d_compact_views")
+        return [int(c) for c in counts]
+
+    def clouds(self, first_view, n_views):
+        """The compacted clouds of a batch of views as a list of (n_k, 3) float32 arrays."""
+        counts = (C.c_int64 * n_views)()
+        self._chk(self.L.sl3d_get_clouds(self._h, first_view, n_views, None, 0, counts), "sl3d_get_clouds")
+        total = sum(counts)
+        flat = np.empty((total, 3), dtype=np.float32)
+        self._chk(self.L.sl3d_get_clouds(self._h, first_view, n_views, flat.ctypes.data, total, counts), "sl3d_get_clouds")
+        out, off = [], 0
+        for n in counts:
+            out.append(flat[off:off + n])
+            off += n
         return out
 
     def set_texture(self, bgr, view=0):

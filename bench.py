@@ -216,6 +216,25 @@ def main():
                      "pixels_per_launch": px_per_launch, "avg_launch_ms": round(launch_s * 1e3, 4)},
     }
 
+    # end to end from device-resident frames to compacted clouds: the fused kernel + the batched compaction of
+    # every view (three more launches and one read-back of the counts per step); a side figure, never `value`
+    try:
+        for _ in range(20):
+            sc.run(0, n_views)
+            sc.compact_views(0, n_views)
+        barrier()
+        t0 = time.perf_counter()
+        reps = max(20, args.steps // 10)
+        for _ in range(reps):
+            sc.run(0, n_views)
+            counts = sc.compact_views(0, n_views)
+        barrier()
+        te = dmod.max_over_ranks((time.perf_counter() - t0) / reps, red_dev)
+        out["to_compacted_clouds"] = {"value": round(px_per_launch * world / te / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(te * 1e3, 4),
+                                      "valid_points_per_step_rank0": int(sum(counts))}
+    except Exception as e:
+        out["to_compacted_clouds"] = {"error": repr(e)}
+
     if world > 1 and not args.no_assemble:
         out["assemble"] = measure_assemble(torch, dist, dmod, sc, n_views, V, rows, rank, world)
 

@@ -204,6 +204,13 @@ int sl3d_get_cloud_rgb(sl3d_ctx *ctx, int view, float *xyz, uint8_t *rgb, int64_
  * *device_xyz points at count*3 floats in HBM; the count comes back to the host */
 int sl3d_compact(sl3d_ctx *ctx, int view, const float **device_xyz, int64_t *count);
 
+/* the compaction of views [first_view, first_view+n_views) in one go (three launches, one read-back of the counts):
+ * view first_view+k's cloud is counts[k] points at *device_xyz + 3*k*(*view_stride_points) floats, valid until the next
+ * sl3d_compact_views on this context */
+int sl3d_compact_views(sl3d_ctx *ctx, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts);
+/* the same with a host copy: the clouds back to back in xyz (at most `capacity` points in all; xyz may be NULL) */
+int sl3d_get_clouds(sl3d_ctx *ctx, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts);
+
 /* register_point_clouds(unsigned, float tx, float ty, float tz, float rot_step)  9/register_point_clouds.cpp:23:
  * the compacted clouds of views [first_view, first_view+n_views) are rotated about the Y axis through (tx,ty,tz)
  * by 0, rot_step, 2*rot_step ... degrees and concatenated in view order; writes at most `capacity` points to xyz

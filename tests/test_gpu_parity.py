@@ -344,6 +344,13 @@ def test_coloured_cloud_gather():
             assert np.array_equal(cx, xyz[v])
             assert np.array_equal(crgb, texs[view][v][:, ::-1])   # b,g,r -> r,g,b
             assert np.array_equal(sc.cloud(view), cx)
+        # batched compaction of both views: the same clouds, three launches in all
+        both = sc.clouds(0, 2)
+        assert sc.compact_views(0, 2) == [len(b) for b in both]
+        for view in range(2):
+            xyz, valid = sc.points(view)
+            assert np.array_equal(both[view], xyz[valid == 1])
+        assert np.array_equal(sc.clouds(1, 1)[0], both[1])
     with S.Scanner(W, H, PW, PH, N, 5, fw, fw) as sc:
         with pytest.raises(S.Sl3dError):
             sc.cloud_rgb(0)   # no texture set
