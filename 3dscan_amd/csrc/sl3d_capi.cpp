@@ -817,22 +817,25 @@ extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, flo
         rc = dev_alloc(x, &x->d_reg, (size_t)x->cfg.max_views * P.px_view_stride * 3);
         if (rc) return rc;
     }
+    // one batched compaction (three launches, one read-back), then one transform launch per view, no host sync between them
+    std::vector<int64_t> counts((size_t)n_views);
+    const float *clouds = nullptr;
+    size_t stride = 0;
+    rc = sl3d_compact_views(x, first_view, n_views, &clouds, &stride, counts.data());
+    if (rc) return rc;
     float theta = 0.0f;
     int64_t off = 0;
     for (int k = 0; k < n_views; k++) {
-        int64_t n = 0;
-        const float *cloud = nullptr;
-        rc = sl3d_compact(x, first_view + k, &cloud, &n);
-        if (rc) return rc;
+        const int64_t n = counts[(size_t)k];
         // R entries as the reference stores them: double cos/sin of theta*Pi/180.0 (Pi = 22.0/7.0), rounded to float
         const float R4[4] = {(float)cos(theta * 22.0 / 7.0 / 180.0), (float)(-1.0f * sin(theta * 22.0 / 7.0 / 180.0)),
                              (float)sin(theta * 22.0 / 7.0 / 180.0), (float)cos(theta * 22.0 / 7.0 / 180.0)};
-        rc = launched(x, launch_register(cloud, x->d_reg + 3 * off, (long)n, R4, tx, ty, tz, x->stream));
+        rc = launched(x, launch_register(clouds + 3 * (size_t)k * stride, x->d_reg + 3 * off, (long)n, R4, tx, ty, tz, x->stream));
         if (rc) return rc;
-        HIPCHK(x, hipStreamSynchronize(x->stream));  // d_cloud is reused by the next view's compaction
         off += n;
         theta += rot_step;
     }
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     *total = off;
     const int64_t m = off < capacity ? off : capacity;
     if (xyz && m > 0) {
