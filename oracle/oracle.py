@@ -32,7 +32,9 @@ def _load():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB)
+        # SL3D_ORACLE_LIB: another build of the same source, e.g. `make -C oracle libsl3d_oracle_asan.so` run as
+        #   LD_PRELOAD=$(gcc -print-file-name=libasan.so) SL3D_ORACLE_LIB=oracle/libsl3d_oracle_asan.so pytest tests/test_oracle.py
+        L = C.CDLL(os.environ.get("SL3D_ORACLE_LIB") or _LIB)
         vp = C.c_void_p
         L.orc_create.restype = vp
         L.orc_create.argtypes = [C.POINTER(_Cfg)]
