@@ -10,11 +10,16 @@
 //
 // Arithmetic contract:
 //   * everything up to the correspondence (x,y) is BIT-EXACT with the reference's C expressions:
-//     atan2 comes from a table built by the host with the double-precision libm atan2 the reference
-//     calls (3/wrapped_phase.cpp:175); the +Pi, +code*2.0*Pi, /(2.0*Pi), *fw, lrint chain is
-//     evaluated in fp64 with the reference's operation order and Pi = 22.0/7.0; this file is
-//     compiled with -ffp-contract=off so no FMA is formed behind our back.
+//     (float)atan2 is evaluated in the kernel on the integer lattice its arguments live on and equals
+//     the double-precision libm atan2 the reference calls (3/wrapped_phase.cpp:175) on every lattice
+//     point (atan2_lattice4; proven by exhaustion on the CPU and again on the device at sl3d_create);
+//     the +Pi, +code*2.0*Pi, /(2.0*Pi), *fw, lrint chain is evaluated in fp64 with the reference's
+//     operation order and Pi = 22.0/7.0; this file is compiled with -ffp-contract=off so no FMA is
+//     formed behind our back.
 //   * stage 7 (fp64 4x3 least squares) only has to match within 1e-5; it uses explicit fma().
+//
+// The SL3D_* macros below are compile-time switches for measured A/B builds (tools/ab.sh); the
+// defaults are the shipped configuration and every rejected alternative is recorded in DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -30,8 +35,6 @@
 #ifndef SL3D_OCC
 #define SL3D_OCC 4 /* waves per SIMD the fused kernel is compiled for */
 #endif
-// measurement only (tools/ab.sh): 1 = no per-pixel arithmetic (xyz made of the raw decode results), 2 = no mask reads,
-// 4 = no xyz stores.  Results are wrong by construction; never set in a shipped build.
 // 1: the fused kernel reads 1/d of the atan2 quotient from an LDS table (6 KB per block); 0: v_rcp_f64 + one Newton step
 #ifndef SL3D_RCP_LDS
 #define SL3D_RCP_LDS 1
@@ -56,6 +59,8 @@
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
+// measurement only: 1 = no per-pixel arithmetic (xyz made of the raw decode results), 2 = no mask reads, 4 = no xyz stores.
+// Results are wrong by construction; never set in a shipped build.
 #ifndef SL3D_ABLATE
 #define SL3D_ABLATE 0
 #endif
