@@ -199,7 +199,7 @@ def main():
     kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if nmax == N else 'false'}, {1 if args.rig == 'reference' else 2}>"
 
     out = {
-        "metric": "Mpixels/s decode+unwrap+triangulate @1920x1080",
+        "metric": "Mpixels/s decode+unwrap+triangulate @1920\u00d71080",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (planes through the reference rig, generated on the device, a different plane and noise stream per view)",
