@@ -237,8 +237,10 @@ int sl3d_generate_pattern(sl3d_ctx *ctx, int kind, int axis, int index, uint8_t 
                           const uint8_t **device_ptr, size_t *device_pitch);
 
 /* ---- device-resident access ---------------------------------------------------------------- */
+/* Frames may be produced in place (frames buffer) and points / valid consumed in place.  The mask buffer is exposed for
+ * inspection only: set masks through sl3d_set_mask, which also normalises the bytes to 0/1 and evaluates the quads within
+ * 3 pixels of the frame border on the host (a second plane the kernels read for those quads). */
 int sl3d_get_device_buffers(sl3d_ctx *ctx, sl3d_device_buffers *out);
-/* normalise a mask written directly into the device buffer to 0/1 bytes is the caller's duty */
 
 #ifdef __cplusplus
 }
