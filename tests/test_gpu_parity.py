@@ -313,6 +313,42 @@ def test_batch_of_views_matches_single_views():
     assert not np.array_equal(batch[0][0][batch[0][1] == 1][:100], batch[1][0][batch[1][1] == 1][:100])
 
 
+def test_two_contexts_are_independent():
+    """SURVEY 8b threading row: contexts are independent of each other.  Two contexts of different shapes, rigs and
+    modes on the same GPU with their calls interleaved give what each gives alone."""
+    syn = pkg("synth")
+    S = _scanner()
+    A = dict(W=320, H=200, PW=512, PH=384, N=7, fw=4)
+    B = dict(W=200, H=120, PW=256, PH=192, N=6, fw=8)
+    capA = syn.make_capture(A["W"], A["H"], A["PW"], A["PH"], A["N"], A["N"], A["fw"], A["fw"], noise=1)
+    capB = syn.make_capture(B["W"], B["H"], B["PW"], B["PH"], B["N"], 5, B["fw"], B["fw"], noise=2, plane=(5.0, 0.02, 0.07))
+    calB = {k: np.array(v, dtype=np.float64).copy() for k, v in capB["cal"].items()}
+    calB["dp"] = np.array([0.04, -0.01, 0.0, 0.0, 0.0])  # context B: distorted projector (rig class 2)
+    oA = _oracle_for(capA, A["W"], A["H"], A["PW"], A["PH"], A["N"], A["N"], A["fw"], A["fw"], capA["mask"])
+    oB = _oracle_for(dict(capB, cal=calB), B["W"], B["H"], B["PW"], B["PH"], B["N"], 5, B["fw"], B["fw"], capB["mask"])
+    with S.Scanner(A["W"], A["H"], A["PW"], A["PH"], A["N"], A["N"], A["fw"], A["fw"]) as a, \
+         S.Scanner(B["W"], B["H"], B["PW"], B["PH"], B["N"], 5, B["fw"], B["fw"], keep_stages=True) as b:
+        a.set_calibration(*syn.cal_tuple(capA["cal"]))
+        b.set_calibration(*syn.cal_tuple(calB))
+        b.set_mask(capB["mask"])
+        a.set_mask(capA["mask"])
+        a.set_frames(0, capA["planes_v"])
+        b.set_frames(0, capB["planes_v"])
+        b.set_frames(1, capB["planes_h"])
+        a.set_frames(1, capA["planes_h"])
+        for _ in range(3):
+            a.run()
+            b.run_stages()
+            b.run()
+            a.run()
+        xa, va = a.points()
+        xb, vb = b.points()
+        assert np.array_equal(va == 1, oA.valid_map(2) == 1) and np.array_equal(vb == 1, oB.valid_map(2) == 1)
+        assert_points_close(xa, oA.intersection_points(), oA.valid_map(2) == 1)
+        assert_points_close(xb, oB.intersection_points(), oB.valid_map(2) == 1)
+        assert np.array_equal(b.code(0), oB.code(0)) and np.array_equal(b.c_p_map()[vb == 1], oB.c_p_map()[vb == 1])
+
+
 def test_coloured_cloud_gather():
     """N2: save_point_cloud()'s colour gather on the device: r,g,b of the texture pixel of every valid point, in the
     reference's scan order (8/save_point_cloud.cpp:46-52,70-72,85-104); views keep separate textures."""
