@@ -41,6 +41,8 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // sl3d_process_views: upload and download run beside the compute stream
+    std::vector<hipEvent_t> ev_up, ev_done, ev_down;  // per view slot: frames landed / kernel finished / results copied out
     float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
     unsigned *d_blk_cnt_all = nullptr;
     unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
@@ -270,6 +272,11 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
     (void)hipSetDevice(x->cfg.device);
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     for (void *p : x->allocs) (void)hipFree(p);
+    for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
+    for (hipEvent_t e : x->ev_done) (void)hipEventDestroy(e);
+    for (hipEvent_t e : x->ev_down) (void)hipEventDestroy(e);
+    if (x->s_h2d) (void)hipStreamDestroy(x->s_h2d);
+    if (x->s_d2h) (void)hipStreamDestroy(x->s_d2h);
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
     if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
@@ -681,6 +688,86 @@ extern "C" int sl3d_get_points(sl3d_ctx *x, int view, float *xyz, uint8_t *valid
     if (xyz) rc = get_plane<float>(x, view, x->P.points, 3, xyz, (size_t)x->P.W * 3);
     if (rc == SL3D_OK && valid) rc = get_plane<uint8_t>(x, view, x->P.valid, 1, valid, (size_t)x->P.W);
     return rc;
+}
+
+// ---- host-buffer pipeline -------------------------------------------------------------------------------------------
+// Pinned host memory for frames and results: with it the uploads and downloads of sl3d_process_views are true asynchronous
+// DMA (pageable memory still works, but every copy is then staged and serialised by the runtime).
+extern "C" void *sl3d_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+extern "C" void sl3d_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+// A batch of views that live in HOST memory, through the view slots of the context as a three-stage pipeline on three
+// HIP streams: upload of view k+1 (46 plane copies), fused kernel of view k, download of the xyz / valid planes of view
+// k-1 overlap; events hand a slot from stage to stage.  What the C ABI sustains when the boundary hands over host buffers
+// is then the slowest stage (the upload: PCIe), not the sum of the three.  The mask of every slot must have been set.
+//   planes: n_views * planes_per_view pointers, view-major, plane order as in sl3d_device_buffers; `stride` bytes per row
+//   xyz:    n_views dense [height][width][3] float images (may be NULL);  valid: n_views [height][width] bytes (may be NULL)
+extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid)
+{
+    if (!x || n_views < 1 || !planes) return fail(x, SL3D_E_INVALID_ARG, "process_views: null argument");
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "process_views before set_calibration");
+    const KParams &P = x->P;
+    if (stride < (size_t)P.W) return fail(x, SL3D_E_INVALID_ARG, "process_views: stride < width");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const int S = x->cfg.max_views;  // slots
+    if (!x->s_h2d) {
+        HIPCHK(x, hipStreamCreateWithFlags(&x->s_h2d, hipStreamNonBlocking));
+        HIPCHK(x, hipStreamCreateWithFlags(&x->s_d2h, hipStreamNonBlocking));
+        x->ev_up.resize((size_t)S); x->ev_done.resize((size_t)S); x->ev_down.resize((size_t)S);
+        for (int i = 0; i < S; i++) {
+            HIPCHK(x, hipEventCreateWithFlags(&x->ev_up[(size_t)i], hipEventDisableTiming));
+            HIPCHK(x, hipEventCreateWithFlags(&x->ev_done[(size_t)i], hipEventDisableTiming));
+            HIPCHK(x, hipEventCreateWithFlags(&x->ev_down[(size_t)i], hipEventDisableTiming));
+        }
+    }
+    HIPCHK(x, hipStreamSynchronize(x->stream));  // earlier work on the context's own stream is done before the slots are reused
+    const int ppv = P.planes_per_view;
+    for (int v = 0; v < n_views; v++) {
+        const int slot = v % S;
+        // the slot's previous occupant must have been computed (frames free) and downloaded (results free)
+        if (v >= S) {
+            HIPCHK(x, hipStreamWaitEvent(x->s_h2d, x->ev_done[(size_t)slot], 0));
+            HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_down[(size_t)slot], 0));
+        }
+        // a view whose planes are back to back in host memory, in the device's own pitch, goes up as ONE copy
+        bool contiguous = stride == (size_t)P.pitch && (size_t)P.W == (size_t)P.pitch;
+        for (int p = 0; p < ppv; p++) {
+            const uint8_t *src = planes[(size_t)v * ppv + p];
+            if (!src) return fail(x, SL3D_E_INVALID_ARG, "process_views: null plane");
+            if (p && src != planes[(size_t)v * ppv + p - 1] + P.plane_stride) contiguous = false;
+        }
+        if (contiguous) {
+            HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)slot * P.view_stride, planes[(size_t)v * ppv], P.view_stride, hipMemcpyHostToDevice, x->s_h2d));
+        } else {
+            for (int p = 0; p < ppv; p++)
+                HIPCHK(x, hipMemcpy2DAsync(x->d_frames + (size_t)slot * P.view_stride + (size_t)p * P.plane_stride, P.pitch,
+                                           planes[(size_t)v * ppv + p], stride, P.W, P.H, hipMemcpyHostToDevice, x->s_h2d));
+        }
+        HIPCHK(x, hipEventRecord(x->ev_up[(size_t)slot], x->s_h2d));
+        HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_up[(size_t)slot], 0));
+        const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, x->stream));
+        if (rc) return rc;
+        HIPCHK(x, hipEventRecord(x->ev_done[(size_t)slot], x->stream));
+        HIPCHK(x, hipStreamWaitEvent(x->s_d2h, x->ev_done[(size_t)slot], 0));
+        if (xyz)
+            HIPCHK(x, hipMemcpy2DAsync(xyz + (size_t)v * P.W * P.H * 3, (size_t)P.W * 12, P.points + (size_t)slot * P.px_view_stride * 3,
+                                       (size_t)P.pitch * 12, (size_t)P.W * 12, P.H, hipMemcpyDeviceToHost, x->s_d2h));
+        if (valid)
+            HIPCHK(x, hipMemcpy2DAsync(valid + (size_t)v * P.W * P.H, P.W, P.valid + (size_t)slot * P.px_view_stride, P.pitch, P.W, P.H,
+                                       hipMemcpyDeviceToHost, x->s_d2h));
+        HIPCHK(x, hipEventRecord(x->ev_down[(size_t)slot], x->s_d2h));
+    }
+    HIPCHK(x, hipStreamSynchronize(x->s_d2h));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->s_h2d));
+    return SL3D_OK;
 }
 
 extern "C" int sl3d_compact(sl3d_ctx *x, int view, const float **device_xyz, int64_t *count)

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
+    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
     "sl3d_get_device_buffers",
 )
 
@@ -100,6 +100,11 @@ def load_library(path=None):
     L.sl3d_get_cloud_rgb.argtypes = [vp, i, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_compact.argtypes = [vp, i, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.sl3d_register_views.argtypes = [vp, i, i, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sl3d_host_alloc.restype = vp
+    L.sl3d_host_alloc.argtypes = [C.c_size_t]
+    L.sl3d_host_free.restype = None
+    L.sl3d_host_free.argtypes = [vp]
+    L.sl3d_process_views.argtypes = [vp, i, vp, C.c_size_t, vp, vp]
     L.sl3d_pattern_counts.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
     L.sl3d_generate_pattern.argtypes = [vp, i, i, i, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
@@ -139,6 +144,9 @@ class Scanner:
         if getattr(self, "_h", None):
             self.L.sl3d_destroy(self._h)
             self._h = None
+        for p in getattr(self, "_pinned", []):
+            self.L.sl3d_host_free(p)
+        self._pinned = []
 
     def __del__(self):
         try:
@@ -317,6 +325,28 @@ class Scanner:
         self._chk(self.L.sl3d_register_views(self._h, first_view, n_views, tx, ty, tz, rot_step, out.ctypes.data, n.value, C.byref(n)),
                   "sl3d_register_views")
         return out
+
+    def pinned(self, shape, dtype):
+        """numpy array in pinned host memory (sl3d_host_alloc); freed when the Scanner is closed."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.L.sl3d_host_alloc(n)
+        if not p:
+            raise Sl3dError("sl3d_host_alloc failed")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return np.frombuffer((C.c_char * n).from_address(p), dtype=dtype).reshape(shape)
+
+    def process_views(self, frames, xyz=None, valid=None):
+        """frames: (n_views, planes_per_view, H, W) uint8 host array (pinned for full overlap); returns (xyz, valid)."""
+        n, ppv, H, W = frames.shape
+        assert (H, W) == (self.H, self.W) and frames.dtype == np.uint8 and frames.strides[3] == 1 and frames.strides[2] >= W
+        if xyz is None:
+            xyz = np.empty((n, H, W, 3), dtype=np.float32)
+        if valid is None:
+            valid = np.empty((n, H, W), dtype=np.uint8)
+        ptrs = (C.c_void_p * (n * ppv))(*[frames[v, p].ctypes.data for v in range(n) for p in range(ppv)])
+        self._chk(self.L.sl3d_process_views(self._h, n, ptrs, frames.strides[2], xyz.ctypes.data, valid.ctypes.data), "sl3d_process_views")
+        return xyz, valid
 
     def generate_pattern(self, kind, axis, index):
         """One projector pattern of generate_pattern() (1/pattern_generator.cpp): (proj_height, proj_width) uint8."""

@@ -243,8 +243,8 @@ def main():
         try:
             cap0 = {"planes_v": sc.frames(0, 0), "planes_h": sc.frames(1, 0)}  # the very bytes the GPU processed
             out["cpu_baseline"] = cpu_baseline(args, cap0, cal, valid, xyz, None)
-            # what the C ABI delivers when the boundary hands over HOST buffers (never `value`): upload of the 46 frames of
-            # one view, one launch, download of xyz + valid, pageable numpy memory, median of 5
+            # what the C ABI delivers when the boundary hands over HOST buffers (never `value`):
+            # (a) serial: upload of the 46 frames of one view, one launch, download of xyz + valid, pageable numpy memory
             ts = []
             for _ in range(5):
                 t0 = time.perf_counter()
@@ -256,6 +256,23 @@ def main():
             t = sorted(ts)[2]
             out["host_buffers_one_view"] = {"value": round(W * rows / t / 1e6, 1), "unit": "Mpixels/s", "ms": round(t * 1e3, 2),
                                             "note": "H2D of 46 frames + launch + D2H of xyz and valid for ONE view, pageable host memory"}
+            # (b) pipelined: sl3d_process_views, 12 host-resident views through the view slots on three HIP streams, pinned memory
+            nv = 12
+            fr = sc.pinned((nv, 2 * (3 + 2 * N), rows, W), np.uint8)
+            fr[:] = np.stack(cap0["planes_v"] + cap0["planes_h"])[None]
+            px = sc.pinned((nv, rows, W, 3), np.float32)
+            pv = sc.pinned((nv, rows, W), np.uint8)
+            sc.process_views(fr, xyz=px, valid=pv)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                sc.process_views(fr, xyz=px, valid=pv)
+                ts.append(time.perf_counter() - t0)
+            t = sorted(ts)[1]
+            same = bool(np.array_equal(pv[nv - 1], valid) and np.array_equal(px[nv - 1], xyz, equal_nan=True))
+            out["host_buffers_pipelined"] = {"value": round(nv * W * rows / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_view": round(t / nv * 1e3, 2),
+                                             "note": f"{nv} host-resident views, upload / kernel / download overlapped on 3 streams, pinned memory",
+                                             "equals_resident_result": same}
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"error": repr(e)}
     sc.close()

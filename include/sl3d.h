@@ -218,6 +218,19 @@ int sl3d_get_clouds(sl3d_ctx *ctx, int first_view, int n_views, float *xyz, int6
 int sl3d_register_views(sl3d_ctx *ctx, int first_view, int n_views, float tx, float ty, float tz, float rot_step,
                         float *xyz, int64_t capacity, int64_t *total);
 
+/* ---- host-buffer pipeline -------------------------------------------------------------------- */
+/* The reference hands every stage host images (IplImage loaded from disk, 3/wrapped_phase.cpp:44, 4/phase_unwrap.cpp:78,84)
+ * and reads host arrays back.  For callers that stay on that side of the boundary, sl3d_process_views runs a batch of
+ * host-resident views through the context's view slots as a three-stage pipeline on three HIP streams (upload of view k+1,
+ * fused kernel of view k, download of view k-1 overlap), so the sustained rate is that of the slowest stage (the PCIe
+ * upload), not the sum.  planes: n_views * planes_per_view pointers, view-major, plane order of sl3d_device_buffers;
+ * xyz: n_views dense [height][width][3] float images, NaN where invalid (may be NULL); valid: n_views [height][width]
+ * byte images (may be NULL).  Masks and calibration must be set (sl3d_set_mask for every slot < max_views).
+ * sl3d_host_alloc returns pinned memory: with it the copies are asynchronous DMA (pageable memory works, serialised). */
+void *sl3d_host_alloc(size_t bytes);
+void sl3d_host_free(void *p);
+int sl3d_process_views(sl3d_ctx *ctx, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid);
+
 /* ---- projector patterns (1/pattern_generator.cpp) ------------------------------------------- */
 /* allocate_memory() 1/pattern_generator.cpp:224-229: number of codes = ceil(extent / fringe_width) and number of
  * Gray / binary bit planes = ceil(logf(codes) / logf(2)) (float arithmetic, as the reference writes it). Host only. */

@@ -313,6 +313,43 @@ def test_batch_of_views_matches_single_views():
     assert not np.array_equal(batch[0][0][batch[0][1] == 1][:100], batch[1][0][batch[1][1] == 1][:100])
 
 
+@pytest.mark.parametrize("W", [200, 224])  # 224: width == device pitch, a view goes up as one copy; 200: plane by plane
+def test_host_buffer_pipeline_matches_resident_path(W):
+    """sl3d_process_views: 7 host-resident views through 3 view slots (upload / kernel / download on three streams) give
+    exactly what the resident path gives view by view, with pinned and with pageable host memory, and a 1-slot context
+    degenerates to the serial order."""
+    syn = pkg("synth")
+    S = _scanner()
+    H, PW, PH, N, fw, NV = 120, 256, 192, 6, 8, 7
+    caps = [syn.make_capture(W, H, PW, PH, N, 5, fw, fw, plane=(2.0 * v, 0.05 - 0.004 * v, 0.04), view=v, noise=2) for v in range(NV)]
+    stack = np.stack([np.stack(c["planes_v"] + c["planes_h"]) for c in caps])
+    cal = syn.cal_tuple(caps[0]["cal"])
+    mask = caps[0]["mask"].copy()
+    mask[20:40, 50:80] = 0
+    ref = []
+    with S.Scanner(W, H, PW, PH, N, 5, fw, fw) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        for c in caps:
+            sc.set_frames(0, c["planes_v"])
+            sc.set_frames(1, c["planes_h"])
+            sc.run()
+            ref.append(sc.points())
+    for slots, pin in ((3, True), (3, False), (1, True)):
+        with S.Scanner(W, H, PW, PH, N, 5, fw, fw, max_views=slots) as sc:
+            sc.set_calibration(*cal)
+            for s_ in range(slots):
+                sc.set_mask(mask, view=s_)
+            frames = sc.pinned(stack.shape, np.uint8) if pin else stack.copy()
+            frames[...] = stack
+            xyz = sc.pinned((NV, H, W, 3), np.float32) if pin else None
+            for _ in range(2):  # the second batch reuses slots that still hold the first one's results
+                out_xyz, out_valid = sc.process_views(frames, xyz=xyz)
+                for v in range(NV):
+                    assert np.array_equal(out_valid[v], ref[v][1]), (slots, pin, v)
+                    assert np.array_equal(out_xyz[v], ref[v][0], equal_nan=True), (slots, pin, v)
+
+
 def test_two_contexts_are_independent():
     """SURVEY 8b threading row: contexts are independent of each other.  Two contexts of different shapes, rigs and
     modes on the same GPU with their calls interleaved give what each gives alone."""
