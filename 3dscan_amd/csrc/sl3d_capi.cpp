@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <set>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,8 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    uint8_t *d_und = nullptr;  // cvUndistort2 scratch: source image, result, maps (grown on demand)
+    size_t und_bytes = 0;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // sl3d_process_views: upload and download run beside the compute stream
     std::vector<hipEvent_t> ev_up, ev_done, ev_down;  // per view slot: frames landed / kernel finished / results copied out
     float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
@@ -929,6 +932,39 @@ extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, flo
         HIPCHK(x, hipMemcpyAsync(xyz, x->d_reg, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         HIPCHK(x, hipStreamSynchronize(x->stream));
     }
+    return SL3D_OK;
+}
+
+// ---- N4: cvUndistort2 (2/project_pattern.cpp:220,232,...) -------------------------------------------------------------
+extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride, int width, int height, int channels, const double K[9],
+                              const double dist[5], uint8_t *dst, size_t dst_stride)
+{
+    if (!x || !src || !dst || !K || !dist || width < 1 || height < 1 || (channels != 1 && channels != 3) || width > 32767 || height > 32767)
+        return fail(x, SL3D_E_INVALID_ARG, "undistort: null argument, size, or channels not 1 / 3");
+    const size_t row = (size_t)width * channels, img = (((row + 15) / 16) * 16) * (size_t)height;
+    if (src_stride < row || dst_stride < row) return fail(x, SL3D_E_INVALID_ARG, "undistort: stride < width*channels");
+    const size_t pitch = ((row + 15) / 16) * 16, maps = (size_t)width * height * 6, need = 2 * img + maps + 64;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    if (need > x->und_bytes) {
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+        if (x->d_und) {
+            (void)hipFree(x->d_und);
+            x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_und), x->allocs.end());
+            x->d_und = nullptr;
+            x->und_bytes = 0;
+        }
+        int rc = dev_alloc(x, &x->d_und, need);
+        if (rc) return rc;
+        x->und_bytes = need;
+    }
+    uint8_t *d_src = x->d_und, *d_dst = x->d_und + img;
+    short *m1 = (short *)(x->d_und + 2 * img);
+    unsigned short *m2 = (unsigned short *)(x->d_und + 2 * img + (size_t)width * height * 4);
+    HIPCHK(x, hipMemcpy2DAsync(d_src, pitch, src, src_stride, row, (size_t)height, hipMemcpyHostToDevice, x->stream));
+    int rc = launched(x, launch_undistort(d_src, pitch, d_dst, pitch, width, height, channels, K, dist, m1, m2, x->stream));
+    if (rc) return rc;
+    HIPCHK(x, hipMemcpy2DAsync(dst, dst_stride, d_dst, pitch, row, (size_t)height, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 

@@ -1092,6 +1092,102 @@ int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *st
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// N4: cvUndistort2 (2/project_pattern.cpp:220,232,...), OpenCV 2.4.0's algorithm (parity unpinned, see oracle/):
+// k_undist_map: one lane per image row.  The map of a row is a RECURRENCE along the row in OpenCV ((_x,_y,_w) advance
+//   by (ir0,ir3,ir6) per column, accumulated in double), so a row is walked sequentially to round exactly as it does;
+//   rows are independent (each restarts from i*ir1+ir2 ... of its stripe, whose matrix has cy - y0).
+// k_undist_remap: one lane per pixel, INTER_LINEAR in OpenCV's fixed point (1/32-pixel positions, weights summing to
+//   2^15), BORDER_CONSTANT 0.
+// This file is compiled with -ffp-contract=off and IEEE division, so the doubles round as on the host.
+// ------------------------------------------------------------------------------------------------
+struct UndistParams {
+    double K[9], d[5];
+    int width, height, cn, stripe;
+};
+
+__global__ __launch_bounds__(64) void k_undist_map(UndistParams U, short *__restrict__ m1, unsigned short *__restrict__ m2)
+{
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= U.height) return;
+    const int y0 = (row / U.stripe) * U.stripe, i = row - y0;
+    // iR = inverse of K with cy - y0: closed-form 3x3 (adjugate / determinant), the expressions of cvInvert's n == 3 case
+    double S[9];
+    for (int k = 0; k < 9; k++) S[k] = U.K[k];
+    S[5] = U.K[5] - y0;
+#define Sd(a, b) S[(a) * 3 + (b)]
+    double det = Sd(0, 0) * (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) - Sd(0, 1) * (Sd(1, 0) * Sd(2, 2) - Sd(1, 2) * Sd(2, 0)) +
+                 Sd(0, 2) * (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0));
+    double ir[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (det != 0.) {
+        det = 1. / det;
+        ir[0] = (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) * det;
+        ir[1] = (Sd(0, 2) * Sd(2, 1) - Sd(0, 1) * Sd(2, 2)) * det;
+        ir[2] = (Sd(0, 1) * Sd(1, 2) - Sd(0, 2) * Sd(1, 1)) * det;
+        ir[3] = (Sd(1, 2) * Sd(2, 0) - Sd(1, 0) * Sd(2, 2)) * det;
+        ir[4] = (Sd(0, 0) * Sd(2, 2) - Sd(0, 2) * Sd(2, 0)) * det;
+        ir[5] = (Sd(0, 2) * Sd(1, 0) - Sd(0, 0) * Sd(1, 2)) * det;
+        ir[6] = (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0)) * det;
+        ir[7] = (Sd(0, 1) * Sd(2, 0) - Sd(0, 0) * Sd(2, 1)) * det;
+        ir[8] = (Sd(0, 0) * Sd(1, 1) - Sd(0, 1) * Sd(1, 0)) * det;
+    }
+#undef Sd
+    const double u0 = U.K[2], v0 = U.K[5], fx = U.K[0], fy = U.K[4];
+    const double k1 = U.d[0], k2 = U.d[1], p1 = U.d[2], p2 = U.d[3], k3 = U.d[4];
+    double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+    short *r1 = m1 + (size_t)row * U.width * 2;
+    unsigned short *r2_ = m2 + (size_t)row * U.width;
+    for (int j = 0; j < U.width; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+        const double w = 1. / _w, x = _x * w, y = _y * w;
+        const double x2 = x * x, y2 = y * y;
+        const double r2 = x2 + y2, _2xy = 2 * x * y;
+        const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((0. * r2 + 0.) * r2 + 0.) * r2);
+        const double u = fx * (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)) + u0;
+        const double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy) + v0;
+        const int iu = __double2int_rn(u * 32), iv = __double2int_rn(v * 32);  // cvRound
+        r1[j * 2] = (short)(iu >> 5);
+        r1[j * 2 + 1] = (short)(iv >> 5);
+        r2_[j] = (unsigned short)((iv & 31) * 32 + (iu & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_undist_remap(const uint8_t *__restrict__ src, size_t sstride, UndistParams U, const short *__restrict__ m1,
+                                                      const unsigned short *__restrict__ m2, uint8_t *__restrict__ dst, size_t dstride)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= U.width) return;
+    const size_t o = (size_t)dy * U.width + dx;
+    const int sx = m1[2 * o], sy = m1[2 * o + 1], fxq = m2[o] & 31, fyq = (m2[o] >> 5) & 31;
+    int w[4] = {(32 - fyq) * (32 - fxq) * 32, (32 - fyq) * fxq * 32, fyq * (32 - fxq) * 32, fyq * fxq * 32};
+    if (w[0] == 32768) { w[0] = 32767; w[3] = 1; }  // saturate_cast<short>(32768) and the table's sum fix-up
+    for (int k = 0; k < U.cn; k++) {
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int xx = sx + (t & 1), yy = sy + (t >> 1);
+            const int v = (xx >= 0 && xx < U.width && yy >= 0 && yy < U.height) ? src[(size_t)yy * sstride + (size_t)xx * U.cn + k] : 0;
+            sum += v * w[t];
+        }
+        const int r = (sum + (1 << 14)) >> 15;
+        dst[(size_t)dy * dstride + (size_t)dx * U.cn + k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+    }
+}
+
+int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride, int width, int height, int cn, const double K[9],
+                     const double dist[5], short *m1, unsigned short *m2, void *stream)
+{
+    UndistParams U;
+    for (int k = 0; k < 9; k++) U.K[k] = K[k];
+    for (int k = 0; k < 5; k++) U.d[k] = dist[k];
+    U.width = width; U.height = height; U.cn = cn;
+    int stripe = 4096 / (width > 1 ? width : 1);
+    U.stripe = stripe < 1 ? 1 : (stripe > height ? height : stripe);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_undist_map, dim3((height + 63) / 64), dim3(64), 0, st, U, m1, m2);
+    hipLaunchKernelGGL(k_undist_remap, dim3((width + 255) / 256, height), dim3(256), 0, st, src, sstride, U, m1, m2, dst, dstride);
+    return (int)hipGetLastError();
+}
+
 // N1: one projector pattern (1/pattern_generator.cpp).  Every pattern is constant along one axis, so the host evaluates
 // the reference's expression once per column (or row) with the libm the reference calls (cosf, pow: sl3d_generate_pattern)
 // and this kernel replicates the profile: 16 bytes per lane, write-only, HBM bound (PW*PH bytes per pattern).

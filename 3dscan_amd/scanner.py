@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_pattern_counts", "sl3d_generate_pattern",
+    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_pattern_counts", "sl3d_generate_pattern",
     "sl3d_get_device_buffers",
 )
 
@@ -105,6 +105,7 @@ def load_library(path=None):
     L.sl3d_host_free.restype = None
     L.sl3d_host_free.argtypes = [vp]
     L.sl3d_process_views.argtypes = [vp, i, vp, C.c_size_t, vp, vp]
+    L.sl3d_undistort.argtypes = [vp, vp, C.c_size_t, i, i, i, vp, vp, vp, C.c_size_t]
     L.sl3d_pattern_counts.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
     L.sl3d_generate_pattern.argtypes = [vp, i, i, i, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
@@ -347,6 +348,17 @@ class Scanner:
         ptrs = (C.c_void_p * (n * ppv))(*[frames[v, p].ctypes.data for v in range(n) for p in range(ppv)])
         self._chk(self.L.sl3d_process_views(self._h, n, ptrs, frames.strides[2], xyz.ctypes.data, valid.ctypes.data), "sl3d_process_views")
         return xyz, valid
+
+    def undistort(self, image, K, dist):
+        """cvUndistort2 on an (H, W) or (H, W, 3) uint8 image (any size), on the device."""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        cn = 1 if a.ndim == 2 else a.shape[2]
+        out = np.empty_like(a)
+        Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).ravel())
+        dd = np.ascontiguousarray(np.asarray(dist, dtype=np.float64).ravel())
+        self._chk(self.L.sl3d_undistort(self._h, a.ctypes.data, a.strides[0], a.shape[1], a.shape[0], cn, Kd.ctypes.data, dd.ctypes.data,
+                                        out.ctypes.data, out.strides[0]), "sl3d_undistort")
+        return out
 
     def generate_pattern(self, kind, axis, index):
         """One projector pattern of generate_pattern() (1/pattern_generator.cpp): (proj_height, proj_width) uint8."""

@@ -231,6 +231,15 @@ void *sl3d_host_alloc(size_t bytes);
 void sl3d_host_free(void *p);
 int sl3d_process_views(sl3d_ctx *ctx, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid);
 
+/* ---- capture-side undistortion --------------------------------------------------------------- */
+/* cvUndistort2(src, dst, intrinsic_matrix, distortion_coeffs) as the acquisition stage applies it to every captured frame
+ * before it is saved for stage 3/4 (2/project_pattern.cpp:220,232,287,...): OpenCV 2.4.0's algorithm on the device --
+ * stripe-wise inverse map accumulated along each row in double, positions rounded to 1/32 pixel, INTER_LINEAR in 2^15
+ * fixed point, BORDER_CONSTANT 0.  8-bit images of 1 or 3 interleaved channels, any size; src and dst must not overlap.
+ * The arithmetic lives in OpenCV (not in the reference tree) and no raw capture is available: parity unpinned. */
+int sl3d_undistort(sl3d_ctx *ctx, const uint8_t *src, size_t src_stride, int width, int height, int channels, const double K[9],
+                   const double dist[5], uint8_t *dst, size_t dst_stride);
+
 /* ---- projector patterns (1/pattern_generator.cpp) ------------------------------------------- */
 /* allocate_memory() 1/pattern_generator.cpp:224-229: number of codes = ceil(extent / fringe_width) and number of
  * Gray / binary bit planes = ceil(logf(codes) / logf(2)) (float arithmetic, as the reference writes it). Host only. */

@@ -57,6 +57,7 @@ def _load():
         L.orc_get_undist_point.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.orc_run_scan.argtypes = [vp, vp, vp, C.c_size_t]
         L.orc_run_scan_rowmajor.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, vp]
+        L.orc_undistort.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t]
         L.orc_pattern_counts.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_pattern_profile.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.orc_pattern_image.argtypes = [C.c_int] * 8 + [vp]
@@ -227,6 +228,19 @@ def pattern_image(kind, axis, index, PW, PH, fringe_width, nplanes, F=3):
     L = _load()
     out = np.zeros((PH, PW), dtype=np.uint8)
     L.orc_pattern_image(int(kind), int(axis), int(F), int(index), int(PW), int(PH), int(fringe_width), int(nplanes), out.ctypes.data)
+    return out
+
+
+def undistort(src, K, dist):
+    """cvUndistort2(src, dst, K, dist) on an (H, W) or (H, W, 3) uint8 image (N4; parity unpinned, see orc_undistort)."""
+    L = _load()
+    a = np.ascontiguousarray(src, dtype=np.uint8)
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    H, W = a.shape[:2]
+    out = np.zeros_like(a)
+    Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).ravel())
+    dd = np.ascontiguousarray(np.asarray(dist, dtype=np.float64).ravel())
+    L.orc_undistort(a.ctypes.data, a.strides[0], W, H, cn, Kd.ctypes.data, dd.ctypes.data, out.ctypes.data, out.strides[0])
     return out
 
 

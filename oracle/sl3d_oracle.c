@@ -18,6 +18,7 @@
  *                              reference tree (un-vendored dependency, opencv 2.4.0 per
  *                              M_tech_project_console.cbp:55-58); they are restated here from
  *                              their published algorithms.
+ *   N4 cvUndistort2          : PARITY UNPINNED (OpenCV 2.4.0 arithmetic restated; no raw captures in the tree)
  *   N1 pattern generator     : PINNED  by Generated_patterns/... (every pixel of the 1280x720 fringe, Gray,
  *                              inverse-Gray and binary-coded pattern images)
  *   (tests/golden/make_golden.py replays the two pinned stages on the full
@@ -894,6 +895,84 @@ int orc_run_scan_rowmajor(orc_state *s, const unsigned char *const *planes_v, co
 #else
     return 1;
 #endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* N4: capture-side undistortion, cvUndistort2(src, dst, K, dist)             */
+/* (2/project_pattern.cpp:192,220,232,261,287,...).  PARITY UNPINNED: the     */
+/* arithmetic lives in OpenCV 2.4.0 (imgproc/undistort.cpp: cv::undistort,    */
+/* initUndistortRectifyMap; imgproc/imgwarp.cpp: remap, INTER_LINEAR fixed    */
+/* point), which is not in the reference tree, and the raw captures that the  */
+/* reference's Undistorted/ images came from are not in the tree either.      */
+/* Restated from the published algorithm:                                     */
+/*  - the image is processed in stripes of max(1, 4096 / width) rows; for the */
+/*    stripe starting at row y the new camera matrix is K with cy - y, and    */
+/*    iR = inverse of that matrix (closed-form 3x3, as cvInvert above);       */
+/*  - row i of the stripe starts at (_x,_y,_w) = (i*ir1+ir2, i*ir4+ir5,       */
+/*    i*ir7+ir8) and ADVANCES by (ir0, ir3, ir6) per column (accumulated, not */
+/*    recomputed); x = _x/_w, y = _y/_w go through the forward distortion     */
+/*    model (k1,k2,p1,p2,k3) to source coordinates (u,v) in double;           */
+/*  - (u,v) are rounded to 1/32 pixel: iu = lrint(u*32), iv = lrint(v*32);    */
+/*    the integer parts address the 2x2 source neighbourhood, the 5-bit       */
+/*    fractions pick weights round((1-fy)(1-fx)*32768) ... whose sum is 32768;*/
+/*  - result = (sum of weight*pixel + 16384) >> 15, BORDER_CONSTANT 0 outside.*/
+/* cn = 1 or 3 interleaved channels.                                          */
+/* ------------------------------------------------------------------------- */
+void orc_undistort_map_row(const double *K, const double *dist, int width, int y0, int i, short *m1 /* [width][2] */, unsigned short *m2 /* [width] */)
+{
+    double Ar[9];
+    memcpy(Ar, K, sizeof Ar);
+    Ar[5] = K[5] - y0; /* Ar(1,2) = v0 - y */
+    double ir[9];
+    invert3(Ar, ir);   /* (Ar * I).inv(DECOMP_LU) */
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4], k4 = 0, k5 = 0, k6 = 0;
+    double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+    for (int j = 0; j < width; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+        double w = 1. / _w, x = _x * w, y = _y * w;
+        double x2 = x * x, y2 = y * y;
+        double r2 = x2 + y2, _2xy = 2 * x * y;
+        double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+        double u = fx * (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)) + u0;
+        double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy) + v0;
+        int iu = (int)lrint(u * 32), iv = (int)lrint(v * 32); /* saturate_cast<int> = cvRound */
+        m1[j * 2] = (short)(iu >> 5);
+        m1[j * 2 + 1] = (short)(iv >> 5);
+        m2[j] = (unsigned short)((iv & 31) * 32 + (iu & 31));
+    }
+}
+
+void orc_undistort(const unsigned char *src, size_t sstride, int width, int height, int cn, const double *K, const double *dist,
+                   unsigned char *dst, size_t dstride)
+{
+    int stripe = 4096 / (width > 1 ? width : 1);
+    if (stripe < 1) stripe = 1;
+    if (stripe > height) stripe = height;
+    short *m1 = (short *)malloc(sizeof(short) * 2 * (size_t)width);
+    unsigned short *m2 = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)width);
+    for (int y0 = 0; y0 < height; y0 += stripe)
+        for (int i = 0; i < stripe && y0 + i < height; i++) {
+            orc_undistort_map_row(K, dist, width, y0, i, m1, m2);
+            unsigned char *D = dst + (size_t)(y0 + i) * dstride;
+            for (int dx = 0; dx < width; dx++) {
+                const int sx = m1[dx * 2], sy = m1[dx * 2 + 1], fxq = m2[dx] & 31, fyq = (m2[dx] >> 5) & 31;
+                /* BilinearTab_i: saturate_cast<short>(((1-fy)(1-fx)) * 32768) etc.; exact multiples of 32, except 32768 -> 32767
+                   with the +1 of the sum fix-up landing on the last weight (entry fx = fy = 0) */
+                int w[4] = {(32 - fyq) * (32 - fxq) * 32, (32 - fyq) * fxq * 32, fyq * (32 - fxq) * 32, fyq * fxq * 32};
+                if (w[0] == 32768) { w[0] = 32767; w[3] = 1; }
+                for (int k = 0; k < cn; k++) {
+                    int v[4];
+                    for (int t = 0; t < 4; t++) {
+                        const int xx = sx + (t & 1), yy = sy + (t >> 1);
+                        v[t] = (xx >= 0 && xx < width && yy >= 0 && yy < height) ? src[(size_t)yy * sstride + (size_t)xx * cn + k] : 0; /* BORDER_CONSTANT, 0 */
+                    }
+                    const int sum = v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                    int r = (sum + (1 << 14)) >> 15;
+                    D[(size_t)dx * cn + k] = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+                }
+            }
+        }
+    free(m1); free(m2);
 }
 
 /* One whole scan in main()'s order, m_tech_project_console.cpp:366-395:

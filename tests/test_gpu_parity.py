@@ -350,6 +350,27 @@ def test_host_buffer_pipeline_matches_resident_path(W):
                     assert np.array_equal(out_xyz[v], ref[v][0], equal_nan=True), (slots, pin, v)
 
 
+def test_undistort_matches_restated_opencv_algorithm():
+    """N4: sl3d_undistort == the oracle's restatement of OpenCV 2.4.0's cvUndistort2, byte for byte: 1 and 3 channels,
+    widths that give stripes of 1, 2 and many rows, a skewed K, tangential terms, maps that leave the image."""
+    from oracle import oracle as O
+    S = _scanner()
+    rng = np.random.default_rng(21)
+    with S.Scanner(64, 48, 64, 48, 5, 5, 2, 2) as sc:
+        for (H, W, cn), K, d in (
+                ((120, 160, 1), [150.0, 0, 80.0, 0, 152.0, 60.0, 0, 0, 1], [0.1, -0.05, 0.001, 0.0005, 0.01]),
+                ((75, 2049, 1), [1900.0, 0, 1020.3, 0, 1905.5, 36.2, 0, 0, 1], [-0.2, 0.07, 0, 0, 0]),        # stripe = 1 row... and 2
+                ((600, 800, 3), [1411.4, 0, 396.9, 0, 1418.2, 295.8, 0, 0, 1], [0.0813, -0.1102, 0, 0, 0]),   # the reference's camera, halved
+                ((97, 131, 3), [120.0, 0.7, 60.0, 0, 118.0, 50.0, 0, 0, 1], [0.3, -0.2, 0.004, -0.003, 0.05]),  # skew + tangential
+                ((64, 64, 1), [40.0, 0, 32.0, 0, 40.0, 32.0, 0, 0, 1], [-0.6, 0.1, 0, 0, 0]),                  # leaves the image
+        ):
+            img = rng.integers(0, 256, size=(H, W) if cn == 1 else (H, W, cn), dtype=np.uint8)
+            got = sc.undistort(img, K, d)
+            assert np.array_equal(got, O.undistort(img, K, d)), (H, W, cn)
+        with pytest.raises(S.Sl3dError):
+            sc.undistort(np.zeros((8, 8, 2), np.uint8), [1.0, 0, 0, 0, 1, 0, 0, 0, 1], [0] * 5)
+
+
 def test_two_contexts_are_independent():
     """SURVEY 8b threading row: contexts are independent of each other.  Two contexts of different shapes, rigs and
     modes on the same GPU with their calls interleaved give what each gives alone."""

@@ -267,3 +267,38 @@ def test_rowmajor_openmp_baseline_is_bit_identical():
             assert np.array_equal(valid == 1, v)
             assert np.array_equal(xyz[v], ref[v])
             assert np.isnan(xyz[~v]).all()
+
+
+def test_undistort_restatement_sanity():
+    """N4 (parity unpinned): the restated cvUndistort2 is the identity without distortion, stays within one grey level of
+    a float bilinear resampling of the same map on a smooth image, treats channels independently, and fills with 0 where
+    the map leaves the image."""
+    from oracle import oracle as O
+    H, W = 120, 160
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0)).astype(np.uint8)
+    K = [150.0, 0, 80.0, 0, 152.0, 60.0, 0, 0, 1]
+    d = [0.1, -0.05, 0.001, 0.0005, 0.01]
+    assert np.array_equal(O.undistort(img, K, [0, 0, 0, 0, 0]), img)
+    out = O.undistort(img, K, d)
+    fx, fy, cx, cy = K[0], K[4], K[2], K[5]
+    x, y = (xx - cx) / fx, (yy - cy) / fy
+    r2 = x * x + y * y
+    kr = 1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2
+    u = fx * (x * kr + d[2] * 2 * x * y + d[3] * (r2 + 2 * x * x)) + cx
+    v = fy * (y * kr + d[2] * (r2 + 2 * y * y) + d[3] * 2 * x * y) + cy
+    x0, y0 = np.floor(u).astype(int), np.floor(v).astype(int)
+    a, b = u - x0, v - y0
+
+    def g(r, c):
+        ok = (c >= 0) & (c < W) & (r >= 0) & (r < H)
+        return np.where(ok, img[np.clip(r, 0, H - 1), np.clip(c, 0, W - 1)], 0).astype(float)
+
+    ref = (1 - b) * ((1 - a) * g(y0, x0) + a * g(y0, x0 + 1)) + b * ((1 - a) * g(y0 + 1, x0) + a * g(y0 + 1, x0 + 1))
+    inside = (x0 >= 1) & (x0 + 2 < W) & (y0 >= 1) & (y0 + 2 < H)  # away from the hard 0 border, where 1/32 px moves a lot
+    assert inside.mean() > 0.8 and np.abs(out.astype(float) - ref)[inside].max() <= 1.0
+    c3 = np.stack([img, 255 - img, img // 2], -1)
+    o3 = O.undistort(c3, K, d)
+    assert np.array_equal(o3[..., 0], out) and np.array_equal(o3[..., 1], O.undistort(255 - img, K, d))
+    far = O.undistort(np.full((H, W), 200, np.uint8), K, [-0.9, 0.0, 0, 0, 0])  # strong barrel term: corners sample outside
+    assert far[H // 2, W // 2] == 200
