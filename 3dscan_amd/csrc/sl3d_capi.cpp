@@ -42,8 +42,10 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
-    uint8_t *d_und = nullptr;  // cvUndistort2 scratch: source image, result, maps (grown on demand)
+    uint8_t *d_und = nullptr;  // cvUndistort2 scratch: maps, source image, result (grown on demand)
     size_t und_bytes = 0;
+    double und_key[16] = {0};  // K, dist, width, height of the map held in d_und (the 46 frames of a view share one map)
+    bool und_map_valid = false;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // sl3d_process_views: upload and download run beside the compute stream
     std::vector<hipEvent_t> ev_up, ev_done, ev_down;  // per view slot: frames landed / kernel finished / results copied out
     float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
@@ -943,7 +945,7 @@ extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride
         return fail(x, SL3D_E_INVALID_ARG, "undistort: null argument, size, or channels not 1 / 3");
     const size_t row = (size_t)width * channels, img = (((row + 15) / 16) * 16) * (size_t)height;
     if (src_stride < row || dst_stride < row) return fail(x, SL3D_E_INVALID_ARG, "undistort: stride < width*channels");
-    const size_t pitch = ((row + 15) / 16) * 16, maps = (size_t)width * height * 6, need = 2 * img + maps + 64;
+    const size_t pitch = ((row + 15) / 16) * 16, maps = (size_t)width * height * 6, need = 2 * img + maps + 128;
     HIPCHK(x, hipSetDevice(x->cfg.device));
     if (need > x->und_bytes) {
         HIPCHK(x, hipStreamSynchronize(x->stream));
@@ -952,17 +954,27 @@ extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride
             x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_und), x->allocs.end());
             x->d_und = nullptr;
             x->und_bytes = 0;
+            x->und_map_valid = false;
         }
         int rc = dev_alloc(x, &x->d_und, need);
         if (rc) return rc;
         x->und_bytes = need;
+        x->und_map_valid = false;
     }
-    uint8_t *d_src = x->d_und, *d_dst = x->d_und + img;
-    short *m1 = (short *)(x->d_und + 2 * img);
-    unsigned short *m2 = (unsigned short *)(x->d_und + 2 * img + (size_t)width * height * 4);
+    // layout: maps first (they survive from call to call), then the source and the result image
+    short *m1 = (short *)x->d_und;
+    unsigned short *m2 = (unsigned short *)(x->d_und + (size_t)width * height * 4);
+    uint8_t *d_src = x->d_und + ((maps + 63) / 64) * 64, *d_dst = d_src + img;
+    double key[16];
+    for (int k = 0; k < 9; k++) key[k] = K[k];
+    for (int k = 0; k < 5; k++) key[9 + k] = dist[k];
+    key[14] = width; key[15] = height;
+    const bool build = !x->und_map_valid || memcmp(key, x->und_key, sizeof key) != 0;
     HIPCHK(x, hipMemcpy2DAsync(d_src, pitch, src, src_stride, row, (size_t)height, hipMemcpyHostToDevice, x->stream));
-    int rc = launched(x, launch_undistort(d_src, pitch, d_dst, pitch, width, height, channels, K, dist, m1, m2, x->stream));
+    int rc = launched(x, launch_undistort(d_src, pitch, d_dst, pitch, width, height, channels, K, dist, m1, m2, build, x->stream));
     if (rc) return rc;
+    memcpy(x->und_key, key, sizeof key);
+    x->und_map_valid = true;
     HIPCHK(x, hipMemcpy2DAsync(dst, dst_stride, d_dst, pitch, row, (size_t)height, hipMemcpyDeviceToHost, x->stream));
     HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;

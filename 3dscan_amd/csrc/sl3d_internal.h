@@ -99,7 +99,7 @@ int launch_compact_views(const KParams &P, int first_view, int n_views, unsigned
 int launch_register(const float *in, float *out, long n, const float R4[4], float tx, float ty, float tz, void *stream);
 int launch_synth(const KParams &P, const DevCal &C, const SynthParams &S, int view, void *stream);
 int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride, int width, int height, int cn, const double K[9],
-                     const double dist[5], short *m1, unsigned short *m2, void *stream);
+                     const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream);
 int launch_pattern(uint8_t *dst, size_t pitch, int PW, int PH, int axis, const uint8_t *profile, void *stream);
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 

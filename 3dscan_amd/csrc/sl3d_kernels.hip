@@ -1173,8 +1173,9 @@ __global__ __launch_bounds__(256) void k_undist_remap(const uint8_t *__restrict_
     }
 }
 
+// build_map = false: m1 / m2 already hold the map of this (K, dist, width, height) -- every frame of a scan shares it
 int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride, int width, int height, int cn, const double K[9],
-                     const double dist[5], short *m1, unsigned short *m2, void *stream)
+                     const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream)
 {
     UndistParams U;
     for (int k = 0; k < 9; k++) U.K[k] = K[k];
@@ -1183,7 +1184,7 @@ int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t ds
     int stripe = 4096 / (width > 1 ? width : 1);
     U.stripe = stripe < 1 ? 1 : (stripe > height ? height : stripe);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_undist_map, dim3((height + 63) / 64), dim3(64), 0, st, U, m1, m2);
+    if (build_map) hipLaunchKernelGGL(k_undist_map, dim3((height + 63) / 64), dim3(64), 0, st, U, m1, m2);
     hipLaunchKernelGGL(k_undist_remap, dim3((width + 255) / 256, height), dim3(256), 0, st, src, sstride, U, m1, m2, dst, dstride);
     return (int)hipGetLastError();
 }

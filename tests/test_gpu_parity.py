@@ -367,6 +367,10 @@ def test_undistort_matches_restated_opencv_algorithm():
             img = rng.integers(0, 256, size=(H, W) if cn == 1 else (H, W, cn), dtype=np.uint8)
             got = sc.undistort(img, K, d)
             assert np.array_equal(got, O.undistort(img, K, d)), (H, W, cn)
+            img2 = rng.integers(0, 256, size=img.shape, dtype=np.uint8)   # same calibration and size: the cached map is reused
+            assert np.array_equal(sc.undistort(img2, K, d), O.undistort(img2, K, d)), (H, W, cn, "cached map")
+            d2 = list(d); d2[0] += 0.01                                    # another calibration: the map is rebuilt
+            assert np.array_equal(sc.undistort(img2, K, d2), O.undistort(img2, K, d2)), (H, W, cn, "new map")
         with pytest.raises(S.Sl3dError):
             sc.undistort(np.zeros((8, 8, 2), np.uint8), [1.0, 0, 0, 0, 1, 0, 0, 0, 1], [0] * 5)
 
