@@ -42,6 +42,9 @@ struct sl3d_ctx {
     unsigned long long *d_total = nullptr;
     float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
     float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    uint8_t *d_raw = nullptr;  // sl3d_set_frames_raw: the raw planes of one axis + the camera's undistortion map
+    bool raw_map_valid = false;
+    double Kc_raw[9] = {0}, dc_raw[5] = {0};  // the camera intrinsics the raw path undistorts with (set_calibration)
     uint8_t *d_und = nullptr;  // cvUndistort2 scratch: maps, source image, result (grown on demand)
     size_t und_bytes = 0;
     double und_key[16] = {0};  // K, dist, width, height of the map held in d_und (the 46 frames of a view share one map)
@@ -342,6 +345,9 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     projection_matrix(Kc, rc, tc, x->C.Ac);
     projection_matrix(Kp, rp, tp, x->C.Ap);
     fill_intr(x->C.cam, Kc, dc);
+    memcpy(x->Kc_raw, Kc, sizeof x->Kc_raw);
+    memcpy(x->dc_raw, dc, sizeof x->dc_raw);
+    x->raw_map_valid = false;
     fill_intr(x->C.proj, Kp, dp);
     rodrigues(rc, x->S.Rc);
     rodrigues(rp, x->S.Rp);
@@ -468,6 +474,45 @@ extern "C" int sl3d_set_frames(sl3d_ctx *x, int view, int axis, const uint8_t *c
     return SL3D_OK;
 }
 
+static int launched(sl3d_ctx *x, int hip_err);
+
+// sl3d_set_frames for RAW captures: what the acquisition stage does between the camera and the files stage 3/4 read
+// (cvUndistort2 with the camera calibration, 2/project_pattern.cpp:220,232,287,...) happens on the device, one launch for
+// all planes of the axis with the camera's map (built once per calibration).  Whole frames only: a window or a row stripe
+// would need source rows from outside itself.
+extern "C" int sl3d_set_frames_raw(sl3d_ctx *x, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    const KParams &P = x->P;
+    const int N = axis == 0 ? P.Nv : P.Nh;
+    if ((axis != 0 && axis != 1) || !planes || n_planes != P.F + 2 * N || stride < (size_t)P.W)
+        return fail(x, SL3D_E_INVALID_ARG, "set_frames_raw: expected n_fringe + 2*n_gray planes (fringe, gray, inverse) and stride >= width");
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "set_frames_raw before set_calibration");
+    if (P.W != P.fullW || P.H != P.fullH) return fail(x, SL3D_E_UNSUPPORTED, "set_frames_raw: whole frames only (no window / stripe)");
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    const size_t maps = (((size_t)P.W * P.H * 6 + 63) / 64) * 64, max_planes = (size_t)P.F + 2 * (size_t)std::max(P.Nv, P.Nh);
+    if (!x->d_raw) {
+        rc = dev_alloc(x, &x->d_raw, maps + max_planes * P.plane_stride);
+        if (rc) return rc;
+    }
+    short *m1 = (short *)x->d_raw;
+    unsigned short *m2 = (unsigned short *)(x->d_raw + (size_t)P.W * P.H * 4);
+    uint8_t *raw = x->d_raw + maps;
+    for (int i = 0; i < n_planes; i++) {
+        if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames_raw: null plane");
+        HIPCHK(x, hipMemcpy2DAsync(raw + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+    }
+    const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
+    uint8_t *dst = x->d_frames + (size_t)view * P.view_stride + (size_t)base * P.plane_stride;
+    rc = launched(x, launch_undistort_planes(raw, P.pitch, P.plane_stride, dst, P.pitch, P.plane_stride, P.W, P.H, n_planes, x->Kc_raw, x->dc_raw, m1, m2,
+                                             !x->raw_map_valid, x->stream));
+    if (rc) return rc;
+    x->raw_map_valid = true;
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+
 extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
 {
     int rc = check_view(x, src);
@@ -484,7 +529,6 @@ extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
     return SL3D_OK;
 }
 
-static int launched(sl3d_ctx *x, int hip_err);
 
 // Synthetic capture of one view written straight into the resident frame stack (N1; formulas of
 // 1/pattern_generator.cpp:80-105,302,313,497 -- see k_synth).  Benchmark / test input, not part of the timed path.

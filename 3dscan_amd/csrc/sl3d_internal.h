@@ -100,6 +100,8 @@ int launch_register(const float *in, float *out, long n, const float R4[4], floa
 int launch_synth(const KParams &P, const DevCal &C, const SynthParams &S, int view, void *stream);
 int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride, int width, int height, int cn, const double K[9],
                      const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream);
+int launch_undistort_planes(const uint8_t *src, size_t spitch, size_t splane, uint8_t *dst, size_t dpitch, size_t dplane, int width, int height,
+                            int n_planes, const double K[9], const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream);
 int launch_pattern(uint8_t *dst, size_t pitch, int PW, int PH, int axis, const uint8_t *profile, void *stream);
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 

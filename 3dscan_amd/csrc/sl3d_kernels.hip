@@ -1173,6 +1173,50 @@ __global__ __launch_bounds__(256) void k_undist_remap(const uint8_t *__restrict_
     }
 }
 
+// the same remap for a stack of single-channel planes that share one map (the frames of a view): the map entry and the four
+// weights are read / formed once per pixel, then every plane costs 4 taps and one byte
+__global__ __launch_bounds__(256) void k_undist_remap_planes(const uint8_t *__restrict__ src, size_t spitch, size_t splane, int width, int height,
+                                                             int n_planes, const short *__restrict__ m1, const unsigned short *__restrict__ m2,
+                                                             uint8_t *__restrict__ dst, size_t dpitch, size_t dplane)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= width) return;
+    const size_t o = (size_t)dy * width + dx;
+    const int sx = m1[2 * o], sy = m1[2 * o + 1], fxq = m2[o] & 31, fyq = (m2[o] >> 5) & 31;
+    int w[4] = {(32 - fyq) * (32 - fxq) * 32, (32 - fyq) * fxq * 32, fyq * (32 - fxq) * 32, fyq * fxq * 32};
+    if (w[0] == 32768) { w[0] = 32767; w[3] = 1; }
+    size_t off[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int xx = sx + (t & 1), yy = sy + (t >> 1);
+        const bool in = xx >= 0 && xx < width && yy >= 0 && yy < height;
+        off[t] = in ? (size_t)yy * spitch + (size_t)xx : 0;
+        if (!in) w[t] = 0;  // BORDER_CONSTANT 0: the tap contributes nothing
+    }
+    for (int p = 0; p < n_planes; p++) {
+        const uint8_t *sp = src + (size_t)p * splane;
+        const int sum = sp[off[0]] * w[0] + sp[off[1]] * w[1] + sp[off[2]] * w[2] + sp[off[3]] * w[3];
+        const int r = (sum + (1 << 14)) >> 15;
+        dst[(size_t)p * dplane + (size_t)dy * dpitch + dx] = (uint8_t)(r > 255 ? 255 : r);
+    }
+}
+
+int launch_undistort_planes(const uint8_t *src, size_t spitch, size_t splane, uint8_t *dst, size_t dpitch, size_t dplane, int width, int height,
+                            int n_planes, const double K[9], const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream)
+{
+    UndistParams U;
+    for (int k = 0; k < 9; k++) U.K[k] = K[k];
+    for (int k = 0; k < 5; k++) U.d[k] = dist[k];
+    U.width = width; U.height = height; U.cn = 1;
+    int stripe = 4096 / (width > 1 ? width : 1);
+    U.stripe = stripe < 1 ? 1 : (stripe > height ? height : stripe);
+    hipStream_t st = (hipStream_t)stream;
+    if (build_map) hipLaunchKernelGGL(k_undist_map, dim3((height + 63) / 64), dim3(64), 0, st, U, m1, m2);
+    hipLaunchKernelGGL(k_undist_remap_planes, dim3((width + 255) / 256, height), dim3(256), 0, st, src, spitch, splane, width, height, n_planes, m1, m2,
+                       dst, dpitch, dplane);
+    return (int)hipGetLastError();
+}
+
 // build_map = false: m1 / m2 already hold the map of this (K, dist, width, height) -- every frame of a scan shares it
 int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride, int width, int height, int cn, const double K[9],
                      const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream)

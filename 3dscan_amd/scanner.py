@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_pattern_counts", "sl3d_generate_pattern",
+    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
     "sl3d_get_device_buffers",
 )
 
@@ -105,6 +105,7 @@ def load_library(path=None):
     L.sl3d_host_free.restype = None
     L.sl3d_host_free.argtypes = [vp]
     L.sl3d_process_views.argtypes = [vp, i, vp, C.c_size_t, vp, vp]
+    L.sl3d_set_frames_raw.argtypes = [vp, i, i, vp, i, C.c_size_t]
     L.sl3d_undistort.argtypes = [vp, vp, C.c_size_t, i, i, i, vp, vp, vp, C.c_size_t]
     L.sl3d_pattern_counts.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
     L.sl3d_generate_pattern.argtypes = [vp, i, i, i, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -182,6 +183,14 @@ class Scanner:
             assert a.shape == (self.H, self.W), a.shape
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         self._chk(self.L.sl3d_set_frames(self._h, view, axis, ptrs, len(arrs), arrs[0].strides[0]), "sl3d_set_frames")
+
+    def set_frames_raw(self, axis, planes, view=0):
+        """set_frames for raw captures: undistorted on the device with the camera calibration (whole frames only)."""
+        arrs = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+        for a in arrs:
+            assert a.shape == (self.H, self.W), a.shape
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._chk(self.L.sl3d_set_frames_raw(self._h, view, axis, ptrs, len(arrs), arrs[0].strides[0]), "sl3d_set_frames_raw")
 
     def synth_view(self, view=0, plane=(0.0, 0.05, 0.05), seed=0x3D5CA11, view_id=None, noise=0, gain=0.8, offset=10.0):
         """Synthetic capture generated on the device into slot `view` (see 3dscan_amd/synth.py for the host twin)."""

@@ -240,6 +240,11 @@ int sl3d_process_views(sl3d_ctx *ctx, int n_views, const uint8_t *const *planes,
 int sl3d_undistort(sl3d_ctx *ctx, const uint8_t *src, size_t src_stride, int width, int height, int channels, const double K[9],
                    const double dist[5], uint8_t *dst, size_t dst_stride);
 
+/* sl3d_set_frames for RAW captures: the frames go through cvUndistort2 with the camera calibration of sl3d_set_calibration
+ * on their way into the frame stack (one launch for all planes of the axis, the map is built once per calibration), i.e.
+ * the step 2/project_pattern.cpp:220,232,287 performs before stage 3/4 read the images.  Whole frames only. */
+int sl3d_set_frames_raw(sl3d_ctx *ctx, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride);
+
 /* ---- projector patterns (1/pattern_generator.cpp) ------------------------------------------- */
 /* allocate_memory() 1/pattern_generator.cpp:224-229: number of codes = ceil(extent / fringe_width) and number of
  * Gray / binary bit planes = ceil(logf(codes) / logf(2)) (float arithmetic, as the reference writes it). Host only. */

@@ -375,6 +375,43 @@ def test_undistort_matches_restated_opencv_algorithm():
             sc.undistort(np.zeros((8, 8, 2), np.uint8), [1.0, 0, 0, 0, 1, 0, 0, 0, 1], [0] * 5)
 
 
+def test_raw_frames_path_equals_undistort_then_set_frames():
+    """sl3d_set_frames_raw == cvUndistort2 (oracle restatement) of every plane with the camera calibration, then the
+    normal path: the frame stack holds the same bytes and the scan gives the same points; re-calibration rebuilds the map."""
+    from oracle import oracle as O
+    syn = pkg("synth")
+    S = _scanner()
+    W, H, PW, PH, N, fw = 200, 120, 256, 192, 6, 8
+    cap = syn.make_capture(W, H, PW, PH, N, 5, fw, fw, noise=2)
+    rng = np.random.default_rng(9)
+    raw_v = [rng.integers(0, 256, size=(H, W), dtype=np.uint8) for _ in cap["planes_v"]]  # any bytes will do for the byte check
+    raw_h = [np.ascontiguousarray(p[:, ::-1]) for p in cap["planes_h"]]
+    cal = {k: np.array(v, dtype=np.float64).copy() for k, v in cap["cal"].items()}
+    with S.Scanner(W, H, PW, PH, N, 5, fw, fw) as sc, S.Scanner(W, H, PW, PH, N, 5, fw, fw) as ref:
+        for dc in ([0.0813, -0.1102, 0.0, 0.0, 0.0], [0.2, -0.1, 0.002, -0.001, 0.03]):
+            cal["dc"] = np.array(dc)
+            ct = syn.cal_tuple(cal)
+            for s_ in (sc, ref):
+                s_.set_calibration(*ct)
+                s_.set_mask(cap["mask"])
+            sc.set_frames_raw(0, raw_v)
+            sc.set_frames_raw(1, raw_h)
+            und_v = [O.undistort(p, cal["Kc"], cal["dc"]) for p in raw_v]
+            und_h = [O.undistort(p, cal["Kc"], cal["dc"]) for p in raw_h]
+            for got, exp in zip(sc.frames(0, 0) + sc.frames(1, 0), und_v + und_h):
+                assert np.array_equal(got, exp)
+            ref.set_frames(0, und_v)
+            ref.set_frames(1, und_h)
+            sc.run()
+            ref.run()
+            a, b = sc.points(), ref.points()
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
+    with S.Scanner(W, 60, PW, PH, N, 5, fw, fw, full_size=(W, H), origin=(0, 30)) as stripe:
+        stripe.set_calibration(*syn.cal_tuple(cal))
+        with pytest.raises(S.Sl3dError):
+            stripe.set_frames_raw(0, [p[30:90] for p in raw_v])
+
+
 def test_two_contexts_are_independent():
     """SURVEY 8b threading row: contexts are independent of each other.  Two contexts of different shapes, rigs and
     modes on the same GPU with their calls interleaved give what each gives alone."""
