@@ -35,6 +35,9 @@
 #ifndef SL3D_OCC
 #define SL3D_OCC 4 /* waves per SIMD the fused kernel is compiled for */
 #endif
+#ifndef SL3D_BLOCK
+#define SL3D_BLOCK 256 /* threads per block of the fused kernel (tools/ab.sh: 128 and 512 measured) */
+#endif
 // 1: the fused kernel reads 1/d of the atan2 quotient from an LDS table (6 KB per block); 0: v_rcp_f64 + one Newton step
 #ifndef SL3D_RCP_LDS
 #define SL3D_RCP_LDS 1
@@ -632,10 +635,10 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 //
 // FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
 template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG>
-__global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+__global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
-    __shared__ __attribute__((aligned(16))) float s_xyz[256 * 12];
-    __shared__ __attribute__((aligned(16))) double s_cam[256 * 8];  // undistorted camera coordinates of the lane's 4 pixels
+    __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];
+    __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_LDS ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
     if (SL3D_RCP_LDS) {
         fill_rcp_table(s_rcp);
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256, SL3D_OCC) void k_fused(const KParams P, const 
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
     // gridDim.x is a multiple of 8 (launch_fused), so blockIdx.x % 8 is the XCD whatever blockIdx.y is
     const unsigned tile = SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const long q = (long)tile * 256 + threadIdx.x;
+    const long q = (long)tile * SL3D_BLOCK + threadIdx.x;
     const int row = (int)(q / qpr), cq = (int)(q - (long)row * qpr);
     if (row >= P.H) return;
     const int gx0 = P.col0 + cq * 4, gy = P.row0 + row;
@@ -922,13 +925,13 @@ static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st
 int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, void *stream)
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
-    const unsigned bx = ((unsigned)((quads + 255) / 256) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
+    const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
     // views per lane: as many as possible (amortises the camera undistortion) while the grid still
     // has >= ~8 blocks per CU to balance the tail
     int vpt = 1;
     while (vpt < 8 && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
     if (getenv("SL3D_VPT")) vpt = atoi(getenv("SL3D_VPT"));
-    dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(256, 1, 1);
+    dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(SL3D_BLOCK, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     if (keep) {
         if (P.F == 3) launch_fused_n<true, false, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
