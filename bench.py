@@ -86,7 +86,10 @@ def cpu_baseline(args, cap, cal, gpu_valid, gpu_xyz, gpu_cp_note):
     ph = [p[:rows] for p in cap["planes_h"]]
     syn = importlib.import_module("3dscan_amd.synth")
     mask = syn.default_mask(W, H)[:rows]
-    o = Oracle(W, rows, W, H, args.ngray, args.ngray, args.fringe_width, args.fringe_width)
+    # above 2^24 pixels the reference's float pixel index (7/triangulation.cpp:264-265) goes wrong; the product uses integer
+    # rows / columns, so the oracle is asked for the same there
+    big = W * H > (1 << 24)
+    o = Oracle(W, rows, W, H, args.ngray, args.ngray, args.fringe_width, args.fringe_width, exact_index=big)
     o.set_mask(mask)
     o.set_calibration(*cal)
     times = []

@@ -412,6 +412,41 @@ def test_raw_frames_path_equals_undistort_then_set_frames():
             stripe.set_frames_raw(0, [p[30:90] for p in raw_v])
 
 
+def test_above_2p24_pixels_integer_pixel_indices():
+    """BASELINE config 5's shape (8192x6144 camera and projector, N = 12): the reference indexes its stage-7 tables with
+    floorf((float)f / (float)W) (7/triangulation.cpp:264-265), which is wrong above 2^24 pixels.  The product uses integer
+    rows / columns: it equals the oracle run with exact indices (to the float rounding of the output).  The oracle that
+    reproduces the reference's float index puts the first / last columns of projector rows beyond 2^24 / PW in the wrong
+    row (float(f) is only exact to +-2 there), which is visible in its table and in any correspondence that lands there."""
+    syn = pkg("synth")
+    S = _scanner()
+    W, H, N, fw, rows, row0 = 8192, 6144, 12, 2, 24, 3000   # a stripe whose projector rows lie beyond 2^24 / PW = 2048
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    mask = syn.default_mask(W, H)
+    with S.Scanner(W, rows, W, H, N, N, fw, fw, full_size=(W, H), origin=(0, row0)) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        sc.synth_view(0, plane=(0.0, 0.05, 0.05), view_id=0, noise=2)
+        sc.run()
+        xyz, valid = sc.points()
+        pv, ph = sc.frames(0), sc.frames(1)
+    I = np.s_[3:rows - 3]  # the oracle treats the stripe as its own image: skip its first and last rows
+    worst, edge = {}, {}
+    for exact in (True, False):
+        o = Oracle(W, rows, W, H, N, N, fw, fw, exact_index=exact, row0=row0)
+        o.set_mask(mask[row0:row0 + rows])
+        o.set_calibration(*cal)
+        o.run_scan(pv, ph)
+        v = o.valid_map(2) == 1
+        assert np.array_equal(valid[I] == 1, v[I])
+        ref, got = o.intersection_points()[I][v[I]], xyz[I][v[I]].astype(np.float64)
+        worst[exact] = float(np.max(np.linalg.norm(got - ref, axis=-1) / np.linalg.norm(ref, axis=-1)))
+        edge[exact] = o.undist_point(1, W - 1, 3001)  # projector pixel (8191, 3001): index 24,592,383 > 2^24
+        del o
+    assert worst[True] < 2e-7, worst
+    assert abs(edge[True][1] - edge[False][1]) > 0.5, edge  # the reference's float index is a row off there
+
+
 def test_two_contexts_are_independent():
     """SURVEY 8b threading row: contexts are independent of each other.  Two contexts of different shapes, rigs and
     modes on the same GPU with their calls interleaved give what each gives alone."""
