@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box:  tools/profile.sh <tag>
+# Runs on the GPU box:  tools/profile.sh <tag> [extra bench.py arguments, e.g. --width 4096 --height 3000 --fringe-width 4 --views 3]
 #  1. rocprofv3 --kernel-trace --stats of the default bench command (per-kernel average duration)
 #  2. separate --pmc passes (no tracing domains beside --kernel-trace) for FETCH_SIZE and WRITE_SIZE on the bench
 #     and on tools/membench (known byte counts, same access widths) to calibrate the gfx950 counter units
@@ -7,11 +7,13 @@
 # Everything lands in gpurun_out/profile_<tag>/; tools/summarize_profile.py turns it into profiles/<tag>_*.
 set -u
 TAG=${1:-r01}
+shift || true
+EXTRA="$*"
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline"   # PMC passes: counters do not depend on the clocks
-BENCH_STEADY="python3 bench.py --no-cpu-baseline"                    # stats pass: the steady-state defaults (300 + 2000 launches)
+BENCH="python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline $EXTRA"   # PMC passes: counters do not depend on the clocks
+BENCH_STEADY="python3 bench.py --no-cpu-baseline $EXTRA"                    # stats pass: the steady-state defaults (300 + 2000 launches)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH_STEADY > $OUT/stats_bench.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   n=$(echo $c | tr " " "_" | cut -c1-30)

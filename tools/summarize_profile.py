@@ -52,9 +52,15 @@ if "FETCH_SIZE" in mem and "WRITE_SIZE" in mem:
     if "FETCH_SIZE" in bench and "WRITE_SIZE" in bench:
         rd = bench["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KiB"]
         wr = bench["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KiB"]
-        px_launch = 16 * 1920 * 1080
+        # pixels and algorithmic bytes per launch of the profiled command: from the bench line saved next to the stats
+        px_launch, bpp = 16 * 1920 * 1080, 60
+        try:
+            bl = json.loads(open(f"{src}/stats_bench.json").read())
+            px_launch, bpp = bl["roofline"]["pixels_per_launch"], bl["roofline"]["algorithmic_bytes_per_pixel"]
+        except Exception:
+            pass
         traffic = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                   "algorithmic_bytes_per_launch": 60 * px_launch, "ratio_to_algorithmic": (rd + wr) / (60 * px_launch),
+                   "algorithmic_bytes_per_launch": bpp * px_launch, "ratio_to_algorithmic": (rd + wr) / (bpp * px_launch),
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); gfx950 counts a wide "
                              "coalesced read at half its bytes and leaves other widths uncalibrated, so both counters are scaled by "
                              "the factors measured on tools/membench mode 0 (same access widths, known byte counts) in the same session",
