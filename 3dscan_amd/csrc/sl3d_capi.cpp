@@ -1024,6 +1024,28 @@ extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride
     return SL3D_OK;
 }
 
+// One cloud of 9/register_point_clouds.cpp:83-128 that lives in host memory (the reference reads each from a PLY file):
+// p -> R_y(theta) * (p - t) + t with the reference's float / double-accumulator arithmetic (k_register), theta in degrees
+// converted with Pi = 22/7.  The caller advances theta by rot_step IN FLOAT from cloud to cloud, as :145 does.
+extern "C" int sl3d_transform_cloud(sl3d_ctx *x, const float *xyz_in, int64_t n, float theta_deg, float tx, float ty, float tz, float *xyz_out)
+{
+    if (!x || n < 0 || (n > 0 && (!xyz_in || !xyz_out))) return fail(x, SL3D_E_INVALID_ARG, "transform_cloud: null argument");
+    if (n == 0) return SL3D_OK;
+    HIPCHK(x, hipSetDevice(x->cfg.device));
+    float *d = nullptr;
+    HIPCHK(x, hipMalloc((void **)&d, (size_t)n * 6 * sizeof(float)));
+    const float theta = theta_deg;
+    const float R4[4] = {(float)cos(theta * 22.0 / 7.0 / 180.0), (float)(-1.0f * sin(theta * 22.0 / 7.0 / 180.0)),
+                         (float)sin(theta * 22.0 / 7.0 / 180.0), (float)cos(theta * 22.0 / 7.0 / 180.0)};
+    hipError_t e = hipMemcpyAsync(d, xyz_in, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, x->stream);
+    int rc = e == hipSuccess ? launch_register(d, d + 3 * (size_t)n, (long)n, R4, tx, ty, tz, x->stream) : (int)e;
+    if (rc == 0) rc = (int)hipMemcpyAsync(xyz_out, d + 3 * (size_t)n, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream);
+    if (rc == 0) rc = (int)hipStreamSynchronize(x->stream);
+    (void)hipFree(d);
+    if (rc) return fail(x, SL3D_E_HIP, std::string("transform_cloud: ") + hipGetErrorString((hipError_t)rc));
+    return SL3D_OK;
+}
+
 // ---- N1: projector patterns (1/pattern_generator.cpp) ---------------------------------------------------------------
 #define PI_REF 22.0 / 7.0 /* PROJECT_GLOBAL/global_cv.h:62: unparenthesised on purpose */
 

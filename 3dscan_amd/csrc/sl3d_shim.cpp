@@ -466,3 +466,81 @@ void save_point_cloud(unsigned cloud_index)
     fclose(f);
     fprintf(stderr, "Saved %lld data points to %s.pcd / .ply\n", (long long)n, base.c_str());
 }
+
+
+// ---- stage 9: register_point_clouds() -------------------------------------------------------------------
+// 9/register_point_clouds.cpp:23-155: Point_cloud/point_cloud_<i>.ply, i = 0..n-1, each rotated about the Y axis through
+// (tx,ty,tz) by theta_i (theta_0 = 0, theta_{i+1} = theta_i + rot_step in float, degrees with Pi = 22/7), colours kept,
+// concatenated into Point_cloud/registered_point_cloud.ply.  Reads the ASCII PLY files save_point_cloud() writes (vertex
+// properties x y z [red green blue] in any order, other properties ignored); the rotation runs on the device.
+namespace {
+struct PlyCloud {
+    std::vector<float> xyz;
+    std::vector<uint8_t> rgb;
+};
+bool read_ply_ascii(const std::string &path, PlyCloud &c)
+{
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char line[512];
+    long nv = -1;
+    std::vector<std::string> props;
+    bool ascii = false, in_vertex = false, header_ok = false;
+    while (fgets(line, sizeof line, f)) {
+        char a[64] = "", b[64] = "", d[64] = "";
+        const int k = sscanf(line, "%63s %63s %63s", a, b, d);
+        if (k >= 1 && !strcmp(a, "end_header")) { header_ok = true; break; }
+        if (k >= 2 && !strcmp(a, "format")) ascii = !strcmp(b, "ascii");
+        if (k >= 3 && !strcmp(a, "element")) { in_vertex = !strcmp(b, "vertex"); if (in_vertex) nv = atol(d); }
+        if (k >= 3 && !strcmp(a, "property") && in_vertex && strcmp(b, "list")) props.push_back(d);
+    }
+    if (!header_ok || !ascii || nv < 0) { fclose(f); return false; }
+    int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1;
+    for (int i = 0; i < (int)props.size(); i++) {
+        if (props[i] == "x") ix = i; else if (props[i] == "y") iy = i; else if (props[i] == "z") iz = i;
+        else if (props[i] == "red" || props[i] == "r") ir = i; else if (props[i] == "green" || props[i] == "g") ig = i;
+        else if (props[i] == "blue" || props[i] == "b") ib = i;
+    }
+    if (ix < 0 || iy < 0 || iz < 0) { fclose(f); return false; }
+    c.xyz.resize((size_t)nv * 3);
+    c.rgb.assign((size_t)nv * 3, 0);
+    std::vector<double> v(props.size());
+    for (long p = 0; p < nv; p++) {
+        for (size_t i = 0; i < props.size(); i++)
+            if (fscanf(f, "%lf", &v[i]) != 1) { fclose(f); return false; }
+        c.xyz[3 * p] = (float)v[ix]; c.xyz[3 * p + 1] = (float)v[iy]; c.xyz[3 * p + 2] = (float)v[iz];
+        if (ir >= 0 && ig >= 0 && ib >= 0) { c.rgb[3 * p] = (uint8_t)v[ir]; c.rgb[3 * p + 1] = (uint8_t)v[ig]; c.rgb[3 * p + 2] = (uint8_t)v[ib]; }
+    }
+    fclose(f);
+    return true;
+}
+}  // namespace
+
+void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float tz, float rot_step)
+{
+    g.status = SL3D_OK;
+    if (!ensure_ctx()) return;
+    std::vector<float> all_xyz;
+    std::vector<uint8_t> all_rgb;
+    float theta = 0.0;  // :79
+    for (unsigned i = 0; i < num_point_clouds; i++) {
+        PlyCloud c;
+        const std::string path = data_root() + "/Point_cloud/point_cloud_" + std::to_string(i) + ".ply";
+        if (!read_ply_ascii(path, c)) { fail(SL3D_E_INVALID_ARG, "cannot read " + path + " (ASCII PLY with x y z vertex properties)"); return; }
+        const int64_t n = (int64_t)c.xyz.size() / 3;
+        std::vector<float> out((size_t)n * 3);
+        if (!ok(sl3d_transform_cloud(g.ctx, c.xyz.data(), n, theta, tx, ty, tz, out.data()), "sl3d_transform_cloud")) return;
+        all_xyz.insert(all_xyz.end(), out.begin(), out.end());
+        all_rgb.insert(all_rgb.end(), c.rgb.begin(), c.rgb.end());
+        theta += rot_step;  // :145
+    }
+    const std::string outp = data_root() + "/Point_cloud/registered_point_cloud.ply";
+    FILE *f = fopen(outp.c_str(), "w");
+    if (!f) { fail(SL3D_E_INVALID_ARG, "cannot write " + outp); return; }
+    const long long n = (long long)all_xyz.size() / 3;
+    fprintf(f, "ply\nformat ascii 1.0\ncomment generated by sl3d (3dscan_amd)\nelement vertex %lld\nproperty float x\nproperty float y\n"
+               "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", n);
+    for (long long i = 0; i < n; i++)
+        fprintf(f, "%.9g %.9g %.9g %u %u %u\n", all_xyz[3 * i], all_xyz[3 * i + 1], all_xyz[3 * i + 2], all_rgb[3 * i], all_rgb[3 * i + 1], all_rgb[3 * i + 2]);
+    fclose(f);
+}

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
-    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
+    "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
     "sl3d_get_device_buffers",
 )
 
@@ -109,6 +109,7 @@ def load_library(path=None):
     L.sl3d_undistort.argtypes = [vp, vp, C.c_size_t, i, i, i, vp, vp, vp, C.c_size_t]
     L.sl3d_pattern_counts.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
     L.sl3d_generate_pattern.argtypes = [vp, i, i, i, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.sl3d_transform_cloud.argtypes = [vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
     if path is None:
         _lib = L
@@ -373,6 +374,12 @@ class Scanner:
         """One projector pattern of generate_pattern() (1/pattern_generator.cpp): (proj_height, proj_width) uint8."""
         out = np.empty((self.cfg.proj_height, self.cfg.proj_width), dtype=np.uint8)
         self._chk(self.L.sl3d_generate_pattern(self._h, kind, axis, index, out.ctypes.data, out.strides[0], None, None), "sl3d_generate_pattern")
+        return out
+
+    def transform_cloud(self, xyz, theta_deg, tx, ty, tz):
+        a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.empty_like(a)
+        self._chk(self.L.sl3d_transform_cloud(self._h, a.ctypes.data, len(a), theta_deg, tx, ty, tz, out.ctypes.data), "sl3d_transform_cloud")
         return out
 
     def device_buffers(self):

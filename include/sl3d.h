@@ -263,6 +263,10 @@ int sl3d_pattern_counts(int proj_extent, int fringe_width, int *n_codes, int *n_
 int sl3d_generate_pattern(sl3d_ctx *ctx, int kind, int axis, int index, uint8_t *host_dst, size_t stride,
                           const uint8_t **device_ptr, size_t *device_pitch);
 
+/* one cloud of register_point_clouds() (9/register_point_clouds.cpp:83-128) given in host memory, as the reference reads
+ * it from a PLY file: p -> R_y(theta)*(p - t) + t in the reference's arithmetic; theta in degrees (Pi = 22/7) */
+int sl3d_transform_cloud(sl3d_ctx *ctx, const float *xyz_in, int64_t n, float theta_deg, float tx, float ty, float tz, float *xyz_out);
+
 /* ---- device-resident access ---------------------------------------------------------------- */
 /* Frames may be produced in place (frames buffer) and points / valid consumed in place.  The mask buffer is exposed for
  * inspection only: set masks through sl3d_set_mask, which also normalises the bytes to 0/1 and evaluates the quads within

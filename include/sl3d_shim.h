@@ -59,6 +59,10 @@ void save_point_cloud(unsigned cloud_index);  /* 8/save_point_cloud.cpp:19: Poin
                                                  (device compaction + colour gather of the last triangulate(); standard PCD / PLY
                                                  ASCII text, not PCL 1.6's exact bytes) */
 
+void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float tz, float rot_step); /* 9/register_point_clouds.cpp:23:
+                                                 Point_cloud/point_cloud_<i>.ply (the ASCII files save_point_cloud() writes) ->
+                                                 Point_cloud/registered_point_cloud.ply, rotation on the device */
+
 /* ---- shim configuration (not in the reference) ----
  * The reference reads its inputs from hard-coded paths: absolute /home/pranav/Desktop/M_tech_project_console/...
  * in stages 3 and 7 (3/wrapped_phase.cpp:39-50, 7/triangulation.cpp:152-167,1069-1082), relative paths in

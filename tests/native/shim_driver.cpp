@@ -2,6 +2,7 @@
 // and selected_region, calls the four stage functions in main()'s order through the drop-in shim, and dumps
 // the reference-layout global arrays to a binary file for the Python test to compare with the oracle.
 //   shim_driver <data_root> <out.bin> Nv Nh fwv fwh ncv nch
+//   shim_driver register <data_root> n tx ty tz rot_step : register_point_clouds() only (9/register_point_clouds.cpp:23)
 //   shim_driver patterns <data_root> F fwv fwh      : generate_pattern() only (1/pattern_generator.cpp:513); prints the counts
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,12 @@
 
 int main(int argc, char **argv)
 {
+    if (argc >= 8 && std::string(argv[1]) == "register") {
+        sl3d_shim_set_data_root(argv[2]);
+        register_point_clouds((unsigned)atoi(argv[3]), (float)atof(argv[4]), (float)atof(argv[5]), (float)atof(argv[6]), (float)atof(argv[7]));
+        if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 30; }
+        return 0;
+    }
     if (argc >= 6 && std::string(argv[1]) == "patterns") {
         sl3d_shim_set_data_root(argv[2]);
         number_of_patterns_fringe = atoi(argv[3]);

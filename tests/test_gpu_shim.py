@@ -155,3 +155,41 @@ def test_shim_generate_pattern_reproduces_reference_files(tmp_path):
         raw = open(f"{root}/Generated_patterns/{rel}", "rb").read()
         assert raw[:1078] == fx["bmp_header"].tobytes(), rel
         assert hashlib.sha256(raw).hexdigest() == h, rel
+
+
+def test_shim_register_point_clouds_files(tmp_path):
+    """register_point_clouds() through the shim: reads Point_cloud/point_cloud_<i>.ply (ASCII, as save_point_cloud() writes
+    them), rotates cloud i by i*rot_step on the device, writes registered_point_cloud.ply; equal to the oracle's restatement
+    of 9/register_point_clouds.cpp:83-148 bit for bit, colours carried along."""
+    from oracle.oracle import register_point_clouds as orc_register
+    rng = np.random.default_rng(17)
+    root = str(tmp_path)
+    os.makedirs(f"{root}/Point_cloud")
+    clouds, cols = [], []
+    for i, n in enumerate((1500, 0, 733)):
+        xyz = (rng.standard_normal((n, 3)) * 40 + [60, 35, -2]).astype(np.float32)
+        rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+        with open(f"{root}/Point_cloud/point_cloud_{i}.ply", "w") as f:
+            f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                    "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n)
+            for p, c in zip(xyz, rgb):
+                f.write("%.9g %.9g %.9g %d %d %d\n" % (*p, *c))
+        clouds.append(xyz)
+        cols.append(rgb)
+    exe = f"{root}/shim_driver"
+    csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
+    defs = ["-DCamera_imagewidth=64", "-DCamera_imageheight=48", "-DProjector_imagewidth=64", "-DProjector_imageheight=48"]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *defs, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "shim_driver.cpp"), os.path.join(csrc, "sl3d_shim.cpp"),
+                           os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"), "-lsl3d",
+                           "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
+    tx, ty, tz, step = 60.0, 35.0, -2.0, 12.5
+    r = subprocess.run([exe, "register", root, "3", str(tx), str(ty), str(tz), str(step)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = orc_register(clouds, tx, ty, tz, step)
+    ply = open(f"{root}/Point_cloud/registered_point_cloud.ply").read().split("\n")
+    k = ply.index("end_header")
+    assert f"element vertex {len(exp)}" in ply[:k]
+    rows = np.array([ln.split() for ln in ply[k + 1:] if ln])
+    assert np.array_equal(rows[:, :3].astype(np.float32), exp)
+    assert np.array_equal(rows[:, 3:].astype(np.uint8), np.concatenate(cols))
