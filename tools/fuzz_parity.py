@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU: random camera / projector sizes, windows (crops and row stripes of a larger frame),
+Gray depths, fringe widths, fringe counts, masks, noise and rigs; every case compares the timed fused kernel (points, valid)
+and the parity mode (codes, phases, correspondences) with the oracle.   python tools/fuzz_parity.py [cases] [seed]"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+from oracle.oracle import Oracle
+syn = importlib.import_module("3dscan_amd.synth"); S = importlib.import_module("3dscan_amd.scanner")
+
+def close(xyz, ref, v):
+    if not v.any():
+        return 0.0
+    a, b = xyz[v].astype(np.float64), ref[v]
+    return float(np.max(np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)))
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for case in range(cases):
+        fullW, fullH = int(rng.integers(5, 400)), int(rng.integers(5, 200))
+        if rng.random() < 0.5:
+            W, H, col0, row0 = fullW, fullH, 0, 0
+        else:  # a window: column origin multiple of 4 (one lane = 4 pixels), any row origin
+            col0 = int(rng.integers(0, max(1, fullW // 8))) * 4
+            row0 = int(rng.integers(0, max(1, fullH // 2)))
+            W, H = int(rng.integers(1, fullW - col0 + 1)), int(rng.integers(1, fullH - row0 + 1))
+        Nv, Nh = int(rng.integers(1, 13)), int(rng.integers(1, 13))
+        fwv, fwh = int(rng.choice([1, 2, 3, 4, 8, 32])), int(rng.choice([1, 2, 3, 5, 16]))
+        PW = int(min(fwv * (1 << Nv), rng.integers(4, 3000)))
+        PH = int(min(fwh * (1 << Nh), rng.integers(4, 2000)))
+        F = int(rng.choice([3, 3, 3, 4, 5]))
+        noise = int(rng.integers(0, 40))
+        cap = syn.make_capture(W, H, PW, PH, Nv, Nh, fwv, fwh, n_fringe=F, noise=noise, col0=col0, row0=row0, full=(fullW, fullH),
+                               plane=(float(rng.uniform(-20, 20)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2))))
+        full_mask = (rng.random((fullH, fullW)) < rng.choice([0.5, 0.9, 0.99, 1.0])).astype(np.uint8)
+        if rng.random() < 0.3:
+            full_mask[:] = rng.integers(0, 3, size=full_mask.shape)  # values other than 0/1 count as unselected
+        cal = {k: np.array(v, dtype=np.float64).copy() for k, v in cap["cal"].items()}
+        rig = int(rng.integers(0, 3))
+        if rig >= 1:
+            cal["dp"] = np.array([0.05, -0.02, 0.001, -0.0005, 0.01]) * rng.uniform(0, 1)
+        if rig == 2:
+            cal["Kc"][1] = rng.uniform(-0.5, 0.5)  # skew: the general path
+        ct = syn.cal_tuple(cal)
+        o = Oracle(W, H, PW, PH, Nv, Nh, fwv, fwh, F=F, col0=col0, row0=row0)
+        # the oracle sees the window as its own image: give it the window of the mask, compare away from the window's edge
+        o.set_mask(full_mask[row0:row0 + H, col0:col0 + W])
+        o.set_calibration(*ct)
+        o.run_scan(cap["planes_v"], cap["planes_h"])
+        inner = np.zeros((H, W), bool)
+        lo_r, hi_r = (0 if row0 == 0 else 3), (H if row0 + H == fullH else H - 3)
+        lo_c, hi_c = (0 if col0 == 0 else 3), (W if col0 + W == fullW else W - 3)
+        if hi_r > lo_r and hi_c > lo_c:
+            inner[lo_r:hi_r, lo_c:hi_c] = True
+        msg = []
+        for keep in (False, True):
+            with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, n_fringe=F, keep_stages=keep, full_size=(fullW, fullH), origin=(col0, row0)) as sc:
+                sc.set_calibration(*ct)
+                sc.set_mask(full_mask)
+                sc.set_frames(0, cap["planes_v"])
+                sc.set_frames(1, cap["planes_h"])
+                sc.run()
+                xyz, valid = sc.points()
+                v = (o.valid_map(2) == 1) & inner
+                if not np.array_equal((valid == 1) & inner, v):
+                    msg.append(f"keep={keep}: valid map differs on {int(((valid == 1) & inner != v).sum())} px")
+                    continue
+                e = close(xyz, o.intersection_points(), v)
+                if e > 1e-5:
+                    msg.append(f"keep={keep}: point error {e:.3g}")
+                if keep:
+                    for a in (0, 1):
+                        va = (o.valid_map(a) == 1) & inner
+                        if not np.array_equal(sc.code(a)[va], o.code(a)[va]): msg.append(f"code axis {a}")
+                        if not np.array_equal(sc.unwrapped_phase(a)[va], o.unwrapped_phi(a)[va]): msg.append(f"unwrapped axis {a}")
+                    if not np.array_equal(sc.c_p_map()[v], o.c_p_map()[v]): msg.append("c_p_map")
+        tag = f"case {case}: full {fullW}x{fullH} window {W}x{H}@({col0},{row0}) proj {PW}x{PH} N {Nv}/{Nh} fw {fwv}/{fwh} F {F} noise {noise} rig {rig} valid {int((o.valid_map(2) == 1).sum())}"
+        if msg:
+            bad += 1
+            print("FAIL", tag, msg, flush=True)
+        del o
+    print(f"{cases} cases, {bad} failures")
+    return 1 if bad else 0
+
+if __name__ == "__main__":
+    sys.exit(main())
