@@ -770,8 +770,8 @@ void orc_pattern_image(int kind, int axis, int F, int index, int PW, int PH, int
 /* (so its results are bit-identical to orc_run_scan's: tests/test_oracle.py), */
 /* but fused, without the [col][row] arrays, without the per-scan stage-7      */
 /* tables (T1 is evaluated for the two points a pixel needs) and with shifts   */
-/* for the powers of two.  The boundary removal stays the literal sequential   */
-/* scan (it is scan-order dependent).  xyz: [H][W][3] float, NaN where invalid;*/
+/* for the powers of two, and with the boundary removal in its order-free      */
+/* closed form (rows in parallel).  xyz: [H][W][3] float, NaN where invalid;   */
 /* valid: [H][W].  threads <= 0: all cores.                                    */
 /* ------------------------------------------------------------------------- */
 #ifdef _OPENMP
@@ -797,31 +797,43 @@ int orc_run_scan_rowmajor(orc_state *s, const unsigned char *const *planes_v, co
 {
     const int W = s->c.W, H = s->c.H, F = s->c.F, PW = s->c.PW, PH = s->c.PH;
     if (F != 3 && F != 4) return -1;
-    /* S3b + S3d once (both axes start from the same selection): literal scan on a row-major copy */
-    unsigned char *vm = (unsigned char *)malloc((size_t)W * H), *visited = (unsigned char *)calloc((size_t)W * H, 1);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    /* S3b + S3d once (both axes start from the same selection).  The literal scan (erode_valid_map above) is order
+       dependent; its closed form (tests/test_oracle.py::test_boundary_removal_closed_form checks the equivalence) is not,
+       so the rows can be evaluated in parallel:  V = selected, later(q) = {E,SW,S,SE}, earlier(q) = {NW,N,NE,W},
+       L(q) = some later neighbour unselected, B(q) = some earlier neighbour is an unselected frame-border pixel,
+       interior p: valid = V(p) & !L(p) & AND_{n in earlier(p)} [V(n) | (interior(n) & (L(n) | B(n)))];  border p: valid = V(p) */
+    unsigned char *sel = (unsigned char *)malloc((size_t)W * H), *vm = (unsigned char *)malloc((size_t)W * H);
+#pragma omp parallel for schedule(static)
     for (int r = 0; r < H; r++)
-        for (int c = 0; c < W; c++) vm[(size_t)r * W + c] = s->selected_region[IDX(s, c, r)] == 1;
-#define VM(u, y) vm[(size_t)(y) * W + (u)]
-#define VS(u, y) visited[(size_t)(y) * W + (u)]
-    for (int y = 1; y < H - 1; y++)
-        for (int u = 1; u < W - 1; u++)
-            if ((!VM(u - 1, y - 1) && !VS(u - 1, y - 1)) || (!VM(u, y - 1) && !VS(u, y - 1)) || (!VM(u + 1, y - 1) && !VS(u + 1, y - 1)) ||
-                (!VM(u - 1, y) && !VS(u - 1, y)) || (!VM(u + 1, y) && !VS(u + 1, y)) || (!VM(u - 1, y + 1) && !VS(u - 1, y + 1)) ||
-                (!VM(u, y + 1) && !VS(u, y + 1)) || (!VM(u + 1, y + 1) && !VS(u + 1, y + 1))) {
-                VM(u, y) = 0;
-                VS(u, y) = 1;
-            }
-#undef VM
-#undef VS
-    free(visited);
+        for (int c = 0; c < W; c++) sel[(size_t)r * W + c] = s->selected_region[IDX(s, c, r)] == 1;
+#define V_(x, y) (sel[(size_t)(y) * W + (x)])
+#define INT_(x, y) ((x) >= 1 && (x) <= W - 2 && (y) >= 1 && (y) <= H - 2)
+#define L_(x, y) (!V_((x) + 1, (y)) || !V_((x) - 1, (y) + 1) || !V_((x), (y) + 1) || !V_((x) + 1, (y) + 1))
+#define BU_(x, y) (!INT_((x), (y)) && !V_((x), (y)))
+#define B_(x, y) (BU_((x) - 1, (y) - 1) || BU_((x), (y) - 1) || BU_((x) + 1, (y) - 1) || BU_((x) - 1, (y)))
+#define OK_(x, y) (V_((x), (y)) || (INT_((x), (y)) && (L_((x), (y)) || B_((x), (y)))))
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int u = 0; u < W; u++) {
+            unsigned char ok = V_(u, y);
+            if (ok && INT_(u, y)) ok = !L_(u, y) && OK_(u - 1, y - 1) && OK_(u, y - 1) && OK_(u + 1, y - 1) && OK_(u - 1, y);
+            vm[(size_t)y * W + u] = ok;
+        }
+#undef V_
+#undef INT_
+#undef L_
+#undef BU_
+#undef B_
+#undef OK_
+    free(sel);
     double A_cam[12], A_proj[12];
     compute_A(s->Kc, s->rc, s->tc, A_cam);
     compute_A(s->Kp, s->rp, s->tp, A_proj);
     const unsigned char *const *gv = planes_v + F, *const *iv = planes_v + F + s->c.N_v;
     const unsigned char *const *gh = planes_h + F, *const *ih = planes_h + F + s->c.N_h;
-#ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(threads);
-#endif
     const float nanf_ = nanf("");
 #pragma omp parallel for schedule(dynamic, 8)
     for (int r = 0; r < H; r++) {
