@@ -302,3 +302,53 @@ def test_undistort_restatement_sanity():
     assert np.array_equal(o3[..., 0], out) and np.array_equal(o3[..., 1], O.undistort(255 - img, K, d))
     far = O.undistort(np.full((H, W), 200, np.uint8), K, [-0.9, 0.0, 0, 0, 0])  # strong barrel term: corners sample outside
     assert far[H // 2, W // 2] == 200
+
+
+def test_restated_opencv_routines_against_independent_implementations():
+    """Stage 7 calls OpenCV routines that are not in the reference tree; the oracle restates them.  Independent checks:
+    cvRodrigues2 + cvGEMM (T0: A = K [R|t]) against scipy's rotation-vector conversion, cvUndistortPoints against the
+    forward Brown model it inverts (5 fixed-point iterations converge to ~1e-9 px for the reference's coefficients),
+    cvInvert + the literal (P^T P)^-1 P^T F of T3 against numpy's least squares."""
+    from scipy.spatial.transform import Rotation
+    ct, _ = golden_calibration()
+    cal = dict(zip(("Kc", "dc", "rc", "tc", "Kp", "dp", "rp", "tp"), ct))
+    o = Oracle(64, 48, 1280, 720, 6, 5, 32, 32)
+    o.set_calibration(*ct)
+    A_cam, A_proj = (np.array(a).reshape(3, 4) for a in o.projection_matrices())
+    for A, K, r, t in ((A_cam, cal["Kc"], cal["rc"], cal["tc"]), (A_proj, cal["Kp"], cal["rp"], cal["tp"])):
+        Rm = Rotation.from_rotvec(np.array(r)).as_matrix()
+        ref = np.array(K).reshape(3, 3) @ np.hstack([Rm, np.array(t).reshape(3, 1)])
+        assert np.allclose(A, ref, rtol=1e-13, atol=1e-10)
+    # undistort_point + re-projection (T1): distorting the result with the forward model returns the pixel
+    K, d = np.array(cal["Kc"]).reshape(3, 3), np.array(cal["dc"])
+    for col, row in ((0, 0), (63, 47), (10, 40), (33, 7)):
+        u, v = o.undist_point(0, col, row)[:2]
+        x, y = (u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1]
+        r2 = x * x + y * y
+        kr = 1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2
+        xd = x * kr + 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x)
+        yd = y * kr + d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y
+        assert abs(K[0, 0] * xd + K[0, 2] - col) < 1e-6 and abs(K[1, 1] * yd + K[1, 2] - row) < 1e-6
+    # T2 + T3 on a synthetic scan: every valid point is numpy's least-squares solution of its 4x3 system
+    from conftest import pkg
+    syn = pkg("synth")
+    W, H, PW, PH, N, fw = 96, 64, 128, 96, 5, 4
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw)
+    o2 = Oracle(W, H, PW, PH, N, N, fw, fw)
+    o2.set_mask(cap["mask"])
+    ct = syn.cal_tuple(cap["cal"])
+    o2.set_calibration(*ct)
+    o2.run_scan(cap["planes_v"], cap["planes_h"])
+    Ac, Ap = (np.array(a).reshape(3, 4) for a in o2.projection_matrices())
+    v = o2.valid_map(2) == 1
+    cp, pts = o2.c_p_map(), o2.intersection_points()
+    rng = np.random.default_rng(0)
+    ys, xs = np.nonzero(v)
+    for k in rng.choice(len(ys), size=40, replace=False):
+        r, c = ys[k], xs[k]
+        cu, cv = o2.undist_point(0, c, r)[:2]
+        pu, pv = o2.undist_point(1, int(cp[r, c, 0]), int(cp[r, c, 1]))[:2]
+        P = np.array([Ac[0, :3] - cu * Ac[2, :3], Ac[1, :3] - cv * Ac[2, :3], Ap[0, :3] - pu * Ap[2, :3], Ap[1, :3] - pv * Ap[2, :3]])
+        F = np.array([Ac[2, 3] * cu - Ac[0, 3], Ac[2, 3] * cv - Ac[1, 3], Ap[2, 3] * pu - Ap[0, 3], Ap[2, 3] * pv - Ap[1, 3]])
+        X = np.linalg.lstsq(P, F, rcond=None)[0]
+        assert np.linalg.norm(X - pts[r, c]) <= 1e-9 * max(1.0, np.linalg.norm(X))
