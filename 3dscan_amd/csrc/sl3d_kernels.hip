@@ -936,8 +936,10 @@ int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view,
     if (keep) {
         if (P.F == 3) launch_fused_n<true, false, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
         else launch_fused_n<true, true, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (P.F != 3) {
-        launch_fused_n<false, true, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+    } else if (P.F != 3) {  // 4-step (and the all-invalid 5-step) fringes: the F test stays a run-time branch
+        if (rig == 1) launch_fused_n<false, true, 1>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else if (rig == 2 && P.proj_disp) launch_fused_n<false, true, 2>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<false, true, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (rig == 1) {
         launch_fused_n<false, false, 1>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (rig == 2 && P.proj_disp) {
