@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity run on the GPU: random camera / projector sizes, windows (crops and row stripes of a larger frame),
 Gray depths, fringe widths, fringe counts, masks, noise and rigs; every case compares the timed fused kernel (points, valid)
-and the parity mode (codes, phases, correspondences) with the oracle.   python tools/fuzz_parity.py [cases] [seed]"""
+and the parity mode (codes, phases, correspondences) with the oracle.   python tests/fuzz_parity.py [cases] [seed]
+(lives under tests/: it imports the oracle, which only tests, smoke() and the bench's cpu_baseline leg may do)"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

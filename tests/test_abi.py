@@ -61,6 +61,11 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "sl3d_kernels.hip" and "tests/test_oracle.py" in txt, f
+    # the measurement tools may not use it either (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert "from oracle" not in txt and "import oracle" not in txt and "oracle." not in txt, f
 
 
 def test_pattern_counts_host_function():

@@ -677,14 +677,14 @@ def test_projector_patterns_match_oracle_and_reference():
 
 
 def test_randomised_configurations():
-    """tools/fuzz_parity.py: 120 random combinations of frame / window / projector sizes, Gray depths, fringe widths and
+    """tests/fuzz_parity.py: 120 random combinations of frame / window / projector sizes, Gray depths, fringe widths and
     counts, masks (including bytes other than 0/1), noise and rigs, timed and parity mode against the oracle
     (1200 cases over three other seeds were run clean when this was written)."""
     import importlib.util
     import os
     import sys
     from conftest import ROOT
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tests", "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     argv = sys.argv
