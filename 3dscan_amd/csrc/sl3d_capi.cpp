@@ -17,68 +17,16 @@
 #include <string>
 #include <vector>
 
-#include "../../include/sl3d.h"
-#include "sl3d_internal.h"
-
-using namespace sl3d;
-
-struct sl3d_ctx {
-    sl3d_config cfg{};
-    KParams P{};
-    DevCal C{};
-    SynthParams S{};  // extrinsics kept for the synthetic-capture generator
-    bool have_cal = false;
-    int rig = 0;
-    bool keep = false;
-    bool own_stream = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<void *> allocs;
-    std::string err;
-    uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
-    float *d_points = nullptr;
-    unsigned *d_blk_cnt = nullptr;            // compaction scratch: per-1024-pixel block counts,
-    unsigned long long *d_blk_off = nullptr;  // their exclusive scan, and the total
-    unsigned long long *d_total = nullptr;
-    float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
-    float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
-    uint8_t *d_raw = nullptr;  // sl3d_set_frames_raw: the raw planes of one axis + the camera's undistortion map
-    bool raw_map_valid = false;
-    double Kc_raw[9] = {0}, dc_raw[5] = {0};  // the camera intrinsics the raw path undistorts with (set_calibration)
-    uint8_t *d_und = nullptr;  // cvUndistort2 scratch: maps, source image, result (grown on demand)
-    size_t und_bytes = 0;
-    double und_key[16] = {0};  // K, dist, width, height of the map held in d_und (the 46 frames of a view share one map)
-    bool und_map_valid = false;
-    hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // sl3d_process_views: upload and download run beside the compute stream
-    std::vector<hipEvent_t> ev_up, ev_done, ev_down;  // per view slot: frames landed / kernel finished / results copied out
-    float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
-    unsigned *d_blk_cnt_all = nullptr;
-    unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
-    uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)
-    uint8_t *d_cloud_rgb = nullptr;           // r,g,b of the compacted cloud of one view
-    std::vector<char> have_texture;
-    float2 *d_proj_disp = nullptr;            // RIG 2: projector undistortion table (allocated when a distorted projector is set)
-    uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
-    size_t pattern_pitch = 0;
-    DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
-    size_t mask_rows = 0;
-};
+#include "sl3d_ctx.h"
 
 static thread_local std::string g_create_err;
 
-static int fail(sl3d_ctx *c, int code, const std::string &msg)
+int sl3d_fail(sl3d_ctx *c, int code, const std::string &msg)
 {
     if (c) c->err = msg;
     else g_create_err = msg;
     return code;
 }
-
-#define HIPCHK(c, call)                                                                             \
-    do {                                                                                            \
-        hipError_t e_ = (call);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
-            return fail((c), SL3D_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
-    } while (0)
 
 extern "C" const char *sl3d_version(void) { return SL3D_VERSION_STRING " (gfx950, hip)"; }
 
@@ -165,7 +113,8 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
             return e_ == hipErrorOutOfMemory ? SL3D_E_NOMEM : SL3D_E_HIP;                \
         }                                                                                \
     } while (0)
-    CREATE_CHK(hipSetDevice(c.device));
+    DeviceGuard dev_guard_(c.device);
+    CREATE_CHK(dev_guard_.err);
     if (c.stream) {
         x->stream = (hipStream_t)c.stream;
     } else {
@@ -180,7 +129,9 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     P.col0 = c.col0; P.row0 = c.row0; P.PW = c.proj_width; P.PH = c.proj_height;
     P.F = c.n_fringe; P.Nv = c.n_gray_v; P.Nh = c.n_gray_h; P.fwv = c.fringe_width_v; P.fwh = c.fringe_width_h;
     P.ncodes_v = c.n_codes_v; P.ncodes_h = c.n_codes_h;
+#ifdef SL3D_MEASURE
     P.ablate = getenv("SL3D_ABLATE") ? atoi(getenv("SL3D_ABLATE")) : 0;
+#endif
     P.pitch = (c.width + 15) & ~15;
     P.planes_per_view = 2 * P.F + 2 * P.Nv + 2 * P.Nh;
     P.plane_stride = (size_t)P.pitch * P.H;
@@ -216,6 +167,7 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
         ALLOC(x->d_cloud, P.px_view_stride * 3);
     }
     ALLOC(x->d_band, V * P.px_view_stride);
+    ALLOC(x->d_mask_raw, P.mask_view_stride);
     CREATE_CHK(hipMemsetAsync(x->d_mask, 0, V * P.mask_view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_frames, 0, V * P.view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_valid, 0, V * P.px_view_stride, x->stream));
@@ -277,7 +229,7 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
 extern "C" void sl3d_destroy(sl3d_ctx *x)
 {
     if (!x) return;
-    (void)hipSetDevice(x->cfg.device);
+    DeviceGuard dev_guard_(x->cfg.device);
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     for (void *p : x->allocs) (void)hipFree(p);
     for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
@@ -374,7 +326,7 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     memcpy(x->S.tc, tc, sizeof x->S.tc);
     memcpy(x->S.tp, tp, sizeof x->S.tp);
     memcpy(x->S.Kp, Kp, sizeof x->S.Kp);
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     HIPCHK(x, hipStreamSynchronize(x->stream));  // no launch may still be reading the previous constants
     HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
     // rig class of the timed fused kernel (pixel_chain): 1 = the reference's kind of calibration, 2 = distorted projector
@@ -395,6 +347,8 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     return SL3D_OK;
 }
 
+static int launched(sl3d_ctx *x, int hip_err);
+
 static int check_view(sl3d_ctx *x, int view, int n = 1)
 {
     if (!x) return SL3D_E_INVALID_ARG;
@@ -402,56 +356,37 @@ static int check_view(sl3d_ctx *x, int view, int n = 1)
     return SL3D_OK;
 }
 
+// true if `p` is pinned (hipHostMalloc / hipHostRegister) host memory: copies from it are asynchronous DMA, so the caller
+// owns the hand-over (see include/sl3d.h); pageable memory is consumed before the call returns
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory is not known to the runtime: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// selected_region -> the context's mask plane, on the device: the caller's rows (window + 2-pixel halo, clipped to the
+// frame) go up as ONE 2-D copy into a staging plane, k_mask_prepare normalises them to 0/1 and evaluates the border band
+// (3/wrapped_phase.cpp:253-279 in closed form, MaskView::valid).  No host-side pass over the mask, no allocation, and no
+// stream synchronisation when the source is pinned memory.
 extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t stride)
 {
     int rc = check_view(x, view);
     if (rc) return rc;
     if (!m || stride < (size_t)x->cfg.full_width) return fail(x, SL3D_E_INVALID_ARG, "mask: null or stride < full_width");
     const KParams &P = x->P;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
-    // window + halo, normalised to 0/1; cells outside the frame stay 0
-    std::vector<uint8_t> host(P.mask_view_stride, 0);
-    for (int r = -SL3D_MASK_HALO; r < P.H + SL3D_MASK_HALO; r++) {
-        const int gy = P.row0 + r;
-        if (gy < 0 || gy >= P.fullH) continue;
-        uint8_t *dst = host.data() + (size_t)(r + SL3D_MASK_HALO) * P.mpitch + SL3D_MASK_LPAD;
-        const uint8_t *src = m + (size_t)gy * stride;
-        for (int c = -SL3D_MASK_HALO; c < P.W + SL3D_MASK_HALO; c++) {
-            const int gx = P.col0 + c;
-            if (gx < 0 || gx >= P.fullW) continue;
-            dst[c] = src[gx] == 1 ? 1 : 0;
-        }
-    }
-    HIPCHK(x, hipMemcpyAsync(x->d_mask + (size_t)view * P.mask_view_stride, host.data(), host.size(), hipMemcpyHostToDevice, x->stream));
-
-    // Valid map of the quads within 3 pixels of the frame border, by the generic closed form of the
-    // reference's boundary removal (3/wrapped_phase.cpp:253-279; derivation in sl3d_kernels.hip).
-    // The fused kernel evaluates the interior with byte-parallel logic and reads this band at the border.
-    const int FW = P.fullW, FH = P.fullH;
-    auto V = [&](int gx, int gy) { return gx >= 0 && gy >= 0 && gx < FW && gy < FH && m[(size_t)gy * stride + gx] == 1; };
-    auto interior = [&](int gx, int gy) { return gx >= 1 && gx <= FW - 2 && gy >= 1 && gy <= FH - 2; };
-    auto L = [&](int gx, int gy) { return !V(gx + 1, gy) || !V(gx - 1, gy + 1) || !V(gx, gy + 1) || !V(gx + 1, gy + 1); };
-    auto BU = [&](int gx, int gy) { return gx >= 0 && gy >= 0 && gx < FW && gy < FH && !interior(gx, gy) && !V(gx, gy); };
-    auto Bq = [&](int gx, int gy) { return BU(gx - 1, gy - 1) || BU(gx, gy - 1) || BU(gx + 1, gy - 1) || BU(gx - 1, gy); };
-    auto OK = [&](int gx, int gy) { return V(gx, gy) || (interior(gx, gy) && (L(gx, gy) || Bq(gx, gy))); };
-    auto valid = [&](int gx, int gy) {
-        if (!V(gx, gy)) return false;
-        if (!interior(gx, gy)) return true;
-        if (L(gx, gy)) return false;
-        return OK(gx - 1, gy - 1) && OK(gx, gy - 1) && OK(gx + 1, gy - 1) && OK(gx - 1, gy);
-    };
-    std::vector<uint8_t> band(P.px_view_stride, 0);
-    for (int r = 0; r < P.H; r++) {
-        const int gy = P.row0 + r;
-        const bool row_band = !(gy >= 3 && gy <= FH - 4);
-        for (int c = 0; c < P.W; c += 4) {
-            const int gx = P.col0 + c;
-            if (!row_band && gx >= 4 && gx + 3 <= FW - 5) continue;  // same test as quad_valid_bits()
-            for (int k = 0; k < 4 && c + k < P.W; k++) band[(size_t)r * P.pitch + c + k] = valid(gx + k, gy) ? 1 : 0;
-        }
-    }
-    HIPCHK(x, hipMemcpyAsync(x->d_band + (size_t)view * P.px_view_stride, band.data(), band.size(), hipMemcpyHostToDevice, x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    ON_DEVICE(x);
+    const int gy0 = std::max(P.row0 - SL3D_MASK_HALO, 0), gy1 = std::min(P.row0 + P.H + SL3D_MASK_HALO, P.fullH);
+    const int gx0 = std::max(P.col0 - SL3D_MASK_HALO, 0), gx1 = std::min(P.col0 + P.W + SL3D_MASK_HALO, P.fullW);
+    uint8_t *dst = x->d_mask_raw + (size_t)(gy0 - P.row0 + SL3D_MASK_HALO) * P.mpitch + SL3D_MASK_LPAD + (gx0 - P.col0);
+    HIPCHK(x, hipMemcpy2DAsync(dst, P.mpitch, m + (size_t)gy0 * stride + gx0, stride, (size_t)(gx1 - gx0), (size_t)(gy1 - gy0),
+                               hipMemcpyHostToDevice, x->stream));
+    rc = launched(x, launch_mask_prepare(P, view, x->d_mask_raw, x->stream));
+    if (rc) return rc;
+    if (!is_pinned_host(m)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
 }
 
@@ -463,18 +398,24 @@ extern "C" int sl3d_set_frames(sl3d_ctx *x, int view, int axis, const uint8_t *c
     const int N = axis == 0 ? P.Nv : P.Nh;
     if ((axis != 0 && axis != 1) || !planes || n_planes != P.F + 2 * N || stride < (size_t)P.W)
         return fail(x, SL3D_E_INVALID_ARG, "set_frames: expected n_fringe + 2*n_gray planes (fringe, gray, inverse) and stride >= width");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
+    bool back_to_back = true;  // the planes follow each other in host memory with the same row stride
     for (int i = 0; i < n_planes; i++) {
         if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames: null plane");
-        uint8_t *dst = x->d_frames + (size_t)view * P.view_stride + (size_t)(base + i) * P.plane_stride;
-        HIPCHK(x, hipMemcpy2DAsync(dst, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+        if (i && planes[i] != planes[i - 1] + stride * (size_t)P.H) back_to_back = false;
     }
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    uint8_t *dst0 = x->d_frames + (size_t)view * P.view_stride + (size_t)base * P.plane_stride;
+    if (back_to_back) {
+        // the device planes of an axis are back to back too (plane_stride = pitch * H): the whole axis is ONE 2-D copy
+        HIPCHK(x, hipMemcpy2DAsync(dst0, P.pitch, planes[0], stride, P.W, (size_t)P.H * n_planes, hipMemcpyHostToDevice, x->stream));
+    } else {
+        for (int i = 0; i < n_planes; i++)
+            HIPCHK(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+    }
+    if (!is_pinned_host(planes[0])) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
 }
-
-static int launched(sl3d_ctx *x, int hip_err);
 
 // sl3d_set_frames for RAW captures: what the acquisition stage does between the camera and the files stage 3/4 read
 // (cvUndistort2 with the camera calibration, 2/project_pattern.cpp:220,232,287,...) happens on the device, one launch for
@@ -490,7 +431,7 @@ extern "C" int sl3d_set_frames_raw(sl3d_ctx *x, int view, int axis, const uint8_
         return fail(x, SL3D_E_INVALID_ARG, "set_frames_raw: expected n_fringe + 2*n_gray planes (fringe, gray, inverse) and stride >= width");
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "set_frames_raw before set_calibration");
     if (P.W != P.fullW || P.H != P.fullH) return fail(x, SL3D_E_UNSUPPORTED, "set_frames_raw: whole frames only (no window / stripe)");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const size_t maps = (((size_t)P.W * P.H * 6 + 63) / 64) * 64, max_planes = (size_t)P.F + 2 * (size_t)std::max(P.Nv, P.Nh);
     if (!x->d_raw) {
         rc = dev_alloc(x, &x->d_raw, maps + max_planes * P.plane_stride);
@@ -519,7 +460,7 @@ extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
     if (rc || (rc = check_view(x, dst))) return rc;
     if (src == dst) return SL3D_OK;
     const KParams &P = x->P;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)dst * P.view_stride, x->d_frames + (size_t)src * P.view_stride, P.view_stride,
                              hipMemcpyDeviceToDevice, x->stream));
     HIPCHK(x, hipMemcpyAsync(x->d_mask + (size_t)dst * P.mask_view_stride, x->d_mask + (size_t)src * P.mask_view_stride,
@@ -540,7 +481,7 @@ extern "C" int sl3d_synth_view(sl3d_ctx *x, int view, const double plane[3], uin
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     if (x->P.PW > x->P.fwv * (1 << x->P.Nv) || x->P.PH > x->P.fwh * (1 << x->P.Nh))
         return fail(x, SL3D_E_INVALID_ARG, "Gray code too short for the projector size");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     SynthParams S = x->S;
     S.z0 = plane[0]; S.a = plane[1]; S.b = plane[2];
     S.seed = seed; S.view_id = view_id; S.noise = noise; S.gain = gain; S.offset = offset;
@@ -556,7 +497,7 @@ extern "C" int sl3d_get_frames(sl3d_ctx *x, int view, int axis, uint8_t *const *
     const int N = axis == 0 ? P.Nv : P.Nh;
     if ((axis != 0 && axis != 1) || !planes || n_planes != P.F + 2 * N || stride < (size_t)P.W)
         return fail(x, SL3D_E_INVALID_ARG, "get_frames: expected n_fringe + 2*n_gray planes and stride >= width");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
     for (int i = 0; i < n_planes; i++) {
         const uint8_t *src = x->d_frames + (size_t)view * P.view_stride + (size_t)(base + i) * P.plane_stride;
@@ -584,7 +525,7 @@ extern "C" int sl3d_compute_wrapped_phase(sl3d_ctx *x, int view, int axis)
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
     if (axis != 0 && axis != 1) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     return launched(x, launch_wrap(x->P, view, axis, x->stream));
 }
 
@@ -593,7 +534,7 @@ extern "C" int sl3d_unwrap_phase(sl3d_ctx *x, int view, int axis)
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
     if (axis != 0 && axis != 1) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     return launched(x, launch_unwrap(x->P, view, axis, x->stream));
 }
 
@@ -601,7 +542,7 @@ extern "C" int sl3d_compute_c_p_map(sl3d_ctx *x, int view)
 {
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     return launched(x, launch_corr(x->P, view, x->stream));
 }
 
@@ -610,7 +551,7 @@ extern "C" int sl3d_triangulate(sl3d_ctx *x, int view)
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     return launched(x, launch_tri(x->P, x->C, view, x->stream));
 }
 
@@ -619,8 +560,8 @@ extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, x->stream));
+    ON_DEVICE(x);
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream));
 }
 
 extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
@@ -628,9 +569,9 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
-    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, x->stream));
+    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream));
     if (rc) return rc;
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));
@@ -643,7 +584,7 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
 extern "C" int sl3d_timer_start(sl3d_ctx *x)
 {
     if (!x) return SL3D_E_INVALID_ARG;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
     return SL3D_OK;
 }
@@ -651,7 +592,7 @@ extern "C" int sl3d_timer_start(sl3d_ctx *x)
 extern "C" int sl3d_timer_stop(sl3d_ctx *x, float *ms)
 {
     if (!x) return SL3D_E_INVALID_ARG;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));
     float t = 0;
@@ -663,7 +604,7 @@ extern "C" int sl3d_timer_stop(sl3d_ctx *x, float *ms)
 extern "C" int sl3d_synchronize(sl3d_ctx *x)
 {
     if (!x) return SL3D_E_INVALID_ARG;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
@@ -678,7 +619,7 @@ static int get_plane(sl3d_ctx *x, int view, const T *dev_base, int comps, T *out
     if (!dev_base) return fail(x, SL3D_E_STATE, "plane not available (SL3D_FLAG_KEEP_STAGES not set?)");
     const KParams &P = x->P;
     if (out_stride_elems < (size_t)P.W * comps) return fail(x, SL3D_E_INVALID_ARG, "output stride too small");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const T *src = dev_base + (size_t)view * P.px_view_stride * comps;
     HIPCHK(x, hipMemcpy2DAsync(out, out_stride_elems * sizeof(T), src, (size_t)P.pitch * comps * sizeof(T), (size_t)P.W * comps * sizeof(T),
                                P.H, hipMemcpyDeviceToHost, x->stream));
@@ -764,7 +705,7 @@ extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "process_views before set_calibration");
     const KParams &P = x->P;
     if (stride < (size_t)P.W) return fail(x, SL3D_E_INVALID_ARG, "process_views: stride < width");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const int S = x->cfg.max_views;  // slots
     if (!x->s_h2d) {
         HIPCHK(x, hipStreamCreateWithFlags(&x->s_h2d, hipStreamNonBlocking));
@@ -778,44 +719,124 @@ extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const
     }
     HIPCHK(x, hipStreamSynchronize(x->stream));  // earlier work on the context's own stream is done before the slots are reused
     const int ppv = P.planes_per_view;
-    for (int v = 0; v < n_views; v++) {
-        const int slot = v % S;
-        // the slot's previous occupant must have been computed (frames free) and downloaded (results free)
-        if (v >= S) {
-            HIPCHK(x, hipStreamWaitEvent(x->s_h2d, x->ev_done[(size_t)slot], 0));
-            HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_down[(size_t)slot], 0));
+    // every pointer is checked BEFORE anything is enqueued: an error return must never leave copies running against
+    // buffers the caller is about to free
+    for (size_t i = 0; i < (size_t)n_views * (size_t)ppv; i++)
+        if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "process_views: null plane");
+    auto pipeline = [&]() -> int {
+        for (int v = 0; v < n_views; v++) {
+            const int slot = v % S;
+            // the slot's previous occupant must have been computed (frames free) and downloaded (results free)
+            if (v >= S) {
+                HIPCHK(x, hipStreamWaitEvent(x->s_h2d, x->ev_done[(size_t)slot], 0));
+                HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_down[(size_t)slot], 0));
+            }
+            // a view whose planes are back to back in host memory, in the device's own pitch, goes up as ONE copy
+            bool contiguous = stride == (size_t)P.pitch && (size_t)P.W == (size_t)P.pitch;
+            for (int p = 1; p < ppv; p++)
+                if (planes[(size_t)v * ppv + p] != planes[(size_t)v * ppv + p - 1] + P.plane_stride) contiguous = false;
+            if (contiguous) {
+                HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)slot * P.view_stride, planes[(size_t)v * ppv], P.view_stride, hipMemcpyHostToDevice, x->s_h2d));
+            } else {
+                for (int p = 0; p < ppv; p++)
+                    HIPCHK(x, hipMemcpy2DAsync(x->d_frames + (size_t)slot * P.view_stride + (size_t)p * P.plane_stride, P.pitch,
+                                               planes[(size_t)v * ppv + p], stride, P.W, P.H, hipMemcpyHostToDevice, x->s_h2d));
+            }
+            HIPCHK(x, hipEventRecord(x->ev_up[(size_t)slot], x->s_h2d));
+            HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_up[(size_t)slot], 0));
+            const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, false, x->stream));
+            if (rc) return rc;
+            HIPCHK(x, hipEventRecord(x->ev_done[(size_t)slot], x->stream));
+            HIPCHK(x, hipStreamWaitEvent(x->s_d2h, x->ev_done[(size_t)slot], 0));
+            if (xyz)
+                HIPCHK(x, hipMemcpy2DAsync(xyz + (size_t)v * P.W * P.H * 3, (size_t)P.W * 12, P.points + (size_t)slot * P.px_view_stride * 3,
+                                           (size_t)P.pitch * 12, (size_t)P.W * 12, P.H, hipMemcpyDeviceToHost, x->s_d2h));
+            if (valid)
+                HIPCHK(x, hipMemcpy2DAsync(valid + (size_t)v * P.W * P.H, P.W, P.valid + (size_t)slot * P.px_view_stride, P.pitch, P.W, P.H,
+                                           hipMemcpyDeviceToHost, x->s_d2h));
+            HIPCHK(x, hipEventRecord(x->ev_down[(size_t)slot], x->s_d2h));
         }
-        // a view whose planes are back to back in host memory, in the device's own pitch, goes up as ONE copy
-        bool contiguous = stride == (size_t)P.pitch && (size_t)P.W == (size_t)P.pitch;
-        for (int p = 0; p < ppv; p++) {
-            const uint8_t *src = planes[(size_t)v * ppv + p];
-            if (!src) return fail(x, SL3D_E_INVALID_ARG, "process_views: null plane");
-            if (p && src != planes[(size_t)v * ppv + p - 1] + P.plane_stride) contiguous = false;
-        }
-        if (contiguous) {
-            HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)slot * P.view_stride, planes[(size_t)v * ppv], P.view_stride, hipMemcpyHostToDevice, x->s_h2d));
-        } else {
-            for (int p = 0; p < ppv; p++)
-                HIPCHK(x, hipMemcpy2DAsync(x->d_frames + (size_t)slot * P.view_stride + (size_t)p * P.plane_stride, P.pitch,
-                                           planes[(size_t)v * ppv + p], stride, P.W, P.H, hipMemcpyHostToDevice, x->s_h2d));
-        }
-        HIPCHK(x, hipEventRecord(x->ev_up[(size_t)slot], x->s_h2d));
-        HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_up[(size_t)slot], 0));
-        const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, x->stream));
-        if (rc) return rc;
-        HIPCHK(x, hipEventRecord(x->ev_done[(size_t)slot], x->stream));
-        HIPCHK(x, hipStreamWaitEvent(x->s_d2h, x->ev_done[(size_t)slot], 0));
-        if (xyz)
-            HIPCHK(x, hipMemcpy2DAsync(xyz + (size_t)v * P.W * P.H * 3, (size_t)P.W * 12, P.points + (size_t)slot * P.px_view_stride * 3,
-                                       (size_t)P.pitch * 12, (size_t)P.W * 12, P.H, hipMemcpyDeviceToHost, x->s_d2h));
-        if (valid)
-            HIPCHK(x, hipMemcpy2DAsync(valid + (size_t)v * P.W * P.H, P.W, P.valid + (size_t)slot * P.px_view_stride, P.pitch, P.W, P.H,
-                                       hipMemcpyDeviceToHost, x->s_d2h));
-        HIPCHK(x, hipEventRecord(x->ev_down[(size_t)slot], x->s_d2h));
+        return SL3D_OK;
+    };
+    const int rc = pipeline();
+    // success or not, nothing may still be running against the caller's buffers when this returns, and the three streams are
+    // left drained for the next call
+    const std::string first_err = x->err;
+    const hipError_t e1 = hipStreamSynchronize(x->s_h2d), e2 = hipStreamSynchronize(x->stream), e3 = hipStreamSynchronize(x->s_d2h);
+    if (rc) {
+        x->err = first_err;
+        return rc;
     }
-    HIPCHK(x, hipStreamSynchronize(x->s_d2h));
+    HIPCHK(x, e1);
+    HIPCHK(x, e2);
+    HIPCHK(x, e3);
+    return SL3D_OK;
+}
+
+// ---- compacted clouds straight from the fused kernel ----------------------------------------------------------------
+static int ensure_cloud_buffers(sl3d_ctx *x)
+{
+    if (x->d_clouds && x->d_tile_status) return SL3D_OK;
+    KParams &P = x->P;
+    const size_t mv = (size_t)x->cfg.max_views;
+    int rc = SL3D_OK;
+    if (!x->d_clouds) {
+        const size_t nb = (P.px_view_stride + 1023) / 1024;
+        rc = dev_alloc(x, &x->d_clouds, mv * P.px_view_stride * 3);
+        if (!rc) rc = dev_alloc(x, &x->d_blk_cnt_all, mv * nb);
+        if (!rc) rc = dev_alloc(x, &x->d_blk_off_all, mv * nb);
+        if (!rc) rc = dev_alloc(x, &x->d_totals, mv);
+        if (rc) return rc;
+    }
+    P.n_tiles = fused_tiles(P);
+    rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles);
+    if (!rc) rc = dev_alloc(x, &x->d_lookback_err, (size_t)1);
+    if (rc) return rc;
+    HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, mv * (size_t)P.n_tiles * sizeof(unsigned long long), x->stream));
+    HIPCHK(x, hipMemsetAsync(x->d_lookback_err, 0, sizeof(int), x->stream));
+    P.clouds = x->d_clouds;
+    P.tile_status = x->d_tile_status;
+    P.cloud_totals = x->d_totals;
+    P.lookback_err = x->d_lookback_err;
+    P.epoch = 0;
+    return SL3D_OK;
+}
+
+// The fused kernel with the compaction of 8/save_point_cloud.cpp:85-104 inside it (k_fused<..., COMPACT>): one launch reads
+// every frame byte once and writes the valid map and the compacted cloud of every view; no dense xyz plane, no second pass.
+extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
+    if (x->keep) return fail(x, SL3D_E_STATE, "sl3d_run_clouds is the timed mode: create the context without SL3D_FLAG_KEEP_STAGES");
+    ON_DEVICE(x);
+    rc = ensure_cloud_buffers(x);
+    if (rc) return rc;
+    if (++x->P.epoch >= (1u << 30)) {  // the generation tag is 30 bits: start over with cleared words
+        HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * sizeof(unsigned long long), x->stream));
+        x->P.epoch = 1;
+    }
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, true, x->stream));
+}
+
+// counts (and the device address) of the clouds the last sl3d_run_clouds over these views produced; synchronises
+extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    if (!x->d_tile_status) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
+    ON_DEVICE(x);
+    std::vector<unsigned long long> t((size_t)n_views);
+    int err = 0;
+    HIPCHK(x, hipMemcpyAsync(t.data(), x->d_totals + first_view, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipMemcpyAsync(&err, x->d_lookback_err, sizeof err, hipMemcpyDeviceToHost, x->stream));
     HIPCHK(x, hipStreamSynchronize(x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->s_h2d));
+    if (err) return fail(x, SL3D_E_HIP, "fused compaction: a tile look-back timed out (tiles were not dispatched in order?)");
+    for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[(size_t)v];
+    if (device_xyz) *device_xyz = x->d_clouds + 3 * (size_t)first_view * x->P.px_view_stride;
+    if (view_stride_points) *view_stride_points = x->P.px_view_stride;
     return SL3D_OK;
 }
 
@@ -824,7 +845,7 @@ extern "C" int sl3d_compact(sl3d_ctx *x, int view, const float **device_xyz, int
     int rc = check_view(x, view);
     if (rc) return rc;
     if (!count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const bool tex = x->d_texture && view < (int)x->have_texture.size() && x->have_texture[view];
     rc = launched(x, launch_compact(x->P, view, x->d_blk_cnt, x->d_blk_off, x->d_total, x->d_cloud,
                                     tex ? x->d_texture + (size_t)view * x->P.px_view_stride * 3 : nullptr, x->d_cloud_rgb, x->stream));
@@ -840,6 +861,7 @@ extern "C" int sl3d_compact(sl3d_ctx *x, int view, const float **device_xyz, int
 extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacity, int64_t *count)
 {
     if (!x || !count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    ON_DEVICE(x);
     // row-major scan, valid pixels only (8/save_point_cloud.cpp:85-104), compacted on the device
     const float *dev = nullptr;
     int rc = sl3d_compact(x, view, &dev, count);
@@ -859,21 +881,15 @@ extern "C" int sl3d_compact_views(sl3d_ctx *x, int first_view, int n_views, cons
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const KParams &P = x->P;
-    const size_t nb = (P.px_view_stride + 1023) / 1024, mv = (size_t)x->cfg.max_views;
-    if (!x->d_clouds) {
-        rc = dev_alloc(x, &x->d_clouds, mv * P.px_view_stride * 3);
-        if (!rc) rc = dev_alloc(x, &x->d_blk_cnt_all, mv * nb);
-        if (!rc) rc = dev_alloc(x, &x->d_blk_off_all, mv * nb);
-        if (!rc) rc = dev_alloc(x, &x->d_totals, mv);
-        if (rc) return rc;
-    }
-    rc = launched(x, launch_compact_views(P, first_view, n_views, x->d_blk_cnt_all, x->d_blk_off_all, x->d_totals,
+    rc = ensure_cloud_buffers(x);
+    if (rc) return rc;
+    rc = launched(x, launch_compact_views(P, first_view, n_views, x->d_blk_cnt_all, x->d_blk_off_all, x->d_totals + first_view,
                                           x->d_clouds + 3 * (size_t)first_view * P.px_view_stride, x->stream));
     if (rc) return rc;
     std::vector<unsigned long long> t((size_t)n_views);
-    HIPCHK(x, hipMemcpyAsync(t.data(), x->d_totals, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipMemcpyAsync(t.data(), x->d_totals + first_view, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
     HIPCHK(x, hipStreamSynchronize(x->stream));
     for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[(size_t)v];
     if (device_xyz) *device_xyz = x->d_clouds + 3 * (size_t)first_view * P.px_view_stride;
@@ -884,6 +900,8 @@ extern "C" int sl3d_compact_views(sl3d_ctx *x, int first_view, int n_views, cons
 // host copy of the batched compaction: the clouds of the views back to back in xyz (at most `capacity` points in all)
 extern "C" int sl3d_get_clouds(sl3d_ctx *x, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts)
 {
+    if (!x) return SL3D_E_INVALID_ARG;
+    ON_DEVICE(x);
     const float *dev = nullptr;
     size_t stride = 0;
     int rc = sl3d_compact_views(x, first_view, n_views, &dev, &stride, counts);
@@ -906,7 +924,7 @@ extern "C" int sl3d_set_texture(sl3d_ctx *x, int view, const uint8_t *bgr, size_
     if (rc) return rc;
     const KParams &P = x->P;
     if (!bgr || stride < (size_t)P.W * 3) return fail(x, SL3D_E_INVALID_ARG, "texture: null or stride < 3*width");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     if (!x->d_texture) {
         rc = dev_alloc(x, &x->d_texture, (size_t)x->cfg.max_views * P.px_view_stride * 3);
         if (rc) return rc;
@@ -926,6 +944,7 @@ extern "C" int sl3d_get_cloud_rgb(sl3d_ctx *x, int view, float *xyz, uint8_t *rg
     if (!x || !count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->d_texture || view < 0 || view >= (int)x->have_texture.size() || !x->have_texture[view])
         return fail(x, SL3D_E_INVALID_ARG, "no texture set for this view (sl3d_set_texture)");
+    ON_DEVICE(x);
     const float *dev = nullptr;
     int rc = sl3d_compact(x, view, &dev, count);
     if (rc) return rc;
@@ -947,7 +966,7 @@ extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, flo
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!total) return fail(x, SL3D_E_INVALID_ARG, "null argument");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const KParams &P = x->P;
     if (!x->d_reg) {
         rc = dev_alloc(x, &x->d_reg, (size_t)x->cfg.max_views * P.px_view_stride * 3);
@@ -990,7 +1009,7 @@ extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride
     const size_t row = (size_t)width * channels, img = (((row + 15) / 16) * 16) * (size_t)height;
     if (src_stride < row || dst_stride < row) return fail(x, SL3D_E_INVALID_ARG, "undistort: stride < width*channels");
     const size_t pitch = ((row + 15) / 16) * 16, maps = (size_t)width * height * 6, need = 2 * img + maps + 128;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     if (need > x->und_bytes) {
         HIPCHK(x, hipStreamSynchronize(x->stream));
         if (x->d_und) {
@@ -1031,7 +1050,7 @@ extern "C" int sl3d_transform_cloud(sl3d_ctx *x, const float *xyz_in, int64_t n,
 {
     if (!x || n < 0 || (n > 0 && (!xyz_in || !xyz_out))) return fail(x, SL3D_E_INVALID_ARG, "transform_cloud: null argument");
     if (n == 0) return SL3D_OK;
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     float *d = nullptr;
     HIPCHK(x, hipMalloc((void **)&d, (size_t)n * 6 * sizeof(float)));
     const float theta = theta_deg;
@@ -1091,7 +1110,7 @@ extern "C" int sl3d_generate_pattern(sl3d_ctx *x, int kind, int axis, int index,
     const int nplanes = axis == 0 ? x->cfg.n_gray_v : x->cfg.n_gray_h, fw = axis == 0 ? x->cfg.fringe_width_v : x->cfg.fringe_width_h;
     if (index < 0 || index >= (kind == SL3D_PATTERN_FRINGE ? F : nplanes + 1)) return fail(x, SL3D_E_INVALID_ARG, "pattern: index out of range");
     if (host_dst && stride < (size_t)PW) return fail(x, SL3D_E_INVALID_ARG, "pattern: stride < proj_width");
-    HIPCHK(x, hipSetDevice(x->cfg.device));
+    ON_DEVICE(x);
     const size_t pitch = ((size_t)PW + 15) / 16 * 16, extent_max = (size_t)std::max(PW, PH) + 16;
     if (!x->d_pattern) {
         HIPCHK(x, hipMalloc((void **)&x->d_pattern, pitch * (size_t)PH));
@@ -1110,6 +1129,15 @@ extern "C" int sl3d_generate_pattern(sl3d_ctx *x, int kind, int axis, int index,
     if (host_dst) HIPCHK(x, hipMemcpy2D(host_dst, stride, x->d_pattern, pitch, (size_t)PW, (size_t)PH, hipMemcpyDeviceToHost));
     if (device_ptr) *device_ptr = x->d_pattern;
     if (device_pitch) *device_pitch = pitch;
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_download(sl3d_ctx *x, void *host_dst, const void *device_src, size_t bytes)
+{
+    if (!x || (bytes && (!host_dst || !device_src))) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    ON_DEVICE(x);
+    if (bytes) HIPCHK(x, hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 

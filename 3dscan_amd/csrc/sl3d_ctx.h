@@ -1,0 +1,90 @@
+// sl3d_ctx.h -- the context behind the opaque sl3d_ctx handle, shared by the C-ABI translation units
+// (sl3d_capi.cpp: single-GPU entry points; sl3d_group.cpp: row-stripe groups over several GPUs).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sl3d.h"
+#include "sl3d_internal.h"
+
+using namespace sl3d;
+
+struct sl3d_ctx {
+    sl3d_config cfg{};
+    KParams P{};
+    DevCal C{};
+    SynthParams S{};  // extrinsics kept for the synthetic-capture generator
+    bool have_cal = false;
+    int rig = 0;
+    bool keep = false;
+    bool own_stream = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void *> allocs;
+    std::string err;
+    uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
+    uint8_t *d_mask_raw = nullptr;            // sl3d_set_mask: the caller's bytes of one view (window + halo), staged for k_mask_prepare
+    float *d_points = nullptr;
+    unsigned *d_blk_cnt = nullptr;            // compaction scratch: per-1024-pixel block counts,
+    unsigned long long *d_blk_off = nullptr;  // their exclusive scan, and the total
+    unsigned long long *d_total = nullptr;
+    float *d_cloud = nullptr;                 // compacted cloud of one view (capacity = window pixels)
+    float *d_reg = nullptr;                   // registered clouds of all views (allocated on first use)
+    uint8_t *d_raw = nullptr;  // sl3d_set_frames_raw: the raw planes of one axis + the camera's undistortion map
+    bool raw_map_valid = false;
+    double Kc_raw[9] = {0}, dc_raw[5] = {0};  // the camera intrinsics the raw path undistorts with (set_calibration)
+    uint8_t *d_und = nullptr;  // cvUndistort2 scratch: maps, source image, result (grown on demand)
+    size_t und_bytes = 0;
+    double und_key[16] = {0};  // K, dist, width, height of the map held in d_und (the 46 frames of a view share one map)
+    bool und_map_valid = false;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // sl3d_process_views: upload and download run beside the compute stream
+    std::vector<hipEvent_t> ev_up, ev_done, ev_down;  // per view slot: frames landed / kernel finished / results copied out
+    float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
+    unsigned *d_blk_cnt_all = nullptr;
+    unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
+    unsigned long long *d_tile_status = nullptr;  // sl3d_run_clouds: look-back words [view][tile] of the fused compaction
+    int *d_lookback_err = nullptr;
+    uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)
+    uint8_t *d_cloud_rgb = nullptr;           // r,g,b of the compacted cloud of one view
+    std::vector<char> have_texture;
+    float2 *d_proj_disp = nullptr;            // RIG 2: projector undistortion table (allocated when a distorted projector is set)
+    uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
+    size_t pattern_pitch = 0;
+    DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
+    size_t mask_rows = 0;
+};
+
+// records the message on the context (or, without one, as the thread's creation error) and returns `code`
+__attribute__((visibility("hidden"))) int sl3d_fail(sl3d_ctx *c, int code, const std::string &msg);
+#define fail sl3d_fail
+
+#define HIPCHK(c, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail((c), SL3D_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+// Every entry point runs on the context's device and hands the caller's current device back on return: the caller may be a
+// process that holds contexts on several GPUs, or a torch process whose current device differs.
+struct DeviceGuard {
+    int prev = -1, dev;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ON_DEVICE(x)                       \
+    DeviceGuard dev_guard_((x)->cfg.device); \
+    HIPCHK((x), dev_guard_.err)
+

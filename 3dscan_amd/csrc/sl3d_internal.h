@@ -59,7 +59,7 @@ struct KParams {
     int F, Nv, Nh;
     int fwv, fwh;
     int ncodes_v, ncodes_h;
-    int ablate;                // debug only (env SL3D_ABLATE): bit0 skip fp64 chain, bit1 skip table gathers, bit2 skip camera undistortion
+    int ablate;                // measurement builds only (-DSL3D_MEASURE, env SL3D_ABLATE): bit2 skips the camera undistortion; 0 otherwise
     int pitch;                 // bytes per row of every u8 plane (multiple of 16)
     int planes_per_view;
     size_t plane_stride;       // pitch * H
@@ -74,6 +74,13 @@ struct KParams {
     float *points;             // [view][row][pitch][3] f32
     uint8_t *valid;            // [view][row][pitch]    merged valid map
     size_t px_view_stride;     // pitch * H   (elements per view of every per-pixel plane)
+    // compacted clouds written by the fused kernel itself (sl3d_run_clouds; NULL until first used)
+    float *clouds;             // [view][px_view_stride][3]: the valid points of a view in row-major scan order
+    unsigned long long *tile_status;   // [view][n_tiles] decoupled look-back words: epoch << 34 | flag << 32 | count
+    unsigned long long *cloud_totals;  // [view] number of valid points
+    int *lookback_err;         // set if a look-back gave up waiting (never expected; reported by sl3d_get_cloud_counts)
+    unsigned epoch;            // launch generation of tile_status (words of older generations read as "not ready")
+    int n_tiles;               // 1024-pixel tiles per view = blocks of the fused kernel along x that own pixels
     // stage-boundary planes (NULL unless SL3D_FLAG_KEEP_STAGES)
     float *wrapped[2];
     float *unwrapped[2];
@@ -86,7 +93,9 @@ struct KParams {
 };
 
 // launchers (sl3d_kernels.hip); `stream` is a hipStream_t
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, void *stream);
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream);
+int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)
+int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream);  // raw: staged bytes in the layout of one mask plane
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);

@@ -59,13 +59,24 @@
 #ifndef SL3D_XCD_BANDS
 #define SL3D_XCD_BANDS 0
 #endif
+// COMPACT kernel: 1 = the previous view's look-back and stores run behind the current view's plane loads, 0 = before them
+#ifndef SL3D_FLUSH_AFTER_LOADS
+#define SL3D_FLUSH_AFTER_LOADS 1
+#endif
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
-// measurement only: 1 = no per-pixel arithmetic (xyz made of the raw decode results), 2 = no mask reads, 4 = no xyz stores.
-// Results are wrong by construction; never set in a shipped build.
-#ifndef SL3D_ABLATE
+// measurement only (tools/ab.sh builds with -DSL3D_MEASURE -DSL3D_ABLATE=n): 1 = no per-pixel arithmetic (xyz made of the raw
+// decode results), 2 = no mask reads, 4 = no xyz stores.  Results are wrong by construction; the shipped build has neither
+// the compile-time switch nor the run-time hooks (SL3D_VPT / SL3D_ABLATE environment variables, KParams::ablate).
+#if !defined(SL3D_MEASURE) || !defined(SL3D_ABLATE)
+#undef SL3D_ABLATE
 #define SL3D_ABLATE 0
+#endif
+#ifdef SL3D_MEASURE
+#define SL3D_ABLATE_RT(P) ((P).ablate)
+#else
+#define SL3D_ABLATE_RT(P) 0
 #endif
 #define SL3D_PRAGMA_(x) _Pragma(#x)
 #define SL3D_UNROLL(n) SL3D_PRAGMA_(unroll n)
@@ -212,6 +223,51 @@ __device__ __forceinline__ unsigned mask_quad_bits(const KParams &P, const MaskQ
     return bits;
 }
 
+// sl3d_set_mask on the device: `raw` holds the caller's bytes of the window + 2-pixel halo (clipped to the frame) in the
+// layout of the mask plane itself (row r of the plane = window row r - 2, byte SL3D_MASK_LPAD + c = window column c).
+// One lane per dword of the plane: normalises the bytes to 0/1 (selected iff byte == 1; outside the frame or the halo: 0) and,
+// for the quads within 3 pixels of the frame border, evaluates the generic closed form of the boundary removal
+// (MaskView::valid on the raw bytes) into the band plane the fused kernel reads there.
+__global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int view, const uint8_t *__restrict__ raw)
+{
+    const int dwords_per_row = P.mpitch >> 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t / dwords_per_row), x = (int)(t - (long)r * dwords_per_row);
+    if (r >= P.H + 2 * SL3D_MASK_HALO) return;
+    MaskView m;
+    m.base = raw + (size_t)SL3D_MASK_HALO * P.mpitch + SL3D_MASK_LPAD;
+    m.mpitch = P.mpitch;
+    m.col0 = P.col0; m.row0 = P.row0; m.fullW = P.fullW; m.fullH = P.fullH;
+    const int c0 = x * 4 - SL3D_MASK_LPAD, wr = r - SL3D_MASK_HALO;  // window column of byte 0, window row
+    const int gy = P.row0 + wr;
+    unsigned norm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = c0 + k;
+        if (c >= -SL3D_MASK_HALO && c < P.W + SL3D_MASK_HALO && m.V(P.col0 + c, gy)) norm |= 1u << (8 * k);
+    }
+    uint8_t *dst = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
+    *(unsigned *)(dst + (size_t)r * P.mpitch + (size_t)x * 4) = norm;
+    if (wr >= 0 && wr < P.H && c0 >= 0 && c0 < P.pitch) {
+        const int cq = c0 >> 2;
+        if (!quad_is_interior(P, cq, wr)) {
+            unsigned band = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (c0 + k < P.W && m.valid(P.col0 + c0 + k, gy)) band |= 1u << (8 * k);
+            *(unsigned *)((uint8_t *)P.band + (size_t)view * P.px_view_stride + (size_t)wr * P.pitch + (size_t)c0) = band;
+        }
+    }
+}
+
+int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream)
+{
+    const long n = (long)(P.mpitch >> 2) * (P.H + 2 * SL3D_MASK_HALO);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_mask_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, view, raw);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // bit-exact phase chain
 // ------------------------------------------------------------------------------------------------
@@ -325,7 +381,7 @@ __device__ __forceinline__ float shift_pi_if(float phi, bool in_range) { return 
 
 // Correctly rounded division by a constant without the IEEE divide expansion (Markstein): with
 // y = RN(1/c), q0 = RN(a*y), r = a - q0*c (exact, one fma), q = RN(q0 + r*y) equals RN(a/c).
-// tests/test_exactdiv.py proves q == a/c exhaustively for the two uses below: c = 7 over every
+// tests/native/exact_arith_check.c (run by tests/test_exact_arith.py) proves q == a/c exhaustively for the two uses below: c = 7 over every
 // a = 44*code, code < 2^20, and c = 44/7 over every float a in [5e-4, 6e4] (all absolute phases).
 __device__ __forceinline__ double div_exact(double a, double c, double y)
 {
@@ -349,10 +405,10 @@ __device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, l
     const double c = 2.0 * PI_REF;  // (2.0*Pi) -> (2.0*22.0)/7.0, folded at compile time exactly as on the host
     const double a = (double)fw * div_exact((double)unwrapped, c, 1.0 / c);
     const double r = rint(a);  // round-half-even, the default rounding mode lrint runs under
-    // FE_INVALID <=> NaN, inf or outside long; those and out-of-range values both clear the pixel
-    // r is an integer-valued finite double (or +-0): the saturating conversion maps r < 0 and r > INT_MAX outside [0, limit)
-    const bool ok = (unsigned)(int)r <= (unsigned)(limit - 1);
-    out = ok ? (long)r : 0;
+    // FE_INVALID <=> NaN, inf or outside long; those and out-of-range values both clear the pixel.  The range test is made on
+    // the double itself (NaN compares false), so no out-of-range value is ever converted to an integer.
+    const bool ok = r >= 0.0 && r <= (double)(limit - 1);
+    out = ok ? (long)(int)r : 0;
     out_d = r;  // the same integer as a double (exact), for stage 7
     return ok;
 }
@@ -529,6 +585,67 @@ __device__ __forceinline__ unsigned ldg32(const GLOBAL_AS uint8_t *base, unsigne
     return *(const GLOBAL_AS unsigned *)(base + (size_t)off);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Ordered compaction inside the fused kernel (O1 / N2: 8/save_point_cloud.cpp:33-37 counts the valid pixels, :85-104 appends
+// them in row-major scan order): single pass, decoupled look-back over the 1024-pixel tiles of a view.
+// A tile (= one block) publishes the number of valid pixels it found in a view as an AGGREGATE word, later its inclusive
+// PREFIX; a tile's exclusive prefix is the sum of the aggregates of its predecessors back to the nearest prefix.
+// Status word: epoch << 34 | flag << 32 | count -- one naturally aligned 8-byte word written by ONE agent-scope store and
+// polled with agent-scope loads, so it needs no fence (data and tag travel together); words of an older launch generation
+// (epoch) read as "not ready", so the array is never cleared between launches.  Tiles are chained in blockIdx.x order
+// inside one view; a tile only ever waits for tiles with a lower linear block index, which the dispatcher started earlier.
+// ------------------------------------------------------------------------------------------------
+#define SL3D_ST_AGG 1ull
+#define SL3D_ST_PREFIX 2ull
+#define SL3D_LOOKBACK_SPINS (1 << 22) /* polls before a look-back gives up and raises KParams::lookback_err (seconds) */
+
+__device__ __forceinline__ unsigned long long status_word(unsigned epoch, unsigned long long flag, unsigned count)
+{
+    return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)count;
+}
+__device__ __forceinline__ void status_publish(unsigned long long *w, unsigned long long v)
+{
+    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// exclusive prefix of tile `tile` in one view's status row; executed by ONE whole wave (lane j looks at tile - 1 - j)
+__device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row, int tile, unsigned epoch, int *err)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned sum = 0;
+    int hi = tile - 1;  // nearest predecessor of the current 64-tile window
+    int spins = 0;
+    for (;;) {
+        const int idx = hi - lane;
+        // tiles before the first one: an inclusive prefix of 0
+        unsigned long long w = status_word(epoch, SL3D_ST_PREFIX, 0u);
+        if (idx >= 0) w = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned flag = (unsigned)(w >> 32) & 3u;
+        const bool ready = (unsigned)(w >> 34) == epoch && flag != 0u;
+        const unsigned long long R = __ballot(ready), Pm = __ballot(ready && flag == (unsigned)SL3D_ST_PREFIX);
+        if (Pm != 0ull) {
+            const int p = __ffsll((long long)Pm) - 1;  // the nearest tile that knows its inclusive prefix
+            const unsigned long long need = p == 63 ? ~0ull : ((1ull << (p + 1)) - 1ull);
+            if ((R & need) == need) return sum + wave_sum(lane <= p ? (unsigned)w : 0u);
+        } else if (R == ~0ull) {  // 64 aggregates and no prefix: add them and look further back
+            sum += wave_sum((unsigned)w);
+            hi -= 64;
+            continue;
+        }
+        if (++spins > SL3D_LOOKBACK_SPINS) {  // never expected: report instead of hanging the GPU
+            if (lane == 0) atomicExch(err, 1);
+            return sum;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // one pixel, everything after the byte loads: stage 4 unwrap, stage 5, stage 7, stage 8 cast.
 // (cu,cv) = undistorted camera pixel coordinates of this pixel (T1, depends on the pixel only);
 // (wv,wh) = wrapped phases, already shifted by +Pi where stage 4 shifts them.
@@ -624,8 +741,8 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 // expensive per-pixel constant of stage 7) is computed once per pixel, not once per pixel per view.
 //
 // Memory-level parallelism: all 2F+2Nv+2Nh plane dwords of a view are requested back to back before
-// the first one is consumed (NMAX is the compile-time unroll bound of the Gray planes; plane indices
-// are clamped to N-1, so the surplus loads of a smaller N re-read a line that is already in L1).
+// the first one is consumed (NMAX is the compile-time unroll bound of the Gray planes; an axis with fewer
+// planes skips the surplus loads through a wave-uniform test).
 // A wave therefore has ~12 KiB of HBM requests in flight instead of a round trip per pair of bit planes.
 // Every plane is addressed as (wave-uniform 64-bit plane base) + (one 32-bit lane offset).
 //
@@ -634,10 +751,18 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 // through LDS so they leave as three 16-B stores per lane (a wave writes 3 KiB contiguous).
 //
 // FGEN = false: 3-step fringes (the reference's configuration) with the F test folded at compile time.
-template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG>
+//
+// COMPACT = true (sl3d_run_clouds, timed mode only): instead of the dense xyz plane the kernel writes the compacted cloud of
+// every view -- the valid points in row-major scan order (8/save_point_cloud.cpp:85-104) -- in the same pass: a block is a
+// 1024-pixel tile of the scan, tile prefixes come from a decoupled look-back (tile_lookback), and the points of view v
+// leave while the planes of view v+1 are in flight (their look-back overlaps that latency).  The valid map is still written.
+template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, bool COMPACT = false>
 __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
+    static_assert(!(KEEP && COMPACT), "the parity mode writes dense planes");
+    static_assert(!COMPACT || (SL3D_BLOCK == 256 && !SL3D_XCD_BANDS), "the look-back chains 1024-pixel tiles in blockIdx.x order");
     __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];
+    __shared__ unsigned s_wtot[4], s_base;  // COMPACT: valid pixels per wave of the current view; exclusive prefix of the tile
     __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_LDS ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
     if (SL3D_RCP_LDS) {
@@ -649,8 +774,12 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
     // gridDim.x is a multiple of 8 (launch_fused), so blockIdx.x % 8 is the XCD whatever blockIdx.y is
     const unsigned tile = SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const long q = (long)tile * SL3D_BLOCK + threadIdx.x;
-    const int row = (int)(q / qpr), cq = (int)(q - (long)row * qpr);
-    if (row >= P.H) return;
+    const int row_q = (int)(q / qpr), cq = (int)(q - (long)row_q * qpr);
+    // COMPACT: a block that owns pixels keeps all its lanes (block barriers in the view loop); lanes past the last row work
+    // on a clamped address and have no valid pixel.  Blocks past the last tile leave as a whole.
+    if (COMPACT ? (int)tile >= P.n_tiles : row_q >= P.H) return;
+    const bool alive = row_q < P.H;
+    const int row = COMPACT ? min(row_q, P.H - 1) : row_q;
     const int gx0 = P.col0 + cq * 4, gy = P.row0 + row;
     const float nanv = __builtin_nanf("");
     float *my_xyz = s_xyz + threadIdx.x * 12;
@@ -663,7 +792,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
 #pragma unroll 1
     for (int k = 0; k < 4; k++) {
         double cu = 0.0, cv = 0.0;
-        if (cq * 4 < P.W && !(P.ablate & 4)) {
+        if (cq * 4 < P.W && !(SL3D_ABLATE_RT(P) & 4)) {
             if (RIG != 0) undistort_normalized((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);  // camera-frame solve
             else undistort_reproject((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);
         }
@@ -717,9 +846,12 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
             const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
 #pragma unroll
             for (int i = 0; i < NMAX; i++) {
-                const unsigned ii = (unsigned)min(i, N - 1);  // clamp: planes beyond N re-read plane N-1 and are ignored by decode
-                g[a][i] = ldg32(vb + (size_t)(pg + ii * psv), lo);
-                iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + ii) * psv), lo);
+                // an axis with fewer than NMAX planes: the surplus loads are not issued (wave-uniform test; decode ignores them)
+                g[a][i] = iv[a][i] = 0u;
+                if (EXACT || i < N) {
+                    g[a][i] = ldg32(vb + (size_t)(pg + (unsigned)i * psv), lo);
+                    iv[a][i] = ldg32(vb + (size_t)(pg + (unsigned)(N + i) * psv), lo);
+                }
             }
         }
     };
@@ -834,7 +966,36 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
     const bool interior = quad_is_interior(P, cq, row);
     // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
     auto valid_bits = [&](const MaskQuad &m) -> unsigned {
+        if (COMPACT && !alive) return 0u;
         return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(P, m, cq, interior);
+    };
+    // ---- COMPACT: the points of the previous view of this lane's loop, still in the LDS staging area --------------------
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    bool pending = false;
+    int pview = 0;
+    unsigned pvout = 0, prank = 0, ptotal = 0;  // valid bytes of the lane's quad, its exclusive rank inside the tile, the tile's count
+    auto flush_pending = [&]() {
+        unsigned long long *row_st = P.tile_status + (size_t)pview * (size_t)P.n_tiles;
+        if (wave == 0) {
+            const unsigned base = tile_lookback(row_st, (int)tile, P.epoch, P.lookback_err);
+            if (lane == 0) {
+                s_base = base;
+                if (tile != 0u) status_publish(row_st + tile, status_word(P.epoch, SL3D_ST_PREFIX, base + ptotal));
+                if ((int)tile == P.n_tiles - 1) P.cloud_totals[pview] = (unsigned long long)(base + ptotal);
+            }
+        }
+        __syncthreads();
+        float *dst = P.clouds + 3 * ((size_t)pview * P.px_view_stride + (size_t)(s_base + prank));
+        typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
+#pragma unroll 1
+        for (int k = 0; k < 4; k++)
+            if ((pvout >> (8 * k)) & 1u) {
+                f32x3 pt;
+                pt.x = my_xyz[3 * k + 0]; pt.y = my_xyz[3 * k + 1]; pt.z = my_xyz[3 * k + 2];
+                *(f32x3 *)dst = pt;
+                dst += 3;
+            }
+        pending = false;
     };
 
     // The mask of the NEXT view is requested before the current view's planes, so a wave never waits a full memory
@@ -863,13 +1024,18 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
                 P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
             }
         }
-        if (KEEP || vbits == 0) fill_nan();
+        if (!COMPACT && (KEEP || vbits == 0)) fill_nan();
 
+        unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
+        if (COMPACT && !SL3D_FLUSH_AFTER_LOADS && pending) flush_pending();
         if (vbits != 0) {
-            unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
             // every load of the view is issued before the first one is consumed
             issue_fringe(view, f);
             issue_gray(view, g, iv);
+        }
+        // COMPACT: the previous view's points leave now, behind this view's loads (its look-back overlaps their latency)
+        if (COMPACT && SL3D_FLUSH_AFTER_LOADS && pending) flush_pending();
+        if (vbits != 0) {
             decode(g, iv, code);
             if (KEEP) {
 #pragma unroll 1
@@ -898,54 +1064,101 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
                 vout = pixel_pairs(px, vbits, f, code);
             }
         }
-        store_quad(px, vout);
+        if (!COMPACT) {
+            store_quad(px, vout);
+            continue;
+        }
+        if (alive) *(unsigned *)(P.valid + px) = vout;
+        // rank of the lane's first valid pixel inside the wave (4 ballots, one per pixel of the quad), wave totals through LDS
+        const unsigned long long b0 = __ballot((vout & 0x00000001u) != 0u), b1 = __ballot((vout & 0x00000100u) != 0u),
+                                 b2 = __ballot((vout & 0x00010000u) != 0u), b3 = __ballot((vout & 0x01000000u) != 0u);
+        auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+        const unsigned rank_w = below(b0) + below(b1) + below(b2) + below(b3);
+        if (lane == 0) s_wtot[wave] = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+        __syncthreads();
+        const unsigned t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
+        ptotal = t0 + t1 + t2 + t3;
+        prank = rank_w + (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+        pvout = vout;
+        pview = view;
+        pending = true;
+        // the tile's count becomes visible to its successors right away; the first tile of a view knows its prefix already
+        if (threadIdx.x == 0)
+            status_publish(P.tile_status + (size_t)view * (size_t)P.n_tiles + tile, status_word(P.epoch, tile == 0u ? SL3D_ST_PREFIX : SL3D_ST_AGG, ptotal));
     }
+    if (COMPACT && pending) flush_pending();
 }
 
-template <bool KEEP, bool FGEN, int RIG>
+// number of 1024-pixel tiles (= blocks along x that own pixels) of one view
+int fused_tiles(const KParams &P)
+{
+    const long quads = (long)(P.pitch >> 2) * P.H;
+    return (int)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK);
+}
+
+// Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT: plane tests fold away)
+// and for the unroll bounds 8 / 12 / 16 otherwise; the parity mode and the 4-/5-step fringes use the bounds only.
+template <bool KEEP, bool FGEN, int RIG, bool COMPACT>
 static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     const int nmax = nv > nh ? nv : nh;
-#define SL3D_LAUNCH(NM)                                                                                                   \
-    do {                                                                                                                  \
-        if (nv == NM && nh == NM)                                                                                         \
-            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, true, RIG>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
-        else                                                                                                              \
-            hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, false, RIG>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
-    } while (0)
-    if (nmax <= 6) SL3D_LAUNCH(6);
-    else if (nmax <= 8) SL3D_LAUNCH(8);
-    else if (nmax <= 10) SL3D_LAUNCH(10);
-    else if (nmax <= 12) SL3D_LAUNCH(12);
-    else SL3D_LAUNCH(SL3D_MAX_GRAY);
+#define SL3D_LAUNCH(NM, EX) hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, COMPACT>), grid, block, 0, st, P, C, first_view, n_views, vpt)
+    if (!KEEP && !FGEN && nv == nh && nv >= 6 && nv <= 12) {
+        switch (nv) {
+        case 6: SL3D_LAUNCH(6, true); break;
+        case 7: SL3D_LAUNCH(7, true); break;
+        case 8: SL3D_LAUNCH(8, true); break;
+        case 9: SL3D_LAUNCH(9, true); break;
+        case 10: SL3D_LAUNCH(10, true); break;
+        case 11: SL3D_LAUNCH(11, true); break;
+        default: SL3D_LAUNCH(12, true); break;
+        }
+    } else if (nmax <= 8) SL3D_LAUNCH(8, false);
+    else if (nmax <= 12) SL3D_LAUNCH(12, false);
+    else SL3D_LAUNCH(SL3D_MAX_GRAY, false);
 #undef SL3D_LAUNCH
 }
 
-// rig: 0 / 1 / 2, see pixel_chain (the host knows the calibration; folded at compile time in the timed 3-step kernel)
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, void *stream)
+template <bool FGEN, bool COMPACT>
+static void launch_fused_rig(int rig, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
+{
+    if (rig == 1) launch_fused_n<false, FGEN, 1, COMPACT>(P.Nv, P.Nh, grid, block, st, P, C, first_view, n_views, vpt);
+    else if (rig == 2 && P.proj_disp) launch_fused_n<false, FGEN, 2, COMPACT>(P.Nv, P.Nh, grid, block, st, P, C, first_view, n_views, vpt);
+    else launch_fused_n<false, FGEN, 0, COMPACT>(P.Nv, P.Nh, grid, block, st, P, C, first_view, n_views, vpt);
+}
+
+// views per lane: as many as possible (amortises the camera undistortion) while the grid still has >= ~8 blocks per CU
+// to balance the tail
+static int views_per_lane(unsigned bx, int n_views)
+{
+    int vpt = 1;
+    while (vpt < 8 && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
+#ifdef SL3D_MEASURE
+    if (getenv("SL3D_VPT") && atoi(getenv("SL3D_VPT")) >= 1) vpt = atoi(getenv("SL3D_VPT"));
+#endif
+    return vpt;
+}
+
+// rig: 0 / 1 / 2, see pixel_chain (the host knows the calibration; folded at compile time in the timed kernels).
+// compact: the timed kernel writes compacted clouds (KParams::clouds / tile_status / cloud_totals must be set) instead of
+// the dense xyz plane.  Returns the hipError_t of THIS launch.
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream)
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
-    // views per lane: as many as possible (amortises the camera undistortion) while the grid still
-    // has >= ~8 blocks per CU to balance the tail
-    int vpt = 1;
-    while (vpt < 8 && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
-    if (getenv("SL3D_VPT")) vpt = atoi(getenv("SL3D_VPT"));
+    const int vpt = views_per_lane(bx, n_views);
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(SL3D_BLOCK, 1, 1);
     hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's
     if (keep) {
-        if (P.F == 3) launch_fused_n<true, false, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<true, true, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (P.F == 3) launch_fused_n<true, false, 0, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<true, true, 0, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (P.F != 3) {  // 4-step (and the all-invalid 5-step) fringes: the F test stays a run-time branch
-        if (rig == 1) launch_fused_n<false, true, 1>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else if (rig == 2 && P.proj_disp) launch_fused_n<false, true, 2>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<false, true, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (rig == 1) {
-        launch_fused_n<false, false, 1>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-    } else if (rig == 2 && P.proj_disp) {
-        launch_fused_n<false, false, 2>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (compact) launch_fused_rig<true, true>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_rig<true, false>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        launch_fused_n<false, false, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (compact) launch_fused_rig<false, true>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_rig<false, false>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
     return (int)hipGetLastError();
 }

@@ -2,18 +2,28 @@
 
 Every stage is a per-pixel map whose only neighbourhood input is the selection MASK (an input, not
 a computed quantity), so a row stripe needs no data from other GPUs: each rank gets the full-frame
-mask and keeps 2 halo rows.  The only exchange is the optional ASSEMBLY of the dense point cloud
-(xyz f32 + valid u8) of each view on one GPU, through torch.distributed (backend "nccl" = RCCL over
-xGMI on MI355X; "gloo" in the CPU tests):
+mask and keeps 2 halo rows.  The only exchange is the ASSEMBLY of the point cloud of each view on one
+GPU (north star: "a single RCCL gather over xGMI"), through torch.distributed (backend "nccl" = RCCL
+over xGMI on MI355X; "gloo" with host staging in the plumbing tests):
 
-  assemble_root     : every stripe of every view goes to rank 0 (the literal "single gather").
+  RootAssembler     : the gather, pipelined per chunk of views: while the fused kernel works on chunk
+                      k+1 on the compute stream, the stripes of chunk k leave on a communication stream
+                      as ONE grouped batch of point-to-point sends that land in place in the root's
+                      dense [view][row] buffers (rank order = row order, so the reference's row-major
+                      scan order of 8/save_point_cloud.cpp:85 is preserved; stripes may have unequal
+                      heights).  dense = xyz f32 + valid u8 (13 B/px); compact = the valid points only,
+                      compacted in scan order by the fused kernel itself (counts exchanged first).
+  assemble_root     : the same gather as one blocking collective over a whole batch (equalised shapes).
   assemble_rotating : view v is assembled on rank v // views_per_rank, one all_to_all for the whole
                       batch, so all point-to-point xGMI links carry traffic at once instead of only
                       the 7 links into one root.
 
-torch is plumbing here (process group + device buffers); the compute never goes through it.
+torch is plumbing here (process group, streams, device buffers); the compute never goes through it.
 """
 import os
+import socket
+import subprocess
+import sys
 
 
 def env_ranks():
@@ -29,6 +39,38 @@ def shard_rows(height, world, rank):
     return row0, rows
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(script, argv, world, extra_env=None):
+    """Start `world` FRESH python processes of `script argv...`, one per rank, with the environment torch.distributed.run
+    would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  The caller must not have touched the GPU
+    (and never exec's): the children are ordinary subprocesses.  Rank 0's stdout is returned; every rank's stderr is
+    inherited.  Raises SystemExit with the first non-zero exit code."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stdout.write(out.decode(errors="replace"))
+        raise SystemExit(f"rank(s) failed: {bad}")
+    return out.decode()
+
+
 def max_over_ranks(seconds, device=None):
     """MAX of a python float over all ranks (1 rank: identity)."""
     import torch
@@ -40,33 +82,166 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
-def assemble_root(stripe, rows_per_rank, root=0):
-    """stripe: [views, rows, ...] tensor of this rank's rows of every view (equal rows on every rank).
-    Returns on `root` the assembled [views, world*rows, ...] tensor (rank order = row order, so the
+def _equalise_rows(stripe, dim=1):
+    """Pad `stripe` along `dim` to the largest row count of any rank (collectives need identical shapes); returns
+    (padded stripe, list of every rank's true row count)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    mine = torch.tensor([stripe.shape[dim]], dtype=torch.int64, device=stripe.device if dist.get_backend() == "nccl" else "cpu")
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    rows = [int(r.item()) for r in rows]
+    mx = max(rows)
+    if stripe.shape[dim] < mx:
+        pad = list(stripe.shape)
+        pad[dim] = mx - stripe.shape[dim]
+        stripe = torch.cat([stripe, stripe.new_zeros(pad)], dim=dim)
+    return stripe.contiguous(), rows
+
+
+def assemble_root(stripe, rows_per_rank=None, root=0):
+    """stripe: [views, rows, ...] tensor of this rank's rows of every view (row counts may differ by rank: the stripes
+    are padded to a common height for the collective and trimmed afterwards).
+    Returns on `root` the assembled [views, sum(rows), ...] tensor (rank order = row order, so the
     reference's row-major scan order of 8/save_point_cloud.cpp:85 is preserved), None elsewhere."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
-    assert stripe.shape[1] == rows_per_rank
-    stripe = stripe.contiguous()
+    if rows_per_rank is not None:
+        assert stripe.shape[1] == rows_per_rank
+    stripe, rows = _equalise_rows(stripe)
     if rank == root:
         parts = [torch.empty_like(stripe) for _ in range(world)]
         dist.gather(stripe, gather_list=parts, dst=root)
-        return torch.cat(parts, dim=1)
+        return torch.cat([p[:, :n] for p, n in zip(parts, rows)], dim=1)
     dist.gather(stripe, gather_list=None, dst=root)
     return None
 
 
 def assemble_rotating(stripe, views_per_rank):
     """stripe: [world*views_per_rank, rows, ...].  View v is assembled on rank v // views_per_rank.
-    Returns this rank's [views_per_rank, world*rows, ...] assembled views (one all_to_all_single)."""
+    Returns this rank's [views_per_rank, sum(rows), ...] assembled views (one all_to_all_single; unequal stripe
+    heights are padded for the collective and trimmed afterwards)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
     assert stripe.shape[0] == world * views_per_rank
-    stripe = stripe.contiguous()
+    stripe, rows = _equalise_rows(stripe)
     out = torch.empty_like(stripe)  # [src_rank * views_per_rank + j, rows, ...]
     dist.all_to_all_single(out, stripe)
-    rows = stripe.shape[1]
-    out = out.view(world, views_per_rank, rows, *stripe.shape[2:])
-    return out.transpose(0, 1).reshape(views_per_rank, world * rows, *stripe.shape[2:])
+    mx = stripe.shape[1]
+    out = out.view(world, views_per_rank, mx, *stripe.shape[2:])
+    return torch.cat([out[r, :, :rows[r]] for r in range(world)], dim=1)
+
+
+class RootAssembler:
+    """Pipelined gather of row stripes to one root, chunk of views by chunk of views.
+
+    dense mode   : every rank sends, per view, its [rows, pitch*3] f32 xyz slab and [rows, pitch] u8 valid slab; they land
+                   in place in the root's [views, H, ...] buffers (a stripe of a view is a contiguous slab there).
+    compact mode : every rank sends, per view, the `count` valid points of its stripe (compacted in scan order by the fused
+                   kernel); the root concatenates them in rank order = the reference's scan order.  Counts travel first
+                   (one small all_gather per chunk), the payload sizes follow from them.
+
+    nccl: tensors are device tensors and the batch of sends/recvs of a chunk is ONE RCCL group on `comm_stream`, which
+    waits for the compute event of that chunk -- so the compute stream never waits for communication.
+    gloo (plumbing tests only): the same schedule, staged through host memory."""
+
+    def __init__(self, rows_by_rank, root=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world, self.rank, self.root = dist.get_world_size(), dist.get_rank(), root
+        self.rows = list(rows_by_rank)
+        self.row0 = [sum(self.rows[:r]) for r in range(self.world)]
+        self.nccl = dist.get_backend() == "nccl"
+        self.comm_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    # -- helpers ---------------------------------------------------------------------------------------------------
+    def _exchange(self, sends, recvs):
+        """sends: [(tensor, dst)], recvs: [(tensor, src)] -- one grouped batch.  Returns when the batch has been ENQUEUED
+        (nccl: on the current stream) or has completed (gloo)."""
+        dist = self.dist
+        ops = [dist.P2POp(dist.isend, t, d) for t, d in sends] + [dist.P2POp(dist.irecv, t, s) for t, s in recvs]
+        if not ops:
+            return
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()  # nccl: makes the current stream wait for the group, the host does not block
+
+    def gather_dense(self, views, pts, val, out_pts, out_val):
+        """pts [n, rows, pitch*3] f32 / val [n, rows, pitch] u8: this rank's stripes (device).  out_* (root only): dense
+        [n, H, ...] device buffers.  Sends views `views` (an iterable of indices).  Enqueues on the current stream."""
+        torch = self.torch
+        r0, n = self.row0[self.rank], self.rows[self.rank]
+        if self.rank == self.root:
+            recvs = []
+            stage = []
+            for v in views:
+                out_pts[v, r0:r0 + n].copy_(pts[v], non_blocking=True)
+                out_val[v, r0:r0 + n].copy_(val[v], non_blocking=True)
+                for src in range(self.world):
+                    if src == self.root or self.rows[src] == 0:
+                        continue
+                    a, b = self.row0[src], self.row0[src] + self.rows[src]
+                    if self.nccl:
+                        recvs += [(out_pts[v, a:b], src), (out_val[v, a:b], src)]
+                    else:
+                        hp = torch.empty(out_pts[v, a:b].shape, dtype=out_pts.dtype)
+                        hv = torch.empty(out_val[v, a:b].shape, dtype=out_val.dtype)
+                        recvs += [(hp, src), (hv, src)]
+                        stage += [(out_pts[v, a:b], hp), (out_val[v, a:b], hv)]
+            self._exchange([], recvs)
+            for dst, h in stage:
+                dst.copy_(h)
+        elif n > 0:
+            sends = []
+            for v in views:
+                if self.nccl:
+                    sends += [(pts[v], self.root), (val[v], self.root)]
+                else:
+                    sends += [(pts[v].cpu(), self.root), (val[v].cpu(), self.root)]
+            self._exchange(sends, [])
+
+    def gather_counts(self, counts):
+        """counts: python list (one per view of the chunk) of this rank's valid points -> [world][n] list on every rank."""
+        torch, dist = self.torch, self.dist
+        dev = "cuda" if self.nccl else "cpu"
+        mine = torch.tensor(counts, dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allc, mine)
+        return [[int(x) for x in c.tolist()] for c in allc]
+
+    def gather_compact(self, views, clouds, view_stride_pts, all_counts, out_cloud, out_offsets):
+        """clouds: flat f32 device tensor, view v's compacted points at [3*v*view_stride_pts, +3*count).  all_counts
+        [world][len(views)] from gather_counts.  out_cloud (root): flat f32 device buffer; out_offsets (root): per view,
+        the float offset at which that view's assembled cloud starts.  Enqueues on the current stream."""
+        torch = self.torch
+        if self.rank == self.root:
+            recvs, stage = [], []
+            for i, v in enumerate(views):
+                off = out_offsets[i]
+                for src in range(self.world):
+                    c = all_counts[src][i]
+                    if c:
+                        dst = out_cloud[off:off + 3 * c]
+                        if src == self.root:
+                            dst.copy_(clouds[3 * v * view_stride_pts:3 * v * view_stride_pts + 3 * c], non_blocking=True)
+                        elif self.nccl:
+                            recvs.append((dst, src))
+                        else:
+                            h = torch.empty(3 * c, dtype=out_cloud.dtype)
+                            recvs.append((h, src))
+                            stage.append((dst, h))
+                    off += 3 * c
+            self._exchange([], recvs)
+            for dst, h in stage:
+                dst.copy_(h)
+        else:
+            sends = []
+            for i, v in enumerate(views):
+                c = all_counts[self.rank][i]
+                if c:
+                    t = clouds[3 * v * view_stride_pts:3 * v * view_stride_pts + 3 * c]
+                    sends.append((t if self.nccl else t.cpu(), self.root))
+            self._exchange(sends, [])

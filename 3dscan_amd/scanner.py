@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SL3D_LIB") or os.path.join(_HERE, "libsl3d.so")
 
 SL3D_FLAG_KEEP_STAGES = 1
+SL3D_FLAG_GROUP_FORCE_RCCL, SL3D_FLAG_GROUP_NO_RCCL = 2, 4
 AXIS_VERTICAL, AXIS_HORIZONTAL = 0, 1
 PATTERN_FRINGE, PATTERN_GRAY, PATTERN_INVERSE_GRAY, PATTERN_BINARY = 0, 1, 2, 3
 VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
@@ -21,11 +22,15 @@ ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
     "sl3d_set_calibration", "sl3d_set_mask", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
-    "sl3d_run", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
+    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
     "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
-    "sl3d_get_device_buffers",
+    "sl3d_get_device_buffers", "sl3d_download",
+    "sl3d_group_create", "sl3d_group_destroy", "sl3d_group_last_error", "sl3d_group_size", "sl3d_group_stripe", "sl3d_group_transport",
+    "sl3d_group_set_calibration", "sl3d_group_set_mask", "sl3d_group_set_frames", "sl3d_group_run", "sl3d_group_gather",
+    "sl3d_group_get_points", "sl3d_group_get_device_buffers", "sl3d_group_run_clouds", "sl3d_group_gather_clouds",
+    "sl3d_group_get_cloud", "sl3d_group_synchronize",
 )
 
 
@@ -82,6 +87,8 @@ def load_library(path=None):
     L.sl3d_synth_view.argtypes = [vp, i, vp, C.c_uint64, i, i, C.c_float, C.c_float]
     L.sl3d_get_frames.argtypes = [vp, i, i, vp, i, C.c_size_t]
     L.sl3d_run.argtypes = [vp, i, i]
+    L.sl3d_run_clouds.argtypes = [vp, i, i]
+    L.sl3d_get_cloud_counts.argtypes = [vp, i, i, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
     L.sl3d_run_timed.argtypes = [vp, i, i, C.POINTER(C.c_float)]
     L.sl3d_synchronize.argtypes = [vp]
     L.sl3d_timer_start.argtypes = [vp]
@@ -110,7 +117,27 @@ def load_library(path=None):
     L.sl3d_pattern_counts.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
     L.sl3d_generate_pattern.argtypes = [vp, i, i, i, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sl3d_transform_cloud.argtypes = [vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    L.sl3d_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
+    L.sl3d_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), i, C.POINTER(vp)]
+    L.sl3d_group_destroy.argtypes = [vp]
+    L.sl3d_group_destroy.restype = None
+    L.sl3d_group_last_error.restype = C.c_char_p
+    L.sl3d_group_last_error.argtypes = [vp]
+    L.sl3d_group_transport.restype = C.c_char_p
+    L.sl3d_group_transport.argtypes = [vp]
+    L.sl3d_group_size.argtypes = [vp]
+    L.sl3d_group_stripe.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(vp)]
+    L.sl3d_group_set_calibration.argtypes = [vp] + [vp] * 8
+    L.sl3d_group_set_mask.argtypes = [vp, i, vp, C.c_size_t]
+    L.sl3d_group_set_frames.argtypes = [vp, i, i, vp, i, C.c_size_t]
+    for n in ("sl3d_group_run", "sl3d_group_gather", "sl3d_group_run_clouds"):
+        getattr(L, n).argtypes = [vp, i, i]
+    L.sl3d_group_gather_clouds.argtypes = [vp, i, i, C.POINTER(C.c_int64)]
+    L.sl3d_group_get_points.argtypes = [vp, i, vp, vp]
+    L.sl3d_group_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
+    L.sl3d_group_get_cloud.argtypes = [vp, i, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sl3d_group_synchronize.argtypes = [vp]
     if path is None:
         _lib = L
     return L
@@ -232,6 +259,33 @@ class Scanner:
     # ---- fused hot path -----------------------------------------------------------------------
     def run(self, first_view=0, n_views=1):
         self._chk(self.L.sl3d_run(self._h, first_view, n_views), "sl3d_run")
+
+    def run_clouds(self, first_view=0, n_views=1):
+        """The fused pass with the ordered compaction inside the kernel (sl3d_run_clouds); asynchronous."""
+        self._chk(self.L.sl3d_run_clouds(self._h, first_view, n_views), "sl3d_run_clouds")
+
+    def cloud_counts(self, first_view=0, n_views=1):
+        """(device address of the first cloud, points between clouds, [count per view]) after run_clouds; synchronises."""
+        counts = (C.c_int64 * n_views)()
+        ptr, stride = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.sl3d_get_cloud_counts(self._h, first_view, n_views, C.byref(ptr), C.byref(stride), counts), "sl3d_get_cloud_counts")
+        return ptr.value, stride.value, [int(c) for c in counts]
+
+    def fused_clouds(self, first_view=0, n_views=1):
+        """run_clouds + host copies: list of (n_k, 3) float32 arrays in the reference's scan order."""
+        self.run_clouds(first_view, n_views)
+        ptr, stride, counts = self.cloud_counts(first_view, n_views)
+        out = []
+        for k, n in enumerate(counts):
+            a = np.empty((n, 3), dtype=np.float32)
+            if n:
+                self._d2h(a, ptr + 12 * k * stride)
+            out.append(a)
+        return out
+
+    def _d2h(self, arr, dev_ptr):
+        """Device -> host copy of an address the library handed out (sl3d_download)."""
+        self._chk(self.L.sl3d_download(self._h, arr.ctypes.data, dev_ptr, arr.nbytes), "sl3d_download")
 
     def run_timed(self, first_view=0, n_views=1):
         ms = C.c_float(0)
@@ -386,3 +440,101 @@ class Scanner:
         b = DeviceBuffers()
         self._chk(self.L.sl3d_get_device_buffers(self._h, C.byref(b)), "sl3d_get_device_buffers")
         return b
+
+
+class Group:
+    """sl3d_group_*: n row stripes of one frame window, stripe i on HIP device devices[i], assembled on stripe 0's GPU
+    (RCCL send/recv between GPUs, device copies inside one)."""
+
+    def __init__(self, width, height, proj_width, proj_height, n_gray_v, n_gray_h, fringe_width_v, fringe_width_h, devices,
+                 n_fringe=3, max_views=1, full_size=None, origin=(0, 0), flags=0):
+        self.L = load_library()
+        fw, fh = full_size if full_size else (width, height)
+        self.cfg = Config(width, height, fw, fh, origin[0], origin[1], proj_width, proj_height, n_fringe,
+                          n_gray_v, n_gray_h, fringe_width_v, fringe_width_h, 0, 0, max_views, 0, flags, None)
+        self.W, self.H = width, height
+        devs = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        rc = self.L.sl3d_group_create(C.byref(self.cfg), devs, len(devices), C.byref(self._h))
+        if rc != 0:
+            raise Sl3dError(f"sl3d_group_create: {self.L.sl3d_strerror(rc).decode()}: {self.L.sl3d_group_last_error(None).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.sl3d_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Sl3dError(f"{what}: {self.L.sl3d_strerror(rc).decode()}: {self.L.sl3d_group_last_error(self._h).decode()}")
+
+    @property
+    def transport(self):
+        return self.L.sl3d_group_transport(self._h).decode()
+
+    def stripes(self):
+        """[(row0, rows, device, ctx handle)] of every stripe."""
+        out = []
+        for k in range(self.L.sl3d_group_size(self._h)):
+            r0, n, d, h = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
+            self._chk(self.L.sl3d_group_stripe(self._h, k, C.byref(r0), C.byref(n), C.byref(d), C.byref(h)), "sl3d_group_stripe")
+            out.append((r0.value, n.value, d.value, h))
+        return out
+
+    def set_calibration(self, Kc, dc, rc, tc, Kp, dp, rp, tp):
+        a = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel()) for v in (Kc, dc, rc, tc, Kp, dp, rp, tp)]
+        self._chk(self.L.sl3d_group_set_calibration(self._h, *[v.ctypes.data for v in a]), "sl3d_group_set_calibration")
+
+    def set_mask(self, full_frame_mask, view=0):
+        m = np.ascontiguousarray(full_frame_mask, dtype=np.uint8)
+        assert m.shape == (self.cfg.full_height, self.cfg.full_width), m.shape
+        self._chk(self.L.sl3d_group_set_mask(self._h, view, m.ctypes.data, m.strides[0]), "sl3d_group_set_mask")
+
+    def set_frames(self, axis, planes, view=0):
+        arrs = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+        for a in arrs:
+            assert a.shape == (self.H, self.W), a.shape
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._chk(self.L.sl3d_group_set_frames(self._h, view, axis, ptrs, len(arrs), arrs[0].strides[0]), "sl3d_group_set_frames")
+
+    def run(self, first_view=0, n_views=1):
+        self._chk(self.L.sl3d_group_run(self._h, first_view, n_views), "sl3d_group_run")
+
+    def gather(self, first_view=0, n_views=1):
+        self._chk(self.L.sl3d_group_gather(self._h, first_view, n_views), "sl3d_group_gather")
+
+    def points(self, view=0):
+        xyz = np.empty((self.H, self.W, 3), dtype=np.float32)
+        valid = np.empty((self.H, self.W), dtype=np.uint8)
+        self._chk(self.L.sl3d_group_get_points(self._h, view, xyz.ctypes.data, valid.ctypes.data), "sl3d_group_get_points")
+        return xyz, valid
+
+    def run_clouds(self, first_view=0, n_views=1):
+        self._chk(self.L.sl3d_group_run_clouds(self._h, first_view, n_views), "sl3d_group_run_clouds")
+
+    def gather_clouds(self, first_view=0, n_views=1):
+        counts = (C.c_int64 * n_views)()
+        self._chk(self.L.sl3d_group_gather_clouds(self._h, first_view, n_views, counts), "sl3d_group_gather_clouds")
+        return [int(c) for c in counts]
+
+    def cloud(self, view=0):
+        n = C.c_int64(0)
+        self._chk(self.L.sl3d_group_get_cloud(self._h, view, None, 0, C.byref(n)), "sl3d_group_get_cloud")
+        out = np.empty((n.value, 3), dtype=np.float32)
+        self._chk(self.L.sl3d_group_get_cloud(self._h, view, out.ctypes.data, n.value, C.byref(n)), "sl3d_group_get_cloud")
+        return out
+
+    def synchronize(self):
+        self._chk(self.L.sl3d_group_synchronize(self._h), "sl3d_group_synchronize")

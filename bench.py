@@ -2,16 +2,21 @@
 """Benchmark of the fused decode -> unwrap -> correspond -> triangulate kernel (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE from env)
 
-Workload (configs[1] of BASELINE.json): 1920x1080 camera, 3 phase-shift + 10 Gray-code bit planes per
-axis, reference-faithful two-axis mode (every Gray frame is thresholded against its inverse frame, so a
-view is 2*(3+10+10) = 46 frames), synthetic captures resident in HBM.  A step is ONE launch of the fused
-kernel over a batch of `--views` views per GPU (default 16, i.e. 2 GB of frames + results: larger than
-the 256 MiB Infinity Cache, so the kernel really streams from HBM).  With N GPUs every view is sharded by
-image rows (1080/N rows per GPU) and the batch grows to N*views views, so per-GPU work is fixed (weak
-scaling); no collective is needed by the per-pixel map itself (the mask halo comes from the input mask).
-The optional assembly of the dense clouds over RCCL is measured separately and reported in `assemble`.
+N > 1: one process per GPU over torch.distributed (backend nccl = RCCL).  Started by torch.distributed.run (the driver's
+way: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) each process is a rank; started plainly, `python
+bench.py --gpus N` spawns its N ranks itself as fresh child processes -- before this process has touched the GPU, and
+never by exec -- and prints rank 0's JSON line.
+
+Workload (configs[1] of BASELINE.json): 1920x1080 camera, 3 phase-shift + 10 Gray-code bit planes per axis,
+reference-faithful two-axis mode (every Gray frame is thresholded against its inverse frame, so a view is
+2*(3+10+10) = 46 frames), synthetic captures resident in HBM.  A step is ONE launch of the fused kernel over a batch of
+`--views` views per GPU (default 16, i.e. 2 GB of frames + results: larger than the 256 MiB Infinity Cache, so the kernel
+really streams from HBM).  With N GPUs every view is sharded by image rows (1080/N rows per GPU) and the batch grows to
+N*views views, so per-GPU work is fixed (weak scaling); the per-pixel map needs no collective (the mask halo comes from
+the input mask).  `value` is that compute-only rate.  The assembly of the clouds on rank 0 -- the north star's "single RCCL
+gather" -- is measured too and reported as `with_assembly`: end to end, pipelined per chunk of views on a communication
+stream beside the compute stream, dense (xyz + valid) and compacted (valid points only, compacted by the fused kernel).
 
 The defaults (300 warm-up + 2000 timed launches, ~1 s of GPU time) let the clocks settle: the kernel runs the package
 into its power limit (~1.4 kW), and a 25 ms run from idle measures the ramp, not the steady state.  For the same reason
@@ -20,6 +25,7 @@ the set-up ends with --precondition-ms (0.4 s) of launches before the W warm-up 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -33,17 +39,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 
 
 def measured_traffic(px_per_launch):
-    """HBM bytes per launch of the fused kernel from the latest committed PMC run (tools/profile.sh +
+    """HBM bytes per launch of the fused kernel from the latest COMMITTED PMC run (tools/profile.sh +
     tools/summarize_profile.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, scaled by the factors
-    calibrated on tools/membench in the same session).  The profile is taken on this same command; bytes scale
-    with the pixels per launch.  None if no profile has been committed."""
+    calibrated on tools/membench in the same session), scaled to the pixels of this launch.  Not measured in this run:
+    the source file is named beside the number.  (None, None) if no profile has been committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
+        return None, None
     t = json.load(open(files[-1]))
     scale = px_per_launch / (t["algorithmic_bytes_per_launch"] / 60.0)
-    return round(t["hbm_bytes_per_launch"] * scale)
+    return round(t["hbm_bytes_per_launch"] * scale), os.path.relpath(files[-1], ROOT)
 
 
 def parse():
@@ -60,12 +66,18 @@ def parse():
     ap.add_argument("--precondition-ms", type=float, default=400.0,
                     help="part of the SETUP, before the W warm-up steps: run the kernel for this long so that the clocks have "
                          "left the idle state whatever W is (the package is power-managed; see profiles/README.md). 0 disables")
-    ap.add_argument("--rig", default="reference", choices=["reference", "distorted"],
+    ap.add_argument("--rig", default="reference", choices=["reference", "distorted", "general"],
                     help="reference = the reference's calibration rescaled (BASELINE workload); distorted = the same rig with "
-                         "projector distortion and camera tangential terms, i.e. the general stage-7 path (sweeps only)")
+                         "projector distortion and camera tangential terms (table path); general = skewed camera matrix as well "
+                         "(everything evaluated in the kernel) -- the other two are sweeps / side figures only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-assemble", action="store_true", help="skip the separate RCCL assembly measurement (N>1)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side figures (1 view latency, other rigs, N=9)")
+    ap.add_argument("--no-assemble", action="store_true", help="skip the assembly measurements (N>1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--devices", default="", help="comma-separated HIP device per rank (default: LOCAL_RANK). Repeating a device "
+                                                  "is refused with nccl and allowed with gloo (plumbing tests on one GPU)")
+    ap.add_argument("--chunks", type=int, default=4, help="chunks of views the assembly pipeline works in")
+    ap.add_argument("--check", action="store_true", help="add SHA-256 digests of the assembled results (dense and compacted) to the line")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of one view timed on the CPU (0 = whole view)")
     return ap.parse_args()
 
@@ -75,6 +87,10 @@ class _DevMem:
 
     def __init__(self, ptr, nbytes):
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def dev_tensor(torch, ptr, nbytes, dtype, device):
+    return torch.as_tensor(_DevMem(ptr, nbytes), device=device).view(dtype)
 
 
 def usable_cores():
@@ -89,7 +105,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(args, cap, cal, gpu_valid, gpu_xyz, gpu_cp_note):
+def cpu_baseline(args, cap, cal, gpu_valid, gpu_xyz):
     """The oracle (CPU restatement of the reference loop: single thread, [col][row] arrays, pow() per bit,
     fenv per pixel, stage-7 tables rebuilt per scan as triangulate() does) timed on one view of the
     same workload; its results also check the GPU output of that view."""
@@ -147,20 +163,96 @@ def cpu_baseline(args, cap, cal, gpu_valid, gpu_xyz, gpu_cp_note):
     }
 
 
+def rig_calibration(syn, np, rig, W, H, PW, PH):
+    cal_d = syn.synth_rig(W, H, PW, PH)
+    if rig in ("distorted", "general"):
+        cal_d["dp"] = np.array([-0.05, 0.02, 0.001, -0.0005, 0.0])
+        cal_d["dc"] = np.array(cal_d["dc"], dtype=np.float64) + np.array([0.0, 0.0, 0.0008, -0.0006, 0.0])
+    if rig == "general":
+        Kc = np.array(cal_d["Kc"], dtype=np.float64).reshape(3, 3).copy()
+        Kc[0, 1] = 0.35   # skew: the camera matrix is no longer "plain", so the camera-frame solve does not apply (RIG 0)
+        cal_d["Kc"] = Kc.ravel()
+    return syn.cal_tuple(cal_d)
+
+
+def steady_rate(sc, n_views, px_per_launch, alg_bytes_px, launches, precondition_ms=200.0, clouds=False):
+    """Launch `launches` times back to back after a short preconditioning; -> (Mpx/s, roofline fraction, ms per launch)."""
+    run = (lambda: sc.run_clouds(0, n_views)) if clouds else (lambda: sc.run(0, n_views))
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < precondition_ms:
+        for _ in range(20):
+            run()
+        sc.synchronize()
+    sc.timer_start()
+    for _ in range(launches):
+        run()
+    ms = sc.timer_stop() / launches
+    return round(px_per_launch / ms / 1e3, 1), round(alg_bytes_px * px_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(ms, 4)
+
+
+def side_figures(args, scm, syn, np, dev_index):
+    """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`."""
+    W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
+    out = {}
+    full_mask = syn.default_mask(W, H)
+
+    def ctx(rig, n_gray, views):
+        sc = scm.Scanner(W, H, W, H, n_gray, n_gray, fw, fw, max_views=views, device=dev_index)
+        sc.set_calibration(*rig_calibration(syn, np, rig, W, H, W, H))
+        for v in range(views):
+            sc.set_mask(full_mask, view=v)
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=args.noise)
+        sc.synchronize()
+        return sc
+
+    try:
+        with ctx("reference", N, 1) as sc:   # the reference's real usage: one view per scan (m_tech_project_console.cpp:372-395)
+            v, f, ms = steady_rate(sc, 1, W * H, 20 + 4 * N, 2000)
+            out["one_view_latency"] = {"value": v, "unit": "Mpixels/s", "frac": f, "launch_us": round(ms * 1e3, 2),
+                                       "note": "1 view per launch, back to back; the 124 MB working set sits in the Infinity Cache"}
+        for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig0_general")):
+            with ctx(rig, N, args.views) as sc:
+                v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 400)
+                out[key] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms}
+        with ctx("reference", N - 1, args.views) as sc:
+            v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * (N - 1), 400)
+            out[f"n_gray_{N - 1}"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "algorithmic_bytes_per_pixel": 20 + 4 * (N - 1)}
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
+
+
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dmod = importlib.import_module("3dscan_amd.distributed")   # imports neither torch nor the HIP runtime
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process stays off the GPU and starts the N ranks as fresh children
+        out = dmod.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        if not lines:
+            raise SystemExit("rank 0 printed no JSON line:\n" + out)
+        print(lines[-1], flush=True)
+        return
+    rank, local_rank, world = dmod.env_ranks()
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: start with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or without it (bench.py then spawns its ranks itself)")
+
     import numpy as np
     # torch first: its bundled HIP runtime must be the one libsl3d.so binds to (one runtime per process)
     import torch
     import torch.distributed as dist
 
-    dmod = importlib.import_module("3dscan_amd.distributed")
-    rank, local_rank, world = dmod.env_ranks()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)  # one GPU per rank on a real node
+    ndev = torch.cuda.device_count()   # counting does not initialise the GPU
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(world))
+    if len(devs) != world:
+        raise SystemExit(f"--devices names {len(devs)} devices for {world} ranks")
+    if max(devs) >= ndev:
+        raise SystemExit(f"rank {rank}: device {max(devs)} requested but only {ndev} GPU(s) are visible (--gpus {world} needs {world})")
+    if world > 1 and args.backend == "nccl" and len(set(devs)) != world:
+        raise SystemExit("RCCL needs one GPU per rank: --devices repeats a device (use --backend gloo for single-GPU plumbing tests)")
+    dev_index = devs[rank]
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -179,12 +271,10 @@ def main():
 
     # ---- synthetic inputs, generated on the device, resident in HBM before the timed region ----
     # every view is a different plane seen by the same rig, with its own noise stream (sl3d_synth_view / k_synth)
-    cal_d = syn.synth_rig(W, H, PW, PH)
-    if args.rig == "distorted":
-        cal_d["dp"] = np.array([-0.05, 0.02, 0.001, -0.0005, 0.0])
-        cal_d["dc"] = np.array(cal_d["dc"], dtype=np.float64) + np.array([0.0, 0.0, 0.0008, -0.0006, 0.0])
-    cal = syn.cal_tuple(cal_d)
-    sc = scm.Scanner(W, rows, PW, PH, N, N, fw, fw, max_views=n_views, device=dev_index, full_size=(W, H), origin=(0, row0))
+    cal = rig_calibration(syn, np, args.rig, W, H, PW, PH)
+    compute_stream = torch.cuda.Stream(device=dev)   # the context launches on it, so torch events can order communication after it
+    sc = scm.Scanner(W, rows, PW, PH, N, N, fw, fw, max_views=n_views, device=dev_index, full_size=(W, H), origin=(0, row0),
+                     stream=compute_stream.cuda_stream)
     sc.set_calibration(*cal)
     full_mask = syn.default_mask(W, H)
     for v in range(n_views):
@@ -217,17 +307,20 @@ def main():
     ev_ms = dmod.max_over_ranks(ev_ms, red_dev)
 
     px_per_launch = n_views * rows * W                     # pixels one launch processes on one GPU
-    total_px = args.steps * px_per_launch * world
-    value = total_px / dt / 1e6
+    px_per_step = n_views * H * W                          # ... and all ranks together
+    value = args.steps * px_per_step / dt / 1e6
     alg_bytes_px = 2 * 3 + 4 * N + 1 + 13                  # read 2F+2Nv+2Nh frame bytes + 1 mask, write xyz f32 + valid
     launch_s = ev_ms / 1e3 / args.steps
     achieved = alg_bytes_px * px_per_launch / launch_s / 1e9
 
-    nmax = next(m for m in (6, 8, 10, 12, 16) if m >= N)   # the instantiation launch_fused picks (sl3d_kernels.hip)
-    kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if nmax == N else 'false'}, {1 if args.rig == 'reference' else 2}>"
+    exact = 6 <= N <= 12                                   # the instantiation launch_fused picks (sl3d_kernels.hip)
+    nmax = N if exact else next(m for m in (8, 12, 16) if m >= N)
+    rig_id = {"reference": 1, "distorted": 2, "general": 0}[args.rig]
+    kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if exact else 'false'}, {rig_id}, false>"
+    traffic, traffic_src = measured_traffic(px_per_launch) if alg_bytes_px == 60 else (None, None)
 
     out = {
-        "metric": "Mpixels/s decode+unwrap+triangulate @1920\u00d71080",
+        "metric": "Mpixels/s decode+unwrap+triangulate @1920×1080",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (planes through the reference rig, generated on the device, a different plane and noise stream per view)",
@@ -239,38 +332,56 @@ def main():
                    "rig": args.rig, "setup_preconditioning_ms": args.precondition_ms},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": measured_traffic(px_per_launch) if alg_bytes_px == 60 else None,
+                     "traffic": traffic, "traffic_source": traffic_src and f"{traffic_src} (committed PMC run of this command, scaled to this launch; not measured in this run)",
                      "kernel": kernel_name, "algorithmic_bytes_per_pixel": alg_bytes_px,
                      "pixels_per_launch": px_per_launch, "avg_launch_ms": round(launch_s * 1e3, 4)},
     }
 
-    # end to end from device-resident frames to compacted clouds: the fused kernel + the batched compaction of
-    # every view (three more launches and one read-back of the counts per step); a side figure, never `value`
+    # end to end from device-resident frames to compacted clouds: ONE launch, the compaction of
+    # 8/save_point_cloud.cpp:85-104 happens inside the fused kernel (sl3d_run_clouds), plus the read-back of the counts;
+    # a side figure, never `value`
     try:
         for _ in range(20):
-            sc.run(0, n_views)
-            sc.compact_views(0, n_views)
+            sc.run_clouds(0, n_views)
+        counts = sc.cloud_counts(0, n_views)[2]
         barrier()
-        t0 = time.perf_counter()
         reps = max(20, args.steps // 10)
+        t0 = time.perf_counter()
         for _ in range(reps):
-            sc.run(0, n_views)
-            counts = sc.compact_views(0, n_views)
+            sc.run_clouds(0, n_views)
+            counts = sc.cloud_counts(0, n_views)[2]
         barrier()
         te = dmod.max_over_ranks((time.perf_counter() - t0) / reps, red_dev)
-        out["to_compacted_clouds"] = {"value": round(px_per_launch * world / te / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(te * 1e3, 4),
-                                      "valid_points_per_step_rank0": int(sum(counts))}
+        sc.timer_start()
+        for _ in range(reps):
+            sc.run_clouds(0, n_views)
+        kms = dmod.max_over_ranks(sc.timer_stop() / reps, red_dev)
+        vf = sum(counts) / float(px_per_launch)
+        out["to_compacted_clouds"] = {"value": round(px_per_step / te / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(te * 1e3, 4),
+                                      "kernel_only": {"value": round(px_per_step / kms / 1e3, 1), "ms_per_launch": round(kms, 4)},
+                                      "valid_points_per_step_rank0": int(sum(counts)), "valid_fraction_rank0": round(vf, 4),
+                                      "algorithmic_bytes_per_pixel": round(2 * 3 + 4 * N + 1 + 1 + 12 * vf, 2),
+                                      "how": "one launch: ordered compaction inside the fused kernel (decoupled look-back over 1024-pixel tiles)"}
     except Exception as e:
         out["to_compacted_clouds"] = {"error": repr(e)}
 
+    digests = {}
     if world > 1 and not args.no_assemble:
-        out["assemble"] = measure_assemble(torch, dist, dmod, sc, n_views, V, rows, rank, world)
+        out["with_assembly"] = measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, V, rows, W, H, rank, world, px_per_step, digests)
+    elif args.check:
+        digests = single_rank_digests(np, sc, n_views)
+    if args.check:
+        out["check"] = digests
+
+    if rank == 0 and world == 1 and not args.no_side:
+        out["side"] = side_figures(args, scm, syn, np, dev_index)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sc.run(0, n_views)
         xyz, valid = sc.points(0)
         try:
             cap0 = {"planes_v": sc.frames(0, 0), "planes_h": sc.frames(1, 0)}  # the very bytes the GPU processed
-            out["cpu_baseline"] = cpu_baseline(args, cap0, cal, valid, xyz, None)
+            out["cpu_baseline"] = cpu_baseline(args, cap0, cal, valid, xyz)
             # what the C ABI delivers when the boundary hands over HOST buffers (never `value`):
             # (a) serial: upload of the 46 frames of one view, one launch, download of xyz + valid, pageable numpy memory
             ts = []
@@ -301,6 +412,20 @@ def main():
             out["host_buffers_pipelined"] = {"value": round(nv * W * rows / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_view": round(t / nv * 1e3, 2),
                                              "note": f"{nv} host-resident views, upload / kernel / download overlapped on 3 streams, pinned memory",
                                              "equals_resident_result": same}
+            # (c) the per-scan mask hand-over of the reference's loop (selected_region changes every scan)
+            pm = sc.pinned(full_mask.shape, np.uint8)
+            pm[:] = full_mask
+            for name, src in (("pinned", pm), ("pageable", full_mask)):
+                sc.synchronize()
+                ts = []
+                for _ in range(20):
+                    t0 = time.perf_counter()
+                    sc.set_mask(src, view=0)
+                    tcall = time.perf_counter() - t0
+                    sc.synchronize()
+                    ts.append((tcall, time.perf_counter() - t0))
+                ts.sort()
+                out.setdefault("set_mask_us", {})[name] = {"call": round(ts[10][0] * 1e6, 1), "until_ready": round(sorted(x[1] for x in ts)[10] * 1e6, 1)}
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"error": repr(e)}
     sc.close()
@@ -311,31 +436,131 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_assemble(torch, dist, dmod, sc, n_views, V, rows, rank, world):
-    """Assembly of the dense clouds over RCCL, outside the timed region: (a) gather of every stripe to rank 0,
-    (b) rotating roots (one all_to_all).  Reported as time per batch and the rate it would sustain."""
+def single_rank_digests(np, sc, n_views):
+    """SHA-256 of what an assembly on rank 0 must reproduce: the dense xyz + valid planes and the compacted clouds of every view."""
+    sc.run(0, n_views)
+    hd, hc = hashlib.sha256(), hashlib.sha256()
+    for v in range(n_views):
+        xyz, val = sc.points(v)
+        hd.update(xyz.tobytes()); hd.update(val.tobytes())
+    for c in sc.fused_clouds(0, n_views):
+        hc.update(c.tobytes())
+    return {"dense_sha256": hd.hexdigest(), "compact_sha256": hc.hexdigest()}
+
+
+def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, V, rows, W, H, rank, world, px_per_step, digests):
+    """End to end WITH the assembly of the clouds on rank 0 (the north star's single gather), pipelined: the batch is cut
+    into chunks of views; chunk k's stripes leave on the communication stream (one grouped batch of sends that land in place
+    in the root's dense planes) while the compute stream already runs chunk k+1.  dense = xyz + valid (13 B/px);
+    compact = the valid points only, compacted by the fused kernel (counts first).  Also the rotating-roots all_to_all
+    (every rank assembles its share of the views: all links busy), as one blocking collective after the compute."""
     res = {}
+    nccl = args.backend == "nccl"
     try:
         b = sc.device_buffers()
         pitch = b.frame_pitch
-        pts = torch.as_tensor(_DevMem(b.points, n_views * b.points_view_stride), device="cuda").view(torch.float32)
-        pts = pts.view(n_views, rows, pitch * 3)
-        val = torch.as_tensor(_DevMem(b.valid, n_views * b.valid_view_stride), device="cuda").view(n_views, rows, pitch)
-        nbytes = pts.numel() * 4 + val.numel()
-        for name, fn in (("root_gather", lambda: (dmod.assemble_root(pts, rows), dmod.assemble_root(val, rows))),
-                         ("rotating_all_to_all", lambda: (dmod.assemble_rotating(pts, V), dmod.assemble_rotating(val, V)))):
-            fn()
-            torch.cuda.synchronize(); dist.barrier()
+        pts = dev_tensor(torch, b.points, n_views * b.points_view_stride, torch.float32, dev).view(n_views, rows, pitch * 3)
+        val = dev_tensor(torch, b.valid, n_views * b.valid_view_stride, torch.uint8, dev).view(n_views, rows, pitch)
+        rows_by_rank = [dmod.shard_rows(H, world, r)[1] for r in range(world)]
+        asm = dmod.RootAssembler(rows_by_rank)
+        comm = asm.comm_stream
+        root = rank == 0
+        out_pts = torch.empty((n_views, H, pitch * 3), dtype=torch.float32, device=dev) if root else None
+        out_val = torch.empty((n_views, H, pitch), dtype=torch.uint8, device=dev) if root else None
+        nchunks = max(1, min(args.chunks, n_views))
+        bounds = [n_views * k // nchunks for k in range(nchunks + 1)]
+        chunks = [(bounds[k], bounds[k + 1] - bounds[k]) for k in range(nchunks) if bounds[k + 1] > bounds[k]]
+        ev_run = [torch.cuda.Event() for _ in chunks]
+        ev_comm = [torch.cuda.Event() for _ in chunks]
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        def timed(step, reps):
+            step(first=True)
+            barrier()
             t0 = time.perf_counter()
-            reps = 3
             for _ in range(reps):
-                fn()
-            torch.cuda.synchronize(); dist.barrier()
-            t = dmod.max_over_ranks((time.perf_counter() - t0) / reps, pts.device)
-            res[name] = {"ms_per_batch": round(t * 1e3, 3), "GB_per_rank": round(nbytes / 1e9, 4),
-                         "job_Mpixels_per_s_if_serialised": round(n_views * rows * world * (pitch) / t / 1e6, 1)}
+                step(first=False)
+            comm.synchronize()
+            barrier()
+            return dmod.max_over_ranks((time.perf_counter() - t0) / reps, dev if nccl else None)
+
+        # ---- dense: xyz + valid of every stripe to rank 0 ----
+        def dense_step(first):
+            for k, (f, n) in enumerate(chunks):
+                if not first:
+                    compute_stream.wait_event(ev_comm[k])      # the chunk's results may be overwritten only once they have left
+                sc.run(f, n)
+                ev_run[k].record(compute_stream)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev_run[k])
+                    asm.gather_dense(range(f, f + n), pts, val, out_pts, out_val)
+                    ev_comm[k].record(comm)
+
+        reps = max(3, min(50, args.steps // 40))
+        t = timed(dense_step, reps)
+        res["dense_root_gather"] = {"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 3),
+                                    "bytes_into_root_per_step": int((n_views * (H - rows_by_rank[0]) * pitch * 13)),
+                                    "chunks": len(chunks), "overlapped_with_compute": True}
+        if args.check and root:
+            h = hashlib.sha256()
+            for v in range(n_views):
+                h.update(out_pts[v].view(H, pitch, 3)[:, :W].contiguous().cpu().numpy().tobytes())
+                h.update(out_val[v][:, :W].contiguous().cpu().numpy().tobytes())
+            digests["dense_sha256"] = h.hexdigest()
+
+        # ---- compact: the valid points only, compacted by the fused kernel ----
+        sc.run_clouds(0, n_views)
+        cptr, cstride, _ = sc.cloud_counts(0, n_views)
+        clouds = dev_tensor(torch, cptr, n_views * cstride * 12, torch.float32, dev)
+        out_cloud = torch.empty(n_views * H * pitch * 3, dtype=torch.float32, device=dev) if root else None
+        state = {}
+
+        def compact_step(first):
+            off = 0
+            offs_all, counts_all = [], []
+            for k, (f, n) in enumerate(chunks):
+                if not first:
+                    compute_stream.wait_event(ev_comm[k])
+                sc.run_clouds(f, n)
+                counts = sc.cloud_counts(f, n)[2]                # waits for this chunk's kernel: the payload sizes come from it
+                with torch.cuda.stream(comm):
+                    allc = asm.gather_counts(counts)
+                    tot = [sum(allc[r][i] for r in range(world)) for i in range(n)]
+                    offs = [3 * (off + sum(tot[:i])) for i in range(n)]
+                    asm.gather_compact(range(f, f + n), clouds, cstride, allc, out_cloud, offs)
+                    ev_comm[k].record(comm)
+                offs_all += offs
+                counts_all += tot
+                off += sum(tot)
+            state["offs"], state["counts"] = offs_all, counts_all
+
+        t = timed(compact_step, reps)
+        res["compact_root_gather"] = {"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 3),
+                                      "points_per_step": int(sum(state["counts"])), "chunks": len(chunks), "overlapped_with_compute": True}
+        if args.check and root:
+            h = hashlib.sha256()
+            for o, c in zip(state["offs"], state["counts"]):
+                h.update(out_cloud[o:o + 3 * c].cpu().numpy().tobytes())
+            digests["compact_sha256"] = h.hexdigest()
+
+        # ---- rotating roots: one all_to_all after the compute (every rank assembles V of the views) ----
+        if nccl:
+            def rot_step(first):
+                sc.run(0, n_views)
+                ev_run[0].record(compute_stream)
+                torch.cuda.current_stream().wait_event(ev_run[0])
+                dmod.assemble_rotating(pts, V)
+                dmod.assemble_rotating(val, V)
+                torch.cuda.current_stream().synchronize()
+            t = timed(rot_step, reps)
+            res["dense_rotating_all_to_all"] = {"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 3),
+                                                "overlapped_with_compute": False}
     except Exception as e:
-        res["error"] = repr(e)
+        import traceback
+        res["error"] = repr(e) + " | " + traceback.format_exc().splitlines()[-3].strip()
     return res
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL3D_VERSION_STRING "0.1.0"
+#define SL3D_VERSION_STRING "0.2.0"
 
 typedef struct sl3d_ctx sl3d_ctx;
 
@@ -56,7 +56,11 @@ enum sl3d_flags {
      * debug images, c_p_map, intersection_points).  Required for the per-stage entry points and
      * their getters; sl3d_run() then also stores them ("parity mode", +~70 B/px of traffic).
      * Without it only sl3d_run() and the point / valid getters are available (the timed mode). */
-    SL3D_FLAG_KEEP_STAGES = 1u
+    SL3D_FLAG_KEEP_STAGES = 1u,
+    /* sl3d_group_create only.  FORCE_RCCL: every stripe but the root's own travels by RCCL send/recv even when it shares the
+     * root's GPU (exercises the RCCL path on a single-GPU box); NO_RCCL: (peer) device copies even across GPUs. */
+    SL3D_FLAG_GROUP_FORCE_RCCL = 2u,
+    SL3D_FLAG_GROUP_NO_RCCL = 4u
 };
 
 /* Replaces the compile-time macros and initialised globals of the reference:
@@ -126,13 +130,18 @@ int sl3d_set_calibration(sl3d_ctx *ctx,
 
 /* selected_region of image_scissor() m_tech_project_console.cpp:146-238, handed over as a
  * FULL-FRAME row-major u8 plane (full_width x full_height); a pixel is selected iff byte == 1
- * (every consumer in the reference tests `== 1`).  The context copies its window plus halo. */
+ * (every consumer in the reference tests `== 1`).  The context copies its window plus a 2-pixel halo in ONE 2-D copy and
+ * prepares it on the device (bytes normalised to 0/1, border band of the boundary removal evaluated by a kernel): no host
+ * pass over the mask.  Pageable memory is consumed before the call returns; PINNED memory (sl3d_host_alloc) is read by
+ * asynchronous DMA on the context's stream, so it must stay unchanged until the next synchronising call on the context
+ * (any getter, sl3d_synchronize) -- the call then costs a copy and a launch (tens of microseconds at 1080p). */
 int sl3d_set_mask(sl3d_ctx *ctx, int view, const uint8_t *full_frame_mask, size_t stride);
 
 /* The captured frames of one axis of one view, window-sized planes in host memory: what
  * read_image() 3/wrapped_phase.cpp:29-58 (n_fringe planes) and read_captured_images()
  * 4/phase_unwrap.cpp:51-131 (n_gray planes + n_gray inverse planes) load.
- * planes[] order: fringe[0..F), gray[0..N), inverse_gray[0..N). */
+ * planes[] order: fringe[0..F), gray[0..N), inverse_gray[0..N).  Planes that follow each other in host memory (plane i+1
+ * at plane i + stride*height) go up as ONE 2-D copy per axis.  Pageable / pinned memory: as for sl3d_set_mask. */
 int sl3d_set_frames(sl3d_ctx *ctx, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride);
 
 /* Device-to-device duplicate of one resident view (frame stack + mask) into another slot of the batch. */
@@ -162,7 +171,16 @@ int sl3d_triangulate(sl3d_ctx *ctx, int view);
  * float cast of 8/save_point_cloud.cpp:100-102, for views [first_view, first_view+n_views), as ONE
  * kernel launch that reads every frame byte once and writes xyz (f32) + valid (u8). Asynchronous. */
 int sl3d_run(sl3d_ctx *ctx, int first_view, int n_views);
-/* same, bracketed by HIP events on the context's stream; returns the kernel time of this launch */
+/* The same pass with the compaction of 8/save_point_cloud.cpp:33-37,85-104 INSIDE the kernel: instead of the dense xyz plane
+ * every view's valid points are written once, already compacted in the reference's row-major scan order (tile prefixes by a
+ * decoupled look-back between the blocks of the launch), plus the valid map.  ~47 + 12*valid_fraction + 1 bytes per pixel
+ * instead of 60 for the dense pass + 25 for a separate compaction.  Timed mode only (no SL3D_FLAG_KEEP_STAGES).  Asynchronous;
+ * sl3d_get_cloud_counts synchronises and returns, for views [first_view, first_view+n_views), the number of points of each
+ * cloud and where they are in HBM: view first_view+k's cloud is counts[k] points (3 floats each) at
+ * *device_xyz + 3*k*(*view_stride_points), valid until the next sl3d_run_clouds / sl3d_compact_views on this context. */
+int sl3d_run_clouds(sl3d_ctx *ctx, int first_view, int n_views);
+int sl3d_get_cloud_counts(sl3d_ctx *ctx, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts);
+/* sl3d_run bracketed by HIP events on the context's stream; returns the kernel time of this launch */
 int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);
 int sl3d_synchronize(sl3d_ctx *ctx);
 /* HIP-event stopwatch on the context's stream (the stream the kernels are launched on): start
@@ -270,8 +288,67 @@ int sl3d_transform_cloud(sl3d_ctx *ctx, const float *xyz_in, int64_t n, float th
 /* ---- device-resident access ---------------------------------------------------------------- */
 /* Frames may be produced in place (frames buffer) and points / valid consumed in place.  The mask buffer is exposed for
  * inspection only: set masks through sl3d_set_mask, which also normalises the bytes to 0/1 and evaluates the quads within
- * 3 pixels of the frame border on the host (a second plane the kernels read for those quads). */
+ * 3 pixels of the frame border (a second plane the kernels read for those quads). */
 int sl3d_get_device_buffers(sl3d_ctx *ctx, sl3d_device_buffers *out);
+/* Copy `bytes` from a device address this library handed out (sl3d_get_cloud_counts, sl3d_compact, sl3d_compact_views,
+ * sl3d_get_device_buffers) to host memory, ordered after the context's work; synchronises. */
+int sl3d_download(sl3d_ctx *ctx, void *host_dst, const void *device_src, size_t bytes);
+
+/* ---- several GPUs behind one caller: row-stripe groups -------------------------------------------------------------
+ * The reference is ONE process that scans one view after the other (m_tech_project_console.cpp:366-395); a group lets that
+ * single caller use the GPUs of a node without becoming a distributed program.  The window of `cfg` is cut into n_stripes
+ * contiguous row stripes (stripe i gets rows [row0_i, row0_i + rows_i): height/n_stripes rows each, the first
+ * height % n_stripes stripes one more); stripe i is an ordinary context on HIP device devices[i] with its own stream.
+ * Every stage is a per-pixel map whose only neighbourhood input is the selection mask, so the stripes need NO exchange
+ * while they compute (each keeps 2 halo rows of the INPUT mask).  The only exchange is the assembly of the results on the
+ * root (stripe 0's device): sl3d_group_gather = ONE RCCL group of point-to-point sends over xGMI (ncclSend / ncclRecv,
+ * a gather) that land in place in the root's dense [view][row] buffers -- rank order = row order, so the row-major scan
+ * order of 8/save_point_cloud.cpp:85 is preserved; stripes that live on the root's own GPU are device-to-device copies.
+ * Devices may repeat (several stripes on one GPU: tests, or more stripes than GPUs).  cfg->device and cfg->stream are
+ * ignored.  All group calls are asynchronous unless stated; compute runs on the stripes' streams, communication on one
+ * communication stream per GPU, handed over by events, so sl3d_group_run of the next views overlaps the gather of the
+ * previous ones. */
+typedef struct sl3d_group sl3d_group;
+
+int sl3d_group_create(const sl3d_config *cfg, const int *devices, int n_stripes, sl3d_group **out);
+void sl3d_group_destroy(sl3d_group *g);
+/* text of the last error on this group; sl3d_last_error(NULL) after a failed sl3d_group_create */
+const char *sl3d_group_last_error(const sl3d_group *g);
+int sl3d_group_size(const sl3d_group *g);
+/* stripe i: its rows inside the window, its device and its context (owned by the group; any single-context call that
+ * does not change the configuration may be used on it, e.g. sl3d_synth_view, sl3d_get_points, sl3d_get_device_buffers) */
+int sl3d_group_stripe(sl3d_group *g, int i, int *row0, int *rows, int *device, sl3d_ctx **ctx);
+/* "rccl" if stripes on other GPUs travel by RCCL send/recv, "copy" if every transfer is a (peer) device copy */
+const char *sl3d_group_transport(const sl3d_group *g);
+
+/* the single-context inputs, applied to every stripe (each uploads only its own byte range of every plane, on its own GPU;
+ * planes are WINDOW-sized: `width` x `height` of cfg) */
+int sl3d_group_set_calibration(sl3d_group *g, const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
+                               const double Kp[9], const double dp[5], const double rp[3], const double tp[3]);
+int sl3d_group_set_mask(sl3d_group *g, int view, const uint8_t *full_frame_mask, size_t stride);
+int sl3d_group_set_frames(sl3d_group *g, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride);
+
+/* sl3d_run on every stripe (one launch per GPU stream) */
+int sl3d_group_run(sl3d_group *g, int first_view, int n_views);
+/* assemble xyz + valid of views [first_view, first_view+n_views) on the root GPU: waits (on the device) for the stripes'
+ * kernels of those views, then one grouped exchange on the communication streams */
+int sl3d_group_gather(sl3d_group *g, int first_view, int n_views);
+/* the assembled dense results of a view (window-sized [height][width][3] f32, NaN where invalid; [height][width] valid);
+ * waits for the gather of that view; either pointer may be NULL */
+int sl3d_group_get_points(sl3d_group *g, int view, float *xyz, uint8_t *valid);
+/* the assembled buffers in the root GPU's memory, for consumers that stay on the device (layout of sl3d_device_buffers'
+ * points / valid with the window's height; frames / mask members are not filled) */
+int sl3d_group_get_device_buffers(sl3d_group *g, sl3d_device_buffers *out);
+
+/* the compacted variant: sl3d_run_clouds on every stripe, then the counts come back to the host and every stripe sends
+ * exactly its valid points; the root concatenates them in stripe order = the reference's scan order.
+ * counts[k] = points of view first_view+k (all stripes).  sl3d_group_get_cloud waits for the transfer. */
+int sl3d_group_run_clouds(sl3d_group *g, int first_view, int n_views);
+int sl3d_group_gather_clouds(sl3d_group *g, int first_view, int n_views, int64_t *counts);
+int sl3d_group_get_cloud(sl3d_group *g, int view, float *xyz, int64_t capacity, int64_t *count);
+
+/* waits for every stripe's stream and every communication stream */
+int sl3d_group_synchronize(sl3d_group *g);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,87 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_pipeline(rank, world, port, q):
+    """RootAssembler on CPU tensors (gloo): dense stripes of UNEQUAL heights land in place; compacted clouds are concatenated
+    in rank order; the equalising collectives (assemble_root / assemble_rotating) accept unequal stripes too."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import importlib
+    d = importlib.import_module("3dscan_amd.distributed")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, H, P = 5, 11, 16            # 11 rows on 2 ranks: 6 + 5
+        g = torch.Generator().manual_seed(7)
+        full = torch.rand((V, H, P * 3), generator=g)
+        fval = (torch.rand((V, H, P), generator=g) > 0.4).to(torch.uint8)
+        rows_by_rank = [d.shard_rows(H, world, r)[1] for r in range(world)]
+        r0, rows = d.shard_rows(H, world, rank)
+        pts, val = full[:, r0:r0 + rows].contiguous(), fval[:, r0:r0 + rows].contiguous()
+        asm = d.RootAssembler(rows_by_rank)
+        out_p = torch.zeros_like(full) if rank == 0 else None
+        out_v = torch.zeros_like(fval) if rank == 0 else None
+        for f, n in ((0, 2), (2, 3)):          # two chunks, as the benchmark's pipeline issues them
+            asm.gather_dense(range(f, f + n), pts, val, out_p, out_v)
+        if rank == 0:
+            assert torch.equal(out_p, full) and torch.equal(out_v, fval)
+        # compacted: every rank holds, per view, `count` points at the start of a fixed-stride region
+        stride = rows * P
+        clouds = torch.zeros(V * stride * 3)
+        counts = []
+        for v in range(V):
+            sel = val[v].reshape(-1) == 1
+            p3 = pts[v].reshape(-1, 3)[sel]
+            clouds[3 * v * stride:3 * v * stride + p3.numel()] = p3.reshape(-1)
+            counts.append(int(sel.sum()))
+        allc = asm.gather_counts(counts)
+        assert allc[rank] == counts and len(allc) == world
+        tot = [sum(allc[r][i] for r in range(world)) for i in range(V)]
+        offs = [3 * sum(tot[:i]) for i in range(V)]
+        out_c = torch.zeros(3 * sum(tot)) if rank == 0 else None
+        asm.gather_compact(range(V), clouds, stride, allc, out_c, offs)
+        if rank == 0:
+            ref = torch.cat([full[v].reshape(-1, 3)[fval[v].reshape(-1) == 1].reshape(-1) for v in range(V)])
+            assert torch.equal(out_c, ref)
+        root = d.assemble_root(pts)
+        if rank == 0:
+            assert torch.equal(root, full)
+        full2 = full[:world * 2]
+        mine = d.assemble_rotating(full2[:, r0:r0 + rows].contiguous(), 2)
+        assert torch.equal(mine, full2[rank * 2:(rank + 1) * 2])
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_assembly_unequal_stripes_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_spawn_ranks_environment(tmp_path):
+    """bench.py's self-launch helper: fresh children with the torch.distributed.run environment, rank 0's stdout returned,
+    a failing rank raises."""
+    d = pkg("distributed")
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys\nprint(os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], sys.argv[1])\n"
+                      "sys.exit(3 if os.environ['RANK'] == sys.argv[2] else 0)\n")
+    out = d.spawn_ranks(str(script), ["hello", "-1"], 3)
+    assert out.split() == ["0", "0", "3", "127.0.0.1", "hello"]
+    with pytest.raises(SystemExit):
+        d.spawn_ranks(str(script), ["x", "2"], 3)
+
+
 def test_assembly_gloo_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

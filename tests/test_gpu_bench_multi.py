@@ -1,0 +1,54 @@
+"""GPU test (-m gpu) of bench.py's N > 1 branch end to end on ONE GPU: `python bench.py --gpus N` spawns its own ranks, every
+rank computes its row stripe on GPU 0 (gloo backend, host-staged assembly: RCCL needs one GPU per rank), rank 0 assembles the
+dense planes and the compacted clouds through the pipelined gather, and their digests equal those of a 1-rank run over the
+same global batch of views."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*argv):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+COMMON = ["--steps", "3", "--warmup", "1", "--precondition-ms", "0", "--no-cpu-baseline", "--no-side", "--check"]
+
+
+@pytest.mark.parametrize("world,height", [(2, 1080), (3, 1000)])
+def test_bench_spawns_ranks_and_assembly_equals_single_rank(world, height):
+    views = 2
+    one = _bench("--gpus", "1", "--views", str(views * world), "--height", str(height), *COMMON)
+    many = _bench("--gpus", str(world), "--backend", "gloo", "--devices", ",".join(["0"] * world), "--views", str(views),
+                  "--height", str(height), "--chunks", "2", *COMMON)
+    assert one["n_gpus"] == 1 and many["n_gpus"] == world and many["scaling"] == "weak"
+    assert many["config"]["rows_per_gpu"] == -(-height // world)
+    wa = many["with_assembly"]
+    assert "error" not in wa, wa
+    assert wa["dense_root_gather"]["value"] > 0 and wa["compact_root_gather"]["value"] > 0
+    assert many["check"]["dense_sha256"] == one["check"]["dense_sha256"]
+    assert many["check"]["compact_sha256"] == one["check"]["compact_sha256"]
+    assert wa["compact_root_gather"]["points_per_step"] == one["to_compacted_clouds"]["valid_points_per_step_rank0"]
+
+
+def test_bench_refuses_wrong_world_and_stacked_rccl():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+    # RCCL with two ranks on one GPU is refused loudly instead of stacking them
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--steps", "1"],
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "one GPU per rank" in (p.stderr + p.stdout)

@@ -1,0 +1,319 @@
+"""GPU tests (-m gpu) of the round-2 rows: the ordered compaction inside the fused kernel (sl3d_run_clouds), the mask
+preparation on the device, row-stripe groups behind the C ABI (sl3d_group_*: the multi-GPU path of the reference's single
+process, here with several stripes on one GPU), and BASELINE configs[2] / [3] / [4] at their full sizes."""
+import numpy as np
+import pytest
+
+from conftest import assert_points_close, pkg
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _S():
+    return pkg("scanner")
+
+
+def _random_mask(rng, W, H, holes=6):
+    m = np.zeros((H, W), np.uint8)
+    m[1:H - 1, 1:W - 1] = 1
+    for _ in range(holes):
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
+        w, h = int(rng.integers(1, max(2, W // 3))), int(rng.integers(1, max(2, H // 3)))
+        m[y:y + h, x:x + w] = rng.integers(0, 2)
+    m[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 0
+    m[rng.integers(0, H, 10), rng.integers(0, W, 10)] = 7   # selected iff == 1
+    return m
+
+
+# ---- ordered compaction inside the fused kernel ------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(640, 200, 8, 8), (333, 77, 9, 9), (200, 120, 6, 5), (1021, 64, 7, 7), (64, 3, 6, 6)])
+@pytest.mark.parametrize("dist_proj", [False, True])
+def test_fused_compaction_equals_dense(shape, dist_proj):
+    """sl3d_run_clouds: the cloud of every view equals xyz[valid] of the dense pass (8/save_point_cloud.cpp:85-104 order),
+    the valid map is the same, and repeated launches reuse the look-back words correctly (launch generations)."""
+    S, syn = _S(), pkg("synth")
+    W, H, Nv, Nh = shape
+    PW, PH, fw, NV = 512, 384, 4, 5
+    rng = np.random.default_rng(W * 7 + H)
+    caps = [syn.make_capture(W, H, PW, PH, Nv, Nh, fw, fw, view=v, noise=2, plane=(2.0 * v, 0.05, 0.03 + 0.01 * v)) for v in range(NV)]
+    cal = {k: np.array(v, dtype=np.float64).copy() for k, v in caps[0]["cal"].items()}
+    if dist_proj:
+        cal["dp"] = np.array([0.04, -0.01, 0.001, -0.0005, 0.0])
+    with S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=NV) as sc:
+        sc.set_calibration(*syn.cal_tuple(cal))
+        for v, c in enumerate(caps):
+            sc.set_mask(_random_mask(rng, W, H) if v else c["mask"], view=v)
+            sc.set_frames(0, c["planes_v"], view=v)
+            sc.set_frames(1, c["planes_h"], view=v)
+        sc.run(0, NV)
+        dense = [sc.points(v) for v in range(NV)]
+        for rep in range(3):
+            first, n = (0, NV) if rep != 1 else (1, NV - 2)   # a sub-range too
+            clouds = sc.fused_clouds(first, n)
+            for k, cl in enumerate(clouds):
+                xyz, val = dense[first + k]
+                assert cl.shape[0] == int((val == 1).sum()), (rep, k)
+                assert np.array_equal(cl, xyz[val == 1]), (rep, k)
+                assert np.array_equal(sc.valid_map(view=first + k), val)
+        assert sum(len(c) for c in clouds) > 0
+        # the older three-launch compaction still agrees
+        for v in range(NV):
+            assert np.array_equal(sc.cloud(v), dense[v][0][dense[v][1] == 1])
+
+
+def test_fused_compaction_full_hd_batch():
+    """BASELINE configs[1] shape: 16 views of 1920x1080 in one launch (8100 tiles per view, 8 views per lane): every
+    cloud equals xyz[valid]; a sparse mask and an empty mask included."""
+    S, syn = _S(), pkg("synth")
+    W, H, N, fw, NV = 1920, 1080, 10, 2, 16
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    rng = np.random.default_rng(5)
+    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV) as sc:
+        sc.set_calibration(*cal)
+        for v in range(NV):
+            m = syn.default_mask(W, H)
+            if v == 3:
+                m[:] = 0
+            elif v == 5:
+                m = _random_mask(rng, W, H, holes=30)
+            elif v == 7:
+                m[:, ::2] = 0
+            sc.set_mask(m, view=v)
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=2)
+        sc.run(0, NV)
+        dense = [sc.points(v) for v in range(NV)]
+        for rep in range(2):
+            clouds = sc.fused_clouds(0, NV)
+            for v in range(NV):
+                xyz, val = dense[v]
+                assert np.array_equal(clouds[v], xyz[val == 1]), v
+        assert len(clouds[3]) == 0 and len(clouds[0]) > 1_900_000
+
+
+# ---- mask preparation on the device -------------------------------------------------------------------------------------
+def test_device_mask_preparation_windows_and_borders():
+    """sl3d_set_mask prepares the mask on the device (normalisation + border band by k_mask_prepare): valid maps of
+    windows that touch every frame border, with arbitrary mask bytes, equal the oracle's boundary removal; pinned and
+    pageable sources give the same."""
+    S, syn = _S(), pkg("synth")
+    FW, FH, PW, PH, N, fw = 150, 90, 256, 192, 6, 8
+    rng = np.random.default_rng(11)
+    cap = syn.make_capture(FW, FH, PW, PH, N, N, fw, fw, noise=1)
+    cal = syn.cal_tuple(cap["cal"])
+    for trial in range(4):
+        mask = _random_mask(rng, FW, FH, holes=10)
+        if trial == 0:
+            mask[:] = 1   # border pixels selected too
+        o = Oracle(FW, FH, PW, PH, N, N, fw, fw)
+        o.set_mask(mask)
+        o.set_calibration(*cal)
+        o.run_scan(cap["planes_v"], cap["planes_h"])
+        vo = o.valid_map(2)
+        for (x0, y0, w, h) in [(0, 0, FW, FH), (0, 0, 70, 40), (83, 51, 67, 39), (5, 0, 100, 90), (0, 7, 150, 50), (31, 29, 17, 5)]:
+            with S.Scanner(w, h, PW, PH, N, N, fw, fw, full_size=(FW, FH), origin=(x0, y0), keep_stages=True) as sc:
+                sc.set_calibration(*cal)
+                pm = sc.pinned(mask.shape, np.uint8)
+                pm[:] = mask
+                for src in (mask, pm):
+                    sc.set_mask(src)
+                    sc.set_frames(0, [p[y0:y0 + h, x0:x0 + w] for p in cap["planes_v"]])
+                    sc.set_frames(1, [p[y0:y0 + h, x0:x0 + w] for p in cap["planes_h"]])
+                    sc.run()
+                    assert np.array_equal(sc.valid_map(0), o.valid_map(0)[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
+                    assert np.array_equal(sc.valid_map(2), vo[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
+                    sc.run_stages()
+                    assert np.array_equal(sc.valid_map(2), vo[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
+
+
+# ---- row-stripe groups behind the C ABI -----------------------------------------------------------------------------------
+def _single_context_reference(W, H, PW, PH, N, fw, cal, masks, caps):
+    S = _S()
+    out = []
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=len(caps)) as sc:
+        sc.set_calibration(*cal)
+        for v, c in enumerate(caps):
+            sc.set_mask(masks[v], view=v)
+            sc.set_frames(0, c["planes_v"], view=v)
+            sc.set_frames(1, c["planes_h"], view=v)
+        sc.run(0, len(caps))
+        for v in range(len(caps)):
+            out.append(sc.points(v))
+    return out
+
+
+@pytest.mark.parametrize("n_stripes,H", [(4, 200), (4, 203), (7, 64), (1, 50)])
+@pytest.mark.parametrize("transport", ["copy", "rccl"])
+def test_group_stripes_equal_single_context(n_stripes, H, transport):
+    """sl3d_group_*: n row stripes (unequal heights included) on GPU 0, run + gather == the single-context result bit for
+    bit (valid, xyz), dense and compacted; with device copies and with the RCCL send/recv path forced (self sends)."""
+    S, syn = _S(), pkg("synth")
+    W, PW, PH, N, fw, NV = 320, 512, 384, 7, 4, 3
+    rng = np.random.default_rng(H + n_stripes)
+    caps = [syn.make_capture(W, H, PW, PH, N, N, fw, fw, view=v, noise=2, plane=(3.0 * v, 0.05, 0.02 * v)) for v in range(NV)]
+    cal = syn.cal_tuple(caps[0]["cal"])
+    masks = [caps[0]["mask"]] + [_random_mask(rng, W, H) for _ in range(NV - 1)]
+    ref = _single_context_reference(W, H, PW, PH, N, fw, cal, masks, caps)
+    flags = S.SL3D_FLAG_GROUP_FORCE_RCCL if transport == "rccl" else S.SL3D_FLAG_GROUP_NO_RCCL
+    with S.Group(W, H, PW, PH, N, N, fw, fw, devices=[0] * n_stripes, max_views=NV, flags=flags) as g:
+        assert g.transport == transport
+        st = g.stripes()
+        assert st[0][0] == 0 and sum(s[1] for s in st) == H and max(s[1] for s in st) - min(s[1] for s in st) <= 1
+        g.set_calibration(*cal)
+        for v, c in enumerate(caps):
+            g.set_mask(masks[v], view=v)
+            g.set_frames(0, c["planes_v"], view=v)
+            g.set_frames(1, c["planes_h"], view=v)
+        # pipelined the way a caller would: compute view v+1 while view v's stripes travel
+        for v in range(NV):
+            g.run(v, 1)
+            g.gather(v, 1)
+        for rep in range(2):
+            for v in range(NV):
+                xyz, val = g.points(v)
+                assert np.array_equal(val, ref[v][1]), (rep, v)
+                assert np.array_equal(xyz, ref[v][0], equal_nan=True), (rep, v)
+            g.run(0, NV)      # the whole batch in one launch per stripe, one exchange
+            g.gather(0, NV)
+        g.run_clouds(0, NV)
+        counts = g.gather_clouds(0, NV)
+        for v in range(NV):
+            cl = g.cloud(v)
+            assert counts[v] == len(cl) == int((ref[v][1] == 1).sum())
+            assert np.array_equal(cl, ref[v][0][ref[v][1] == 1]), v
+        g.synchronize()
+
+
+# ---- BASELINE configs at their full sizes ---------------------------------------------------------------------------------
+def _oracle_stripe(W, RH, PW, PH, N, fw, cal, full_mask, R0, planes_v, planes_h, exact=False):
+    o = Oracle(W, RH, PW, PH, N, N, fw, fw, row0=R0, exact_index=exact)
+    o.set_mask(full_mask[R0:R0 + RH])
+    o.set_calibration(*cal)
+    o.run_scan([p[R0:R0 + RH] for p in planes_v], [p[R0:R0 + RH] for p in planes_h])
+    return o
+
+
+def test_config2_full_12mp_frame():
+    """configs[2]: ONE 4096x3000 context.  (a) fused == per-stage kernels on valid / codes / c_p_map / points over the whole
+    frame, (b) the oracle on 64-row stripes at the top border, mid frame and the bottom border (the oracle treats a stripe
+    as its own image, so rows next to an artificial stripe edge are skipped, rows at the TRUE frame border are compared),
+    (c) 8 row stripes (375 rows: configs[3]/[4]'s decomposition) reproduce the whole frame bit for bit, as a group with
+    the gather, (d) the compacted cloud of the whole frame."""
+    S, syn = _S(), pkg("synth")
+    W, H, PW, PH, N, fw, RH = 4096, 3000, 2048, 2048, 10, 2, 64
+    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
+    mask = syn.default_mask(W, H)
+    mask[2:40, 100:900] = 0          # structure near the top border
+    mask[H - 30:H - 3, 2000:2600] = 0
+    mask[1400:1500, 1:700] = 0
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, keep_stages=True) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        sc.synth_view(0, plane=(0.0, 0.05, 0.05), view_id=0, noise=2)
+        pv, ph = sc.frames(0), sc.frames(1)
+        sc.run()
+        fused = dict(valid=sc.valid_map(2), code0=sc.code(0), code1=sc.code(1), cp=sc.c_p_map(), xyz=sc.points()[0])
+        sc.run_stages()
+        v = sc.valid_map(2) == 1
+        assert np.array_equal(fused["valid"] == 1, v) and int(v.sum()) > 11_000_000
+        assert np.array_equal(fused["code0"][v], sc.code(0)[v]) and np.array_equal(fused["code1"][v], sc.code(1)[v])
+        assert np.array_equal(fused["cp"][v], sc.c_p_map()[v])
+        assert np.array_equal(fused["xyz"][v], sc.points()[0][v])
+    for R0, I in ((0, np.s_[0:RH - 3]), (1472, np.s_[3:RH - 3]), (H - RH, np.s_[3:RH])):
+        o = _oracle_stripe(W, RH, PW, PH, N, fw, cal, mask, R0, pv, ph)
+        vo = o.valid_map(2)[I] == 1
+        sl = np.s_[R0:R0 + RH]
+        assert np.array_equal(fused["valid"][sl][I] == 1, vo), R0
+        assert np.array_equal(fused["cp"][sl][I][vo], o.c_p_map()[I][vo]), R0
+        assert_points_close(fused["xyz"][sl][I], o.intersection_points()[I], vo)
+        assert vo.sum() > 100_000
+    v = fused["valid"] == 1
+    with S.Group(W, H, PW, PH, N, N, fw, fw, devices=[0] * 8, flags=S.SL3D_FLAG_GROUP_NO_RCCL) as g:
+        assert [s[1] for s in g.stripes()] == [375] * 8
+        g.set_calibration(*cal)
+        g.set_mask(mask)
+        g.set_frames(0, pv)
+        g.set_frames(1, ph)
+        g.run(0, 1)
+        g.gather(0, 1)
+        xyz, val = g.points(0)
+        assert np.array_equal(val, fused["valid"])
+        assert np.array_equal(xyz[v], fused["xyz"][v])
+        g.run_clouds(0, 1)
+        n = g.gather_clouds(0, 1)[0]
+        assert n == int(v.sum())
+        assert np.array_equal(g.cloud(0), fused["xyz"][v])
+
+
+def test_config3_shape_8_stripes_of_135_rows():
+    """configs[3]'s per-view decomposition: 1920x1080 views as 8 stripes of 135 rows (one per GPU of the node; here 8
+    contexts on one GPU behind sl3d_group_*), 4 views: the gathered views equal the whole-frame run bit for bit and one
+    view equals the oracle."""
+    S, syn = _S(), pkg("synth")
+    W, H, N, fw, NV = 1920, 1080, 10, 2, 4
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    mask = syn.default_mask(W, H)
+    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV) as sc:
+        sc.set_calibration(*cal)
+        frames = []
+        for v in range(NV):
+            sc.set_mask(mask, view=v)
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=2)
+            frames.append((sc.frames(0, v), sc.frames(1, v)))
+        sc.run(0, NV)
+        whole = [sc.points(v) for v in range(NV)]
+    with S.Group(W, H, W, H, N, N, fw, fw, devices=[0] * 8, max_views=NV, flags=S.SL3D_FLAG_GROUP_NO_RCCL) as g:
+        assert [s[1] for s in g.stripes()] == [135] * 8
+        g.set_calibration(*cal)
+        for v in range(NV):
+            g.set_mask(mask, view=v)
+            g.set_frames(0, frames[v][0], view=v)
+            g.set_frames(1, frames[v][1], view=v)
+        for v in range(NV):      # per-view pipeline: view v+1 computes while view v is gathered
+            g.run(v, 1)
+            g.gather(v, 1)
+        for v in range(NV):
+            xyz, val = g.points(v)
+            assert np.array_equal(val, whole[v][1]), v
+            assert np.array_equal(xyz, whole[v][0], equal_nan=True), v
+    o = Oracle(W, H, W, H, N, N, fw, fw)
+    o.set_mask(mask)
+    o.set_calibration(*cal)
+    o.run_scan(*frames[2])
+    vo = o.valid_map(2) == 1
+    assert np.array_equal(whole[2][1] == 1, vo)
+    assert_points_close(whole[2][0], o.intersection_points(), vo)
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+def test_config4_stripes_at_frame_top_and_bottom(rank):
+    """configs[4]: 8192x6144, N = 12, two axes; the stripes of rank 0 (frame top) and rank 7 (frame bottom), 768 rows each.
+    Fused compaction == dense on the stripe; the oracle (exact pixel indices: the frame exceeds 2^24 pixels)
+    on 24-row sub-stripes at the true frame border and inside the stripe."""
+    S, syn = _S(), pkg("synth")
+    W, H, N, fw, rows = 8192, 6144, 12, 2, 768
+    row0 = rank * rows
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    mask = syn.default_mask(W, H)
+    mask[0:6, 4000:5000] = 1 if rank == 0 else 0     # selected pixels ON the top border row
+    mask[H - 5:H, 100:300] = 1                       # ... and on the bottom border rows
+    with S.Scanner(W, rows, W, H, N, N, fw, fw, full_size=(W, H), origin=(0, row0)) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        sc.synth_view(0, plane=(0.0, 0.05, 0.05), view_id=0, noise=2)
+        sc.run()
+        xyz, valid = sc.points()
+        pv, ph = sc.frames(0), sc.frames(1)
+        cl = sc.fused_clouds(0, 1)[0]
+        assert np.array_equal(cl, xyz[valid == 1])
+    RH = 24
+    subs = [(0, np.s_[0:RH - 3]), (400, np.s_[3:RH - 3])] if rank == 0 else [(rows - RH, np.s_[3:RH]), (400, np.s_[3:RH - 3])]
+    for r, I in subs:
+        o = Oracle(W, RH, W, H, N, N, fw, fw, row0=row0 + r, exact_index=True)
+        o.set_mask(mask[row0 + r:row0 + r + RH])
+        o.set_calibration(*cal)
+        o.run_scan([p[r:r + RH] for p in pv], [p[r:r + RH] for p in ph])
+        vo = o.valid_map(2)[I] == 1
+        assert np.array_equal(valid[r:r + RH][I] == 1, vo), (rank, r)
+        assert_points_close(xyz[r:r + RH][I], o.intersection_points()[I], vo, rel=1e-5)
+        assert vo.sum() > 50_000

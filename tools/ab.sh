@@ -11,21 +11,21 @@ if [ "$1" = build ]; then
   shift; mkdir -p ab
   while [ $# -ge 2 ]; do
     n=$1; f=$2; shift 2
-    hipcc $FLAGS $f -shared -o ab/libsl3d_$n.so 3dscan_amd/csrc/sl3d_kernels.hip 3dscan_amd/csrc/sl3d_capi.cpp -Iinclude \
+    hipcc $FLAGS $f -shared -o ab/libsl3d_$n.so 3dscan_amd/csrc/sl3d_kernels.hip 3dscan_amd/csrc/sl3d_capi.cpp 3dscan_amd/csrc/sl3d_group.cpp -Iinclude -ldl \
       -Rpass-analysis=kernel-resource-usage 2> ab/$n.res || { echo "build $n failed"; tail -5 ab/$n.res; continue; }
-    echo "$n [$f]: $(grep -A12 'k_fusedILb0ELi10ELb0ELb1ELi1' ab/$n.res | grep -E 'VGPRs:|ScratchSize|Occupancy|SGPRs:' | sed 's/.*remark: [^ ]* *//' | tr '\n' ' ')"
+    echo "$n [$f]:"; python3 tools/kres.py ab/$n.res 10 | grep -E "KEEP=0 .*RIG=1" 
   done
 elif [ "$1" = buildrev ]; then
   # tools/ab.sh buildrev NAME REV [flags] : the library as of git revision REV (baseline for the working tree)
   n=$2; rev=$3; f=${4:-}; mkdir -p ab /tmp/ab_$n/3dscan_amd/csrc /tmp/ab_$n/include
-  for x in sl3d_kernels.hip sl3d_capi.cpp sl3d_internal.h sl3d_atan_coeffs.h; do git show $rev:3dscan_amd/csrc/$x > /tmp/ab_$n/3dscan_amd/csrc/$x 2>/dev/null; done
+  for x in sl3d_kernels.hip sl3d_capi.cpp sl3d_group.cpp sl3d_ctx.h sl3d_internal.h sl3d_atan_coeffs.h; do git show $rev:3dscan_amd/csrc/$x > /tmp/ab_$n/3dscan_amd/csrc/$x 2>/dev/null || rm -f /tmp/ab_$n/3dscan_amd/csrc/$x; done
   git show $rev:include/sl3d.h > /tmp/ab_$n/include/sl3d.h
-  hipcc $FLAGS $f -shared -o ab/libsl3d_$n.so /tmp/ab_$n/3dscan_amd/csrc/sl3d_kernels.hip /tmp/ab_$n/3dscan_amd/csrc/sl3d_capi.cpp && echo "built ab/libsl3d_$n.so from $rev"
+  hipcc $FLAGS $f -shared -o ab/libsl3d_$n.so /tmp/ab_$n/3dscan_amd/csrc/*.hip /tmp/ab_$n/3dscan_amd/csrc/*.cpp -ldl && echo "built ab/libsl3d_$n.so from $rev"
 elif [ "$1" = run ]; then
   shift
   for lib in 3dscan_amd/libsl3d.so ab/libsl3d_*.so; do
     [ -f "$lib" ] || continue
-    r=$(SL3D_LIB=$PWD/$lib python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['frac'], d['ms_per_step'])")
+    r=$(SL3D_LIB=$PWD/$lib python3 bench.py --no-cpu-baseline --no-side "$@" 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); c=d.get('to_compacted_clouds',{}); print(d['value'], d['roofline']['frac'], d['ms_per_step'], '| clouds', c.get('value'), (c.get('kernel_only') or {}).get('value'))")
     echo "$(basename $lib) $r"
   done
 fi
