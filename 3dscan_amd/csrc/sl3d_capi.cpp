@@ -132,6 +132,10 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
 #ifdef SL3D_MEASURE
     P.ablate = getenv("SL3D_ABLATE") ? atoi(getenv("SL3D_ABLATE")) : 0;
 #endif
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess) P.n_cus = ncu;
+    }
     P.pitch = (c.width + 15) & ~15;
     P.planes_per_view = 2 * P.F + 2 * P.Nv + 2 * P.Nh;
     P.plane_stride = (size_t)P.pitch * P.H;
@@ -231,7 +235,16 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
     if (!x) return;
     DeviceGuard dev_guard_(x->cfg.device);
     if (x->stream) (void)hipStreamSynchronize(x->stream);
+#ifdef SL3D_MEASURE
+    if (x->d_lookback_err) {  // look-back counters of a -DSL3D_CX=64 build: calls, rounds, re-polls, clock ticks, tiles walked back
+        unsigned long long st[8] = {0};
+        if (hipMemcpy(st, x->d_lookback_err, sizeof st, hipMemcpyDeviceToHost) == hipSuccess && st[1])
+            fprintf(stderr, "[sl3d look-back] calls %llu rounds/call %.2f repolls/call %.2f us/call %.2f tiles_back/call %.1f calls_that_waited %.3f\n", st[1],
+                    (double)st[2] / st[1], (double)st[3] / st[1], (double)st[4] / st[1] / 100.0, (double)st[5] / st[1], (double)st[6] / st[1]);
+    }
+#endif
     for (void *p : x->allocs) (void)hipFree(p);
+    if (x->h_counts) (void)hipHostFree(x->h_counts);
     for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_done) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_down) (void)hipEventDestroy(e);
@@ -790,14 +803,23 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
     }
     P.n_tiles = fused_tiles(P);
     rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles);
-    if (!rc) rc = dev_alloc(x, &x->d_lookback_err, (size_t)1);
+    if (!rc) rc = dev_alloc(x, &x->d_ticket, (size_t)1);
+    if (!rc) rc = dev_alloc(x, &x->d_lookback_err, (size_t)16);  // [0] = error flag; measurement builds keep counters behind it
     if (rc) return rc;
     HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, mv * (size_t)P.n_tiles * sizeof(unsigned long long), x->stream));
-    HIPCHK(x, hipMemsetAsync(x->d_lookback_err, 0, sizeof(int), x->stream));
+    HIPCHK(x, hipMemsetAsync(x->d_lookback_err, 0, 16 * sizeof(int), x->stream));
+    HIPCHK(x, hipMemsetAsync(x->d_ticket, 0, sizeof(unsigned), x->stream));
+    x->tickets_drawn = 0;
+    P.ticket = x->d_ticket;
     P.clouds = x->d_clouds;
     P.tile_status = x->d_tile_status;
     P.cloud_totals = x->d_totals;
     P.lookback_err = x->d_lookback_err;
+#ifdef SL3D_MEASURE
+    rc = dev_alloc(x, &x->P.dbg, mv * (size_t)P.n_tiles * 4);
+    if (rc) return rc;
+    HIPCHK(x, hipMemsetAsync(x->P.dbg, 0, mv * (size_t)P.n_tiles * 4 * sizeof(unsigned long long), x->stream));
+#endif
     P.epoch = 0;
     return SL3D_OK;
 }
@@ -817,7 +839,7 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
         HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * sizeof(unsigned long long), x->stream));
         x->P.epoch = 1;
     }
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, true, x->stream));
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, true, x->stream, &x->tickets_drawn));
 }
 
 // counts (and the device address) of the clouds the last sl3d_run_clouds over these views produced; synchronises
@@ -828,13 +850,14 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->d_tile_status) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
     ON_DEVICE(x);
-    std::vector<unsigned long long> t((size_t)n_views);
-    int err = 0;
-    HIPCHK(x, hipMemcpyAsync(t.data(), x->d_totals + first_view, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipMemcpyAsync(&err, x->d_lookback_err, sizeof err, hipMemcpyDeviceToHost, x->stream));
+    // the counts and the error flag land in pinned memory (two small DMA copies, no staging)
+    if (!x->h_counts) HIPCHK(x, hipHostMalloc((void **)&x->h_counts, ((size_t)x->cfg.max_views + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+    unsigned long long *t = x->h_counts;
+    HIPCHK(x, hipMemcpyAsync(t, x->d_totals + first_view, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipMemcpyAsync(t + n_views, x->d_lookback_err, sizeof(int), hipMemcpyDeviceToHost, x->stream));
     HIPCHK(x, hipStreamSynchronize(x->stream));
-    if (err) return fail(x, SL3D_E_HIP, "fused compaction: a tile look-back timed out (tiles were not dispatched in order?)");
-    for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[(size_t)v];
+    if (*(const int *)(t + n_views)) return fail(x, SL3D_E_HIP, "fused compaction: a tile look-back timed out");
+    for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[v];
     if (device_xyz) *device_xyz = x->d_clouds + 3 * (size_t)first_view * x->P.px_view_stride;
     if (view_stride_points) *view_stride_points = x->P.px_view_stride;
     return SL3D_OK;
@@ -1131,6 +1154,18 @@ extern "C" int sl3d_generate_pattern(sl3d_ctx *x, int kind, int axis, int index,
     if (device_pitch) *device_pitch = pitch;
     return SL3D_OK;
 }
+
+#ifdef SL3D_MEASURE
+// measurement builds: the look-back clock stamps [view][tile][4] (publish, look-back start, look-back end, xcc | base << 32)
+extern "C" int sl3d_debug_buffer(sl3d_ctx *x, const void **dev, size_t *bytes, int *n_tiles)
+{
+    if (!x || !x->P.dbg) return SL3D_E_STATE;
+    *dev = x->P.dbg;
+    *bytes = (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * 4 * sizeof(unsigned long long);
+    *n_tiles = x->P.n_tiles;
+    return SL3D_OK;
+}
+#endif
 
 extern "C" int sl3d_download(sl3d_ctx *x, void *host_dst, const void *device_src, size_t bytes)
 {

@@ -46,6 +46,9 @@ struct sl3d_ctx {
     unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
     unsigned long long *d_tile_status = nullptr;  // sl3d_run_clouds: look-back words [view][tile] of the fused compaction
     int *d_lookback_err = nullptr;
+    unsigned *d_ticket = nullptr;             // work-item counter of the persistent compacting kernel
+    unsigned long long *h_counts = nullptr;   // pinned: the per-view counts (+ error flag) sl3d_get_cloud_counts reads back
+    unsigned tickets_drawn = 0;               // its value once every enqueued launch has run
     uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)
     uint8_t *d_cloud_rgb = nullptr;           // r,g,b of the compacted cloud of one view
     std::vector<char> have_texture;

@@ -80,7 +80,11 @@ struct KParams {
     unsigned long long *cloud_totals;  // [view] number of valid points
     int *lookback_err;         // set if a look-back gave up waiting (never expected; reported by sl3d_get_cloud_counts)
     unsigned epoch;            // launch generation of tile_status (words of older generations read as "not ready")
+    unsigned *ticket;          // work-item counter of the persistent COMPACT kernel (never reset: ticket_base is its value at launch)
+    unsigned ticket_base;
+    int n_cus;                 // compute units of the device (persistent grid of the COMPACT kernel)
     int n_tiles;               // 1024-pixel tiles per view = blocks of the fused kernel along x that own pixels
+    unsigned long long *dbg;   // measurement builds (-DSL3D_CX=128): [view][tile][4] clock stamps of the look-back; NULL otherwise
     // stage-boundary planes (NULL unless SL3D_FLAG_KEEP_STAGES)
     float *wrapped[2];
     float *unwrapped[2];
@@ -93,7 +97,9 @@ struct KParams {
 };
 
 // launchers (sl3d_kernels.hip); `stream` is a hipStream_t
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream);
+// tickets_drawn (compact only): host mirror of *KParams::ticket, advanced by what this launch will draw
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream,
+                 unsigned *tickets_drawn = nullptr);
 int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)
 int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream);  // raw: staged bytes in the layout of one mask plane
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);

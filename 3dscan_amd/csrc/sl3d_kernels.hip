@@ -73,6 +73,13 @@
 #undef SL3D_ABLATE
 #define SL3D_ABLATE 0
 #endif
+// measurement builds only: bits that switch parts of the in-kernel compaction off (results wrong by construction)
+//   1 no look-back (prefix 0)   2 no barrier before the stores   4 no barrier / wave totals after the pixel loop
+//   8 points leave as three 16-byte stores per lane at the tile's dense position   16 no status words published
+#if !defined(SL3D_MEASURE) || !defined(SL3D_CX)
+#undef SL3D_CX
+#define SL3D_CX 0
+#endif
 #ifdef SL3D_MEASURE
 #define SL3D_ABLATE_RT(P) ((P).ablate)
 #else
@@ -614,35 +621,106 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-// exclusive prefix of tile `tile` in one view's status row; executed by ONE whole wave (lane j looks at tile - 1 - j)
-__device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row, int tile, unsigned epoch, int *err)
+// exclusive prefix of tile `tile` in one view's status row; executed by ONE whole wave.  A round looks at the
+// SL3D_LB_LANES * SL3D_LB_WORDS nearest predecessors (word k of lane j: tile hi - k*LANES - j, so every load is one contiguous
+// run).  Measured on the 16 x 1080p batch (profiles/README.md, round 2): the nearest known prefix is ~10-20 tiles back, so a
+// small window suffices, and what a look-back costs is its polls -- agent-scope 8-byte loads that go to the memory side of the
+// L2 every time -- and above all WAITING for predecessor tiles that are still computing the view: with the look-back right
+// behind the tile's own count 57 % of the calls had to wait (3.6 us per call); deferred by one whole view (SL3D_HOLD) 19 %
+// (1.5 us, one round trip that rides behind the next view's plane loads).  Wider windows only add polls: 64 lanes -3 %,
+// 256 tiles per round -25 %.
+#ifndef SL3D_LB_WORDS
+#define SL3D_LB_WORDS 1
+#endif
+// COMPACT kernel: 1 = the pending view's points wait in registers for a whole iteration (more slack for the look-back, +12 VGPRs),
+// 0 = they stay in the LDS staging area and leave right behind the next view's plane loads
+#ifndef SL3D_HOLD
+#define SL3D_HOLD 1
+#endif
+// COMPACT kernel, where a block's work item comes from: 0 = blockIdx (relies on in-order dispatch), 1 = one ticket per block
+// (blocks come and go as in the dense kernel, but a look-back can never wait for a tile that has not started), 2 = persistent
+// blocks that keep drawing tickets
+#ifndef SL3D_PERSIST
+#define SL3D_PERSIST 1
+#endif
+#ifndef SL3D_LB_SLEEP
+#define SL3D_LB_SLEEP 8 /* x64 clocks between two polls of a window that is not ready */
+#endif
+#ifndef SL3D_LB_LANES
+#define SL3D_LB_LANES 16 /* lanes of the wave that poll (a round covers SL3D_LB_LANES * SL3D_LB_WORDS tiles) */
+#endif
+#if SL3D_CX & 64
+#define SL3D_LB_STATS_ARG , unsigned long long (&g_lb_stats)[6]
+#define SL3D_LB_STATS_PASS , lb_stats
+#else
+#define SL3D_LB_STATS_ARG
+#define SL3D_LB_STATS_PASS
+#endif
+__device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row, int tile, unsigned epoch, int *err SL3D_LB_STATS_ARG)
 {
     const int lane = (int)(threadIdx.x & 63u);
     unsigned sum = 0;
-    int hi = tile - 1;  // nearest predecessor of the current 64-tile window
+    int hi = tile - 1;  // nearest predecessor of the current window
     int spins = 0;
+#if SL3D_CX & 64
+    const unsigned long long t_begin = wall_clock64();
+    unsigned rounds = 0;
+    auto stats = [&](unsigned result) {
+        g_lb_stats[0] += 1ull;
+        g_lb_stats[1] += (unsigned long long)rounds;
+        g_lb_stats[2] += (unsigned long long)spins;
+        g_lb_stats[3] += wall_clock64() - t_begin;
+        g_lb_stats[4] += (unsigned long long)(tile - 1 - hi);
+        if (spins > 0) g_lb_stats[5] += 1ull;
+        return result;
+    };
+#else
+    auto stats = [&](unsigned result) { return result; };
+#endif
     for (;;) {
-        const int idx = hi - lane;
-        // tiles before the first one: an inclusive prefix of 0
-        unsigned long long w = status_word(epoch, SL3D_ST_PREFIX, 0u);
-        if (idx >= 0) w = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned flag = (unsigned)(w >> 32) & 3u;
-        const bool ready = (unsigned)(w >> 34) == epoch && flag != 0u;
-        const unsigned long long R = __ballot(ready), Pm = __ballot(ready && flag == (unsigned)SL3D_ST_PREFIX);
-        if (Pm != 0ull) {
-            const int p = __ffsll((long long)Pm) - 1;  // the nearest tile that knows its inclusive prefix
-            const unsigned long long need = p == 63 ? ~0ull : ((1ull << (p + 1)) - 1ull);
-            if ((R & need) == need) return sum + wave_sum(lane <= p ? (unsigned)w : 0u);
-        } else if (R == ~0ull) {  // 64 aggregates and no prefix: add them and look further back
-            sum += wave_sum((unsigned)w);
-            hi -= 64;
+#if SL3D_CX & 64
+        rounds++;
+#endif
+        unsigned long long w[SL3D_LB_WORDS];
+#pragma unroll
+        for (int k = 0; k < SL3D_LB_WORDS; k++) {
+            const int idx = hi - SL3D_LB_LANES * k - lane;  // word k of every lane: one contiguous run of tiles per load
+            // tiles before the first one: an inclusive prefix of 0; lanes beyond the polling window: an empty aggregate
+            w[k] = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
+            if (idx >= 0 && lane < SL3D_LB_LANES) w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (SL3D_CX & 32) return (unsigned)w[0];  // measurement: one round of polls, no waiting
+        // nearest first = word 0 of lanes 0..L-1, then word 1 of lanes 0..L-1, ...: walk the words until one holds a prefix
+        bool done = false, retry = false;
+        unsigned add = 0;
+#pragma unroll
+        for (int k = 0; k < SL3D_LB_WORDS; k++) {
+            if (!done && !retry) {
+                const unsigned flag = (unsigned)(w[k] >> 32) & 3u;
+                const bool ready = (unsigned)(w[k] >> 34) == epoch && flag != 0u;
+                const unsigned long long R = __ballot(ready), Pm = __ballot(ready && flag == (unsigned)SL3D_ST_PREFIX);
+                if (Pm != 0ull) {
+                    const int p = __ffsll((long long)Pm) - 1;  // the lane that holds the nearest known inclusive prefix
+                    const unsigned long long need = p == 63 ? ~0ull : ((1ull << (p + 1)) - 1ull);
+                    if ((R & need) == need) {
+                        add += lane <= p ? (unsigned)w[k] : 0u;
+                        done = true;
+                    } else retry = true;
+                } else if (R == ~0ull) add += (unsigned)w[k];  // a run of aggregates: add them, go on to the next word
+                else retry = true;
+            }
+        }
+        if (done) return stats(sum + wave_sum(add));
+        if (!retry) {  // the whole window held aggregates and no prefix: look further back
+            sum += wave_sum(add);
+            hi -= SL3D_LB_LANES * SL3D_LB_WORDS;
             continue;
         }
         if (++spins > SL3D_LOOKBACK_SPINS) {  // never expected: report instead of hanging the GPU
             if (lane == 0) atomicExch(err, 1);
             return sum;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(SL3D_LB_SLEEP);
     }
 }
 
@@ -756,8 +834,13 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
 // every view -- the valid points in row-major scan order (8/save_point_cloud.cpp:85-104) -- in the same pass: a block is a
 // 1024-pixel tile of the scan, tile prefixes come from a decoupled look-back (tile_lookback), and the points of view v
 // leave while the planes of view v+1 are in flight (their look-back overlaps that latency).  The valid map is still written.
+// the COMPACT kernel keeps a second view's points in registers (SL3D_HOLD): 3 waves per SIMD leave it 168 VGPRs (150 used,
+// no scratch); squeezed into the 128 of 4 waves per SIMD it spills 88 bytes per lane and loses 15 %
+#ifndef SL3D_OCC_COMPACT
+#define SL3D_OCC_COMPACT 3
+#endif
 template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, bool COMPACT = false>
-__global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+__global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     static_assert(!(KEEP && COMPACT), "the parity mode writes dense planes");
     static_assert(!COMPACT || (SL3D_BLOCK == 256 && !SL3D_XCD_BANDS), "the look-back chains 1024-pixel tiles in blockIdx.x order");
@@ -771,34 +854,66 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
     }
     const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
-    // gridDim.x is a multiple of 8 (launch_fused), so blockIdx.x % 8 is the XCD whatever blockIdx.y is
-    const unsigned tile = SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const long q = (long)tile * SL3D_BLOCK + threadIdx.x;
-    const int row_q = (int)(q / qpr), cq = (int)(q - (long)row_q * qpr);
-    // COMPACT: a block that owns pixels keeps all its lanes (block barriers in the view loop); lanes past the last row work
-    // on a clamped address and have no valid pixel.  Blocks past the last tile leave as a whole.
-    if (COMPACT ? (int)tile >= P.n_tiles : row_q >= P.H) return;
-    const bool alive = row_q < P.H;
-    const int row = COMPACT ? min(row_q, P.H - 1) : row_q;
-    const int gx0 = P.col0 + cq * 4, gy = P.row0 + row;
+    // A work ITEM is one 1024-pixel tile (256 lanes x 4 pixels) of the window for one group of `vpt` views.
+    //   dense kernels : one item per block, item = (blockIdx.x, blockIdx.y); gridDim.x is a multiple of 8 (launch_fused),
+    //                   so blockIdx.x % 8 is the XCD whatever blockIdx.y is
+    //   COMPACT       : the blocks are persistent and draw items from a ticket counter (item k = tile k % n_tiles of view
+    //                   group k / n_tiles): whoever holds ticket k started after tickets < k were handed out, so a look-back
+    //                   only ever waits for tiles that are running or done -- no assumption on the dispatch order -- and the
+    //                   flush pipeline (two views behind the one being computed) runs on across items, so a block waits for
+    //                   its predecessors' last counts only once, at the very end of the kernel
+    unsigned tile = 0;
+    int row_q = 0, cq = 0, row = 0, gx0 = 0, gy = 0, v_begin = 0, v_end = 0;
+    bool alive = true, interior = false;
+    unsigned lane_off = 0;  // byte offset of the quad inside any plane
     const float nanv = __builtin_nanf("");
     float *my_xyz = s_xyz + threadIdx.x * 12;
-    const unsigned lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;  // byte offset of the quad inside any plane
     const unsigned ps = (unsigned)P.plane_stride;
-
-    // T1 for the camera depends on the pixel only: once per lane, kept in LDS so the rolled pixel loop can
-    // index it (each lane reads back only what it wrote: no barrier)
     double *my_cam = s_cam + threadIdx.x * 8;
-#pragma unroll 1
-    for (int k = 0; k < 4; k++) {
-        double cu = 0.0, cv = 0.0;
-        if (cq * 4 < P.W && !(SL3D_ABLATE_RT(P) & 4)) {
-            if (RIG != 0) undistort_normalized((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);  // camera-frame solve
-            else undistort_reproject((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);
+    __shared__ unsigned s_ticket[2];
+    unsigned item = 0, n_items = 0, item_parity = 0;
+    auto take_ticket = [&]() -> unsigned { return atomicAdd(P.ticket, 1u) - P.ticket_base; };
+    if (COMPACT) {
+        n_items = (unsigned)P.n_tiles * (unsigned)((n_views + vpt - 1) / vpt);
+        if (SL3D_PERSIST == 0) {
+            item = blockIdx.x;
+        } else {
+            if (threadIdx.x == 0) s_ticket[0] = take_ticket();
+            __syncthreads();
+            item = __builtin_amdgcn_readfirstlane(s_ticket[0]);  // block-uniform: keep it in a scalar register
         }
-        my_cam[2 * k] = cu;
-        my_cam[2 * k + 1] = cv;
     }
+    // everything of an item that depends on the pixel only; false if this lane has nothing to do in a dense kernel
+    auto begin_item = [&](unsigned tile_, int group) -> bool {
+        tile = tile_;
+        v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
+        v_end = min(v_begin + vpt, first_view + n_views);
+        const long q = (long)tile * SL3D_BLOCK + threadIdx.x;
+        row_q = (int)(q / qpr);
+        cq = (int)(q - (long)row_q * qpr);
+        // COMPACT: a block keeps all its lanes (block barriers in the view loop); lanes past the last row work on a clamped
+        // address and have no valid pixel
+        if (!COMPACT && row_q >= P.H) return false;
+        alive = row_q < P.H;
+        row = COMPACT ? min(row_q, P.H - 1) : row_q;
+        gx0 = P.col0 + cq * 4;
+        gy = P.row0 + row;
+        lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;
+        interior = quad_is_interior(P, cq, row);
+        // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
+        // index it (each lane reads back only what it wrote: no barrier)
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            double cu = 0.0, cv = 0.0;
+            if (cq * 4 < P.W && !(SL3D_ABLATE_RT(P) & 4)) {
+                if (RIG != 0) undistort_normalized((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);  // camera-frame solve
+                else undistort_reproject((double)(gx0 + k), (double)gy, opaque_const(Cglobal)->cam, cu, cv);
+            }
+            my_cam[2 * k] = cu;
+            my_cam[2 * k + 1] = cv;
+        }
+        return true;
+    };
 
     PinnedRows PR;
 #pragma unroll
@@ -814,8 +929,6 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
     }
     // EXACT: both axes have exactly NMAX Gray planes (the usual case): the plane clamps and the per-plane tests fold away
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
-    const int v_begin = first_view + (int)blockIdx.y * vpt;
-    const int v_end = min(v_begin + vpt, first_view + n_views);
     // ---- building blocks of one view ------------------------------------------------------------------------------
     // planes of a view: vertical axis (fringe F, gray Nv, inverse Nv), then the horizontal axis.  Plane offsets are added
     // to the scalar view base (SALU); every load uses the same 32-bit VGPR offset.  Instruction selection works per basic
@@ -963,45 +1076,80 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
         for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
     };
 
-    const bool interior = quad_is_interior(P, cq, row);
     // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
     auto valid_bits = [&](const MaskQuad &m) -> unsigned {
         if (COMPACT && !alive) return 0u;
         return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(P, m, cq, interior);
     };
-    // ---- COMPACT: the points of the previous view of this lane's loop, still in the LDS staging area --------------------
+    // ---- COMPACT: two views of this lane's loop are in flight behind the one being computed ----------------------------------
+    //   fresh : the view computed last; its points are still in the LDS staging area (my_xyz), its tile count is published
+    //   held  : the view before it; its points sit in 12 registers while the next view is computed, so that by the time its
+    //           look-back runs (after the NEXT view's plane loads have been issued) every predecessor tile has had a whole
+    //           iteration to publish its count -- the look-back then finds its words ready instead of polling for them
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    bool pending = false;
-    int pview = 0;
-    unsigned pvout = 0, prank = 0, ptotal = 0;  // valid bytes of the lane's quad, its exclusive rank inside the tile, the tile's count
-    auto flush_pending = [&]() {
-        unsigned long long *row_st = P.tile_status + (size_t)pview * (size_t)P.n_tiles;
+#if SL3D_CX & 64
+    unsigned long long lb_stats[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    bool have_fresh = false, have_held = false;
+    int fview = 0, hview = 0;
+    unsigned ftile = 0, htile = 0;
+    unsigned fvout = 0, frank = 0, ftotal = 0;  // valid bytes of the lane's quad, its exclusive rank inside the tile, the tile's count
+    unsigned hvout = 0, hrank = 0, htotal = 0;
+    float held[12];
+    auto hold_fresh = [&]() {
+        const float4 *sx = (const float4 *)my_xyz;
+        float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+        if (SL3D_HOLD) { a = sx[0]; b = sx[1]; c = sx[2]; }
+        held[0] = a.x; held[1] = a.y; held[2] = a.z; held[3] = a.w; held[4] = b.x; held[5] = b.y; held[6] = b.z; held[7] = b.w;
+        held[8] = c.x; held[9] = c.y; held[10] = c.z; held[11] = c.w;
+        hview = fview; htile = ftile; hvout = fvout; hrank = frank; htotal = ftotal;
+        have_held = true;
+        have_fresh = false;
+    };
+    auto flush_held = [&]() {
+        unsigned long long *row_st = P.tile_status + (size_t)hview * (size_t)P.n_tiles;
         if (wave == 0) {
-            const unsigned base = tile_lookback(row_st, (int)tile, P.epoch, P.lookback_err);
+#if SL3D_CX & 128
+            if (lane == 0) P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 1] = wall_clock64();
+#endif
+            const unsigned base = (SL3D_CX & 1) ? htile * 1024u : tile_lookback(row_st, (int)htile, P.epoch, P.lookback_err SL3D_LB_STATS_PASS);
             if (lane == 0) {
+#if SL3D_CX & 128
+                P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 2] = wall_clock64();
+                P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF814 /* HW_REG_XCC_ID */) | ((unsigned long long)base << 32);
+#endif
                 s_base = base;
-                if (tile != 0u) status_publish(row_st + tile, status_word(P.epoch, SL3D_ST_PREFIX, base + ptotal));
-                if ((int)tile == P.n_tiles - 1) P.cloud_totals[pview] = (unsigned long long)(base + ptotal);
+                if (htile != 0u && !(SL3D_CX & 16)) status_publish(row_st + htile, status_word(P.epoch, SL3D_ST_PREFIX, base + htotal));
+                if ((int)htile == P.n_tiles - 1) P.cloud_totals[hview] = (unsigned long long)(base + htotal);
             }
         }
-        __syncthreads();
-        float *dst = P.clouds + 3 * ((size_t)pview * P.px_view_stride + (size_t)(s_base + prank));
+        if (!(SL3D_CX & 2)) __syncthreads();
+        float *dst = P.clouds + 3 * ((size_t)hview * P.px_view_stride + (size_t)(((SL3D_CX & 2) ? htile * 1024u : s_base) + hrank));
         typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
-#pragma unroll 1
+#pragma unroll
         for (int k = 0; k < 4; k++)
-            if ((pvout >> (8 * k)) & 1u) {
+            if ((hvout >> (8 * k)) & 1u) {
                 f32x3 pt;
-                pt.x = my_xyz[3 * k + 0]; pt.y = my_xyz[3 * k + 1]; pt.z = my_xyz[3 * k + 2];
+                if (SL3D_HOLD) { pt.x = held[3 * k + 0]; pt.y = held[3 * k + 1]; pt.z = held[3 * k + 2]; }
+                else { pt.x = my_xyz[3 * k + 0]; pt.y = my_xyz[3 * k + 1]; pt.z = my_xyz[3 * k + 2]; }
                 *(f32x3 *)dst = pt;
                 dst += 3;
             }
-        pending = false;
+        have_held = false;
     };
 
     // The mask of the NEXT view is requested before the current view's planes, so a wave never waits a full memory
     // round trip for 36 bytes before it can ask for its 11.5 KB.  (Going further -- the next view's planes in flight
     // during the pixel loop, landing in the registers the decode has freed -- was measured: 142 VGPRs, 3 waves/SIMD,
     // -6 %; squeezed into 128 with spills, -14 %.  Occupancy hides the latency better than in-wave pipelining.)
+    for (;;) {  // items of this block (dense kernels: exactly one)
+    if (COMPACT) {
+        if (item >= n_items) break;  // block-uniform
+        begin_item(item % (unsigned)P.n_tiles, (int)(item / (unsigned)P.n_tiles));
+    } else if (!begin_item(SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x, (int)blockIdx.y)) {
+        return;
+    }
+    unsigned next_ticket = 0;
     MaskQuad mq = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row, interior);
     for (int view = v_begin; view < v_end; view++) {
         if (!SL3D_MASK_PREFETCH && view > v_begin) mq = load_mask_quad(P, view, cq, row, interior);
@@ -1027,14 +1175,20 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
         if (!COMPACT && (KEEP || vbits == 0)) fill_nan();
 
         unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
-        if (COMPACT && !SL3D_FLUSH_AFTER_LOADS && pending) flush_pending();
+        if (COMPACT && !SL3D_FLUSH_AFTER_LOADS && have_held) flush_held();
         if (vbits != 0) {
             // every load of the view is issued before the first one is consumed
             issue_fringe(view, f);
             issue_gray(view, g, iv);
         }
+        // the ticket of this block's NEXT item is drawn behind the plane loads of the item's first view and handed to the
+        // other waves through LDS; they read it after the view loop (a block barrier per view lies in between)
+        if (COMPACT && SL3D_PERSIST == 2 && view == v_begin && threadIdx.x == 0) next_ticket = take_ticket();
         // COMPACT: the previous view's points leave now, behind this view's loads (its look-back overlaps their latency)
-        if (COMPACT && SL3D_FLUSH_AFTER_LOADS && pending) flush_pending();
+        if (COMPACT && !SL3D_HOLD && have_fresh) hold_fresh();  // (no registers involved: the fresh view becomes the one to flush)
+        if (COMPACT && SL3D_FLUSH_AFTER_LOADS && have_held) flush_held();
+        if (COMPACT && SL3D_HOLD && have_fresh) hold_fresh();  // the staging area is about to be overwritten
+        if (COMPACT && SL3D_PERSIST == 2 && view == v_begin && threadIdx.x == 0) s_ticket[(item_parity + 1u) & 1u] = next_ticket;
         if (vbits != 0) {
             decode(g, iv, code);
             if (KEEP) {
@@ -1075,18 +1229,36 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
         auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
         const unsigned rank_w = below(b0) + below(b1) + below(b2) + below(b3);
         if (lane == 0) s_wtot[wave] = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-        __syncthreads();
-        const unsigned t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
-        ptotal = t0 + t1 + t2 + t3;
-        prank = rank_w + (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
-        pvout = vout;
-        pview = view;
-        pending = true;
+        if (!(SL3D_CX & 4)) __syncthreads();
+        const unsigned t0 = (SL3D_CX & 4) ? 256u : s_wtot[0], t1 = (SL3D_CX & 4) ? 256u : s_wtot[1], t2 = (SL3D_CX & 4) ? 256u : s_wtot[2], t3 = (SL3D_CX & 4) ? 256u : s_wtot[3];
+        ftotal = t0 + t1 + t2 + t3;
+        frank = rank_w + (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+        fvout = vout;
+        fview = view;
+        ftile = tile;
+        have_fresh = true;
         // the tile's count becomes visible to its successors right away; the first tile of a view knows its prefix already
-        if (threadIdx.x == 0)
-            status_publish(P.tile_status + (size_t)view * (size_t)P.n_tiles + tile, status_word(P.epoch, tile == 0u ? SL3D_ST_PREFIX : SL3D_ST_AGG, ptotal));
+#if SL3D_CX & 128
+        if (threadIdx.x == 0) P.dbg[((size_t)view * P.n_tiles + tile) * 4 + 0] = wall_clock64();
+#endif
+        if (threadIdx.x == 0 && !(SL3D_CX & 16))
+            status_publish(P.tile_status + (size_t)view * (size_t)P.n_tiles + tile, status_word(P.epoch, tile == 0u ? SL3D_ST_PREFIX : SL3D_ST_AGG, ftotal));
     }
-    if (COMPACT && pending) flush_pending();
+    if (!COMPACT || SL3D_PERSIST != 2) break;
+    item_parity ^= 1u;
+    item = __builtin_amdgcn_readfirstlane(s_ticket[item_parity & 1u]);
+    }
+    if (COMPACT) {  // drain: the view before last, then the last one
+        if (have_held) flush_held();
+        if (have_fresh) {
+            hold_fresh();
+            flush_held();
+        }
+#if SL3D_CX & 64
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 6; i++) atomicAdd((unsigned long long *)(P.lookback_err + 2) + i, lb_stats[i]);
+#endif
+    }
 }
 
 // number of 1024-pixel tiles (= blocks along x that own pixels) of one view
@@ -1142,12 +1314,22 @@ static int views_per_lane(unsigned bx, int n_views)
 // rig: 0 / 1 / 2, see pixel_chain (the host knows the calibration; folded at compile time in the timed kernels).
 // compact: the timed kernel writes compacted clouds (KParams::clouds / tile_status / cloud_totals must be set) instead of
 // the dense xyz plane.  Returns the hipError_t of THIS launch.
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream)
+int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream,
+                 unsigned *tickets_drawn)
 {
+    KParams P = P_;
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
     const int vpt = views_per_lane(bx, n_views);
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(SL3D_BLOCK, 1, 1);
+    if (compact) {
+        // persistent blocks that draw (tile, view group) items from the context's ticket counter: as many as the GPU holds at
+        // once (more would only queue), each draws one ticket per item plus the one that tells it to stop
+        const unsigned n_items = (unsigned)P.n_tiles * grid.y, slots = (unsigned)(P.n_cus > 0 ? P.n_cus : 256) * SL3D_OCC_COMPACT;
+        grid = dim3(SL3D_PERSIST == 2 && slots < n_items ? slots : n_items, 1, 1);
+        P.ticket_base = *tickets_drawn;
+        *tickets_drawn += SL3D_PERSIST == 2 ? n_items + grid.x : SL3D_PERSIST == 1 ? n_items : 0u;
+    }
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's
     if (keep) {

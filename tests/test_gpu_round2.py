@@ -27,14 +27,14 @@ def _random_mask(rng, W, H, holes=6):
 
 
 # ---- ordered compaction inside the fused kernel ------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(640, 200, 8, 8), (333, 77, 9, 9), (200, 120, 6, 5), (1021, 64, 7, 7), (64, 3, 6, 6)])
+@pytest.mark.parametrize("shape", [(640, 200, 8, 8, 4), (333, 77, 9, 9, 4), (200, 120, 6, 5, 16), (1021, 64, 7, 7, 4), (64, 3, 6, 6, 8)])
 @pytest.mark.parametrize("dist_proj", [False, True])
 def test_fused_compaction_equals_dense(shape, dist_proj):
     """sl3d_run_clouds: the cloud of every view equals xyz[valid] of the dense pass (8/save_point_cloud.cpp:85-104 order),
     the valid map is the same, and repeated launches reuse the look-back words correctly (launch generations)."""
     S, syn = _S(), pkg("synth")
-    W, H, Nv, Nh = shape
-    PW, PH, fw, NV = 512, 384, 4, 5
+    W, H, Nv, Nh, fw = shape
+    PW, PH, NV = 512, 384, 5
     rng = np.random.default_rng(W * 7 + H)
     caps = [syn.make_capture(W, H, PW, PH, Nv, Nh, fw, fw, view=v, noise=2, plane=(2.0 * v, 0.05, 0.03 + 0.01 * v)) for v in range(NV)]
     cal = {k: np.array(v, dtype=np.float64).copy() for k, v in caps[0]["cal"].items()}
@@ -218,7 +218,9 @@ def test_config2_full_12mp_frame():
         assert np.array_equal(fused["valid"] == 1, v) and int(v.sum()) > 11_000_000
         assert np.array_equal(fused["code0"][v], sc.code(0)[v]) and np.array_equal(fused["code1"][v], sc.code(1)[v])
         assert np.array_equal(fused["cp"][v], sc.c_p_map()[v])
-        assert np.array_equal(fused["xyz"][v], sc.points()[0][v])
+        # (the fused kernel takes an undistorted projector's point as the correspondence itself, the stage-7 kernel runs it
+        # through K * ((x - c) / f) + c: equal to ~1e-13 px, so the f32 points agree to the last bit or two)
+        assert_points_close(fused["xyz"], sc.points()[0], v, rel=1e-6)
     for R0, I in ((0, np.s_[0:RH - 3]), (1472, np.s_[3:RH - 3]), (H - RH, np.s_[3:RH])):
         o = _oracle_stripe(W, RH, PW, PH, N, fw, cal, mask, R0, pv, ph)
         vo = o.valid_map(2)[I] == 1
@@ -228,6 +230,17 @@ def test_config2_full_12mp_frame():
         assert_points_close(fused["xyz"][sl][I], o.intersection_points()[I], vo)
         assert vo.sum() > 100_000
     v = fused["valid"] == 1
+    # the timed mode on the whole frame (camera-frame solve: equal to the parity mode's general solve to ~1e-12, not bit for bit)
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        sc.set_frames(0, pv)
+        sc.set_frames(1, ph)
+        sc.run()
+        txyz, tval = sc.points()
+        assert np.array_equal(tval, fused["valid"])
+        assert_points_close(txyz, fused["xyz"], v, rel=1e-6)
+        fused["xyz"] = txyz
     with S.Group(W, H, PW, PH, N, N, fw, fw, devices=[0] * 8, flags=S.SL3D_FLAG_GROUP_NO_RCCL) as g:
         assert [s[1] for s in g.stripes()] == [375] * 8
         g.set_calibration(*cal)

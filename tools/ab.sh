@@ -25,7 +25,7 @@ elif [ "$1" = run ]; then
   shift
   for lib in 3dscan_amd/libsl3d.so ab/libsl3d_*.so; do
     [ -f "$lib" ] || continue
-    r=$(SL3D_LIB=$PWD/$lib python3 bench.py --no-cpu-baseline --no-side "$@" 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); c=d.get('to_compacted_clouds',{}); print(d['value'], d['roofline']['frac'], d['ms_per_step'], '| clouds', c.get('value'), (c.get('kernel_only') or {}).get('value'))")
+    r=$(SL3D_LIB=$PWD/$lib python3 bench.py --no-cpu-baseline --no-side "$@" 2>>gpurun_out/ab_stderr.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); c=d.get('to_compacted_clouds',{}); print(d['value'], d['roofline']['frac'], d['ms_per_step'], '| clouds', c.get('value'), (c.get('kernel_only') or {}).get('value'))")
     echo "$(basename $lib) $r"
   done
 fi
