@@ -346,7 +346,21 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     // behind a per-calibration undistortion table, 0 = everything else, evaluated in the kernel
     x->rig = !x->C.cam.plain ? 0 : x->C.proj.identity ? 1 : 2;
     x->P.proj_disp = nullptr;
-    if (x->rig == 2) {
+    x->P.cam_tab = nullptr;
+    x->P.cam_tab_kind = 0;
+    if (!x->keep && x->C.cam.has_dist) {  // timed mode: T1 of the camera per window pixel (k_cam_table)
+        const int kind = x->C.cam.has_tan ? 2 : 1;
+        if (!x->d_cam_tab || x->cam_tab_doubles < (size_t)kind * x->P.px_view_stride) {
+            int rc = dev_alloc(x, &x->d_cam_tab, (size_t)kind * x->P.px_view_stride);
+            if (rc) return rc;
+            x->cam_tab_doubles = (size_t)kind * x->P.px_view_stride;
+        }
+        const int rc = launch_cam_table(x->P, x->d_cal, kind, x->d_cam_tab, x->stream);
+        if (rc) return fail(x, SL3D_E_HIP, std::string("k_cam_table: ") + hipGetErrorString((hipError_t)rc));
+        x->P.cam_tab = x->d_cam_tab;
+        x->P.cam_tab_kind = kind;
+    }
+    if (!x->C.proj.identity && !x->keep) {  // a distorted projector (rig 2, or rig 0 in the timed mode)
         if (!x->d_proj_disp) {
             HIPCHK(x, hipMalloc((void **)&x->d_proj_disp, (size_t)x->cfg.proj_width * x->cfg.proj_height * sizeof(float2)));
             x->allocs.push_back(x->d_proj_disp);

@@ -52,6 +52,8 @@ struct sl3d_ctx {
     uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)
     uint8_t *d_cloud_rgb = nullptr;           // r,g,b of the compacted cloud of one view
     std::vector<char> have_texture;
+    double *d_cam_tab = nullptr;              // timed mode: camera-side T1 table of the window (sl3d_set_calibration)
+    size_t cam_tab_doubles = 0;
     float2 *d_proj_disp = nullptr;            // RIG 2: projector undistortion table (allocated when a distorted projector is set)
     uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
     size_t pattern_pitch = 0;

@@ -70,6 +70,10 @@ struct KParams {
     const uint8_t *mask;       // 0/1 bytes, halo included
     const uint8_t *band;       // [view][row][pitch]: final valid bytes of the quads within 3 px of the frame border (set_mask)
     const float2 *proj_disp;   // [PH][PW] undistorted-minus-raw projector point (set_calibration; NULL unless the projector is distorted)
+    const double *cam_tab;     // T1 of the camera per window pixel (set_calibration, timed mode): kind 1 = [H][pitch] factor of the last
+                               // undistortion iteration (radial model), kind 2 = [H][pitch][2] normalised point (tangential terms)
+    int cam_tab_kind;          // 0 = no table (no distortion: nothing to iterate)
+    int use_cam_table;         // set per launch: 0, or cam_tab_kind
     // dense results
     float *points;             // [view][row][pitch][3] f32
     uint8_t *valid;            // [view][row][pitch]    merged valid map
@@ -103,6 +107,7 @@ int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view,
 int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)
 int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream);  // raw: staged bytes in the layout of one mask plane
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);
+int launch_cam_table(const KParams &P, const DevCal *d_cal, int kind, double *out, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);
 int launch_corr(const KParams &P, int view, void *stream);

@@ -63,6 +63,14 @@
 #ifndef SL3D_FLUSH_AFTER_LOADS
 #define SL3D_FLUSH_AFTER_LOADS 1
 #endif
+// timed kernels: 1 = the pixel loop is cut in two phases (correspondences of all 4 pixels, then stage 7), 0 = one chain per pixel
+#ifndef SL3D_SPLIT
+#define SL3D_SPLIT 1
+#endif
+// timed kernels: 1 = the next view's planes are requested between the two phases of the current view (needs SL3D_SPLIT)
+#ifndef SL3D_PIPE
+#define SL3D_PIPE 1
+#endif
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
@@ -428,11 +436,13 @@ __device__ __forceinline__ bool correspond(float unwrapped, int fw, int limit, l
 // Terms whose coefficient is exactly zero are skipped through wave-uniform flags; each skipped term is
 // an exact zero in the reference's arithmetic, so the value is unchanged.
 // the 5 fixed-point iterations of cvUndistortPoints on normalised coordinates
+// icd (optional): the factor of the last iteration of a purely radial model, for which the result is exactly (x0*icd, y0*icd)
 template <typename IntrT>
-__device__ __forceinline__ void undistort_normalized(double px, double py, const IntrT &I, double &xo, double &yo)
+__device__ __forceinline__ void undistort_normalized(double px, double py, const IntrT &I, double &xo, double &yo, double *icd = nullptr)
 {
     const double x0 = (px - I.cx) * I.ifx, y0 = (py - I.cy) * I.ify;
     double x = x0, y = y0;
+    if (icd) *icd = 1.0;
     if (I.has_dist) {
         if (I.has_tan) {
 #pragma unroll
@@ -451,6 +461,7 @@ __device__ __forceinline__ void undistort_normalized(double px, double py, const
                 const double icdist = recip(fma(fma(fma(I.k3, r2, I.k2), r2, I.k1), r2, 1.0));
                 x = x0 * icdist;
                 y = y0 * icdist;
+                if (icd) *icd = icdist;
             }
         }
     }
@@ -458,11 +469,10 @@ __device__ __forceinline__ void undistort_normalized(double px, double py, const
     yo = y;
 }
 
+// K * (x, y, 1) and the homogeneous divide
 template <typename IntrT>
-__device__ __forceinline__ void undistort_reproject(double px, double py, const IntrT &I, double &u, double &v)
+__device__ __forceinline__ void reproject(double x, double y, const IntrT &I, double &u, double &v)
 {
-    double x, y;
-    undistort_normalized(px, py, I, x, y);
     double uh, vh;
     if (I.plain) {  // K = [fx 0 cx; 0 fy cy; 0 0 1]
         uh = fma(I.K[0], x, I.K[2]);
@@ -478,6 +488,14 @@ __device__ __forceinline__ void undistort_reproject(double px, double py, const 
     }
     u = uh;
     v = vh;
+}
+
+template <typename IntrT>
+__device__ __forceinline__ void undistort_reproject(double px, double py, const IntrT &I, double &u, double &v)
+{
+    double x, y;
+    undistort_normalized(px, py, I, x, y);
+    reproject(x, y, I, u, v);
 }
 
 // T2 + T3: P (4x3), F (4x1), V = (P^T P)^-1 P^T F   7/triangulation.cpp:1152-1168,1181-1188,1202-1206
@@ -796,6 +814,10 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
             if (C.proj.identity) {
                 up = cxd;
                 vp = cyd;
+            } else if (!KEEP && P.proj_disp) {  // timed mode: the per-calibration table of the same values (see RIG 2)
+                const float2 d = P.proj_disp[(size_t)(int)cy * (size_t)P.PW + (size_t)(int)cx];
+                up = cxd + (double)d.x;
+                vp = cyd + (double)d.y;
             } else {
                 undistort_reproject(cxd, cyd, C.proj, up, vp);
             }
@@ -812,6 +834,56 @@ __device__ __forceinline__ PixelResult pixel_chain(const KParams &P, CalP Cp, co
         }
     }
     return R;
+}
+
+// The two halves of pixel_chain as the timed kernels use them (SL3D_SPLIT): stages 4 + 5 of one pixel -> its correspondence
+// (bit-exact chain, both axes in one basic block), and stage 7 + the cast of stage 8 from that correspondence.
+__device__ __forceinline__ bool correspond_px(const KParams &P, int gx, int gy, float wv, float wh, int code_v, int code_h, int &cx, int &cy)
+{
+    const bool in_v = gx >= 1 && gx <= P.fullW - 2;  // 4/phase_unwrap.cpp:285
+    const bool in_h = gy >= 1 && gy <= P.fullH - 2;  // 4/phase_unwrap.cpp:304
+    float uvv = unwrap_value(wv, code_v), uhv = unwrap_value(wh, code_h);
+    asm volatile("" : "+v"(uvv));
+    asm volatile("" : "+v"(uhv));
+    float uv = in_v ? uvv : 0.0f;
+    float uh = in_h ? uhv : 0.0f;
+    asm volatile("" : "+v"(uv));
+    asm volatile("" : "+v"(uh));
+    long lx, ly;
+    double dxd, dyd;
+    const bool okx = correspond(uv, P.fwv, P.PW, lx, dxd);
+    const bool oky = correspond(uh, P.fwh, P.PH, ly, dyd);
+    cx = (int)lx;
+    cy = (int)ly;
+    return okx && oky;
+}
+
+template <int RIG, typename CalP>
+__device__ __forceinline__ void triangulate_from(const KParams &P, CalP Cp, const PinnedRows &PR, double cu, double cv, int cx, int cy, float2 d, bool table,
+                                                 float &x, float &y, float &z)
+{
+    const auto &C = *Cp;
+    const double cxd = (double)cx, cyd = (double)cy;
+    double X[3];
+    bool singular = false;
+    if (RIG == 1) {
+        triangulate_camframe(C, PR, cu, cv, cxd, cyd, X, singular);
+    } else if (RIG == 2) {
+        triangulate_camframe(C, PR, cu, cv, cxd + (double)d.x, cyd + (double)d.y, X, singular);
+    } else {
+        double up = cxd, vp = cyd;
+        if (table) {
+            up = cxd + (double)d.x;
+            vp = cyd + (double)d.y;
+        } else if (!C.proj.identity) {
+            undistort_reproject(cxd, cyd, C.proj, up, vp);
+        }
+        triangulate_px(C, PR, cu, cv, up, vp, X);
+    }
+    x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
+    y = (float)X[1];
+    z = (float)X[2];
+    if (RIG != 0 && singular) x = y = z = 0.0f;  // cvInvert's zero matrix: V = 0
 }
 
 // grid.x covers the quads (4 pixels) of one window, grid.y covers groups of `vpt` views: a lane keeps
@@ -902,6 +974,41 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         interior = quad_is_interior(P, cq, row);
         // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
         // index it (each lane reads back only what it wrote: no barrier)
+        if (P.use_cam_table) {
+            // the per-calibration table (k_cam_table) holds what the loop below iterates; the doubles that come out are the same
+            const auto &I = opaque_const(Cglobal)->cam;
+            const size_t i0 = (size_t)row * P.pitch + (size_t)cq * 4;
+            const double y0 = ((double)gy - I.cy) * I.ify;
+            double t[8];
+            if (P.use_cam_table == 1) {
+                const double2 *tp = (const double2 *)(P.cam_tab + i0);
+                const double2 a = tp[0], b = tp[1];
+                t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
+            } else {
+                const double2 *tp = (const double2 *)(P.cam_tab + 2 * i0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double2 a = tp[k];
+                    t[2 * k] = a.x;
+                    t[2 * k + 1] = a.y;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                double xn, yn;
+                if (P.use_cam_table == 1) {
+                    xn = (((double)(gx0 + k)) - I.cx) * I.ifx * t[k];
+                    yn = y0 * t[k];
+                } else {
+                    xn = t[2 * k];
+                    yn = t[2 * k + 1];
+                }
+                if (RIG == 0) reproject(xn, yn, I, xn, yn);
+                my_cam[2 * k] = xn;
+                my_cam[2 * k + 1] = yn;
+            }
+            return true;
+        }
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
             double cu = 0.0, cv = 0.0;
@@ -1047,6 +1154,71 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         }
         return vout;
     };
+    // ---- the same work cut in two phases (SL3D_SPLIT): A = stages 3..5 of the lane's 4 pixels, the correspondences parked in the
+    // LDS staging area (slots 3k, 3k+1 of pixel k, which its own result overwrites later); B = stage 7.  Between the two the
+    // plane registers are dead -- that is where a table rig asks for its 4 projector-table entries at once (instead of one
+    // dependent gather inside every pixel's chain), and where the pipelined loop requests the next view's planes.
+    int *my_cp = (int *)my_xyz;
+    auto pixel_A = [&](int i, int k, unsigned vbits, const unsigned (&f)[2][4], const unsigned (&code)[2][2]) -> unsigned {
+        const int sh = 8 * i;
+        const int code_v = (int)((code[0][0] >> (16 * i)) & 0xffffu);
+        const int code_h = (int)((code[1][0] >> (16 * i)) & 0xffffu);
+        const AtanK AK = atan_consts<true>();
+        float wv = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+        float wh = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+        wv = shift_pi(wv);
+        wh = shift_pi(wh);
+        int cx, cy;
+        const bool ok = correspond_px(P, gx0 + k, gy, wv, wh, code_v, code_h, cx, cy) && ((vbits >> i) & 1u);
+        my_cp[3 * k] = ok ? cx : 0;  // a rejected pixel keeps a harmless table index
+        my_cp[3 * k + 1] = ok ? cy : 0;
+        return ok ? 1u : 0u;
+    };
+    auto phase_A = [&](unsigned vbits, unsigned (&f)[2][4], unsigned (&code)[2][2]) -> unsigned {
+        unsigned vout = 0;
+#pragma unroll 1
+        for (int j = 0; j < 2; j++) {
+            const unsigned ok0 = pixel_A(0, 2 * j, vbits, f, code), ok1 = pixel_A(1, 2 * j + 1, vbits, f, code);
+            vout = (vout >> 16) | (ok0 << 16) | (ok1 << 24);  // after two pairs: valid byte of pixel k at byte k
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) f[a][p] >>= 16;
+                code[a][0] = code[a][1];
+            }
+            vbits >>= 2;
+        }
+        return vout;
+    };
+    const bool proj_table = RIG == 2 || (RIG == 0 && !KEEP && P.proj_disp != nullptr);
+    auto gather_B = [&](float2 (&d)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = make_float2(0.f, 0.f);
+        if (proj_table) {
+            // neighbouring camera pixels see neighbouring projector pixels: the 4 gathers stay within a few cache lines per wave
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = P.proj_disp[(size_t)my_cp[3 * k + 1] * (size_t)P.PW + (size_t)my_cp[3 * k]];
+        }
+    };
+    auto phase_B = [&](unsigned vout, float2 (&d)[4]) {
+        unsigned vb = vout;
+#pragma unroll 1
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int k = 2 * j + i;
+                float x, y, z;
+                triangulate_from<RIG>(P, opaque_const(Cglobal), PR, my_cam[2 * k], my_cam[2 * k + 1], my_cp[3 * k], my_cp[3 * k + 1], d[i], proj_table, x, y, z);
+                const bool ok = ((vb >> (8 * i)) & 1u) != 0u;
+                my_xyz[3 * k + 0] = ok ? x : nanv;
+                my_xyz[3 * k + 1] = ok ? y : nanv;
+                my_xyz[3 * k + 2] = ok ? z : nanv;
+            }
+            d[0] = d[2];
+            d[1] = d[3];
+            vb >>= 16;
+        }
+    };
     // the 48 B of xyz a lane produces are staged in LDS (the rolled pixel loop indexes them) and leave as three 16-B
     // stores per lane; each lane reads back only what it wrote itself: no barrier needed
     // (Measured and rejected: reading the staging area back across lanes so that every store instruction of a wave
@@ -1151,10 +1323,29 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     }
     unsigned next_ticket = 0;
     MaskQuad mq = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row, interior);
+    // PIPE (timed kernels): the planes of view v+1 are requested in the middle of view v -- after phase A, when the plane
+    // registers of view v are dead, before stage 7 -- so a wave's own arithmetic runs under its own memory requests
+    // (the general rig's stage 7 is too register-hungry for it: 44 bytes of scratch per lane, -9 %)
+    constexpr bool PIPE = SL3D_PIPE && SL3D_SPLIT && !KEEP && RIG != 0;
+    unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
+    unsigned vb_next = 0;
+    if (PIPE) {
+        vb_next = valid_bits(mq);
+        if (v_begin + 1 < v_end) mq = load_mask_quad(P, v_begin + 1, cq, row, interior);
+        if (vb_next != 0) {
+            issue_fringe(v_begin, f);
+            issue_gray(v_begin, g, iv);
+        }
+    }
     for (int view = v_begin; view < v_end; view++) {
-        if (!SL3D_MASK_PREFETCH && view > v_begin) mq = load_mask_quad(P, view, cq, row, interior);
-        const unsigned vbits = valid_bits(mq);
-        if (SL3D_MASK_PREFETCH && view + 1 < v_end) mq = load_mask_quad(P, view + 1, cq, row, interior);
+        unsigned vbits;
+        if (PIPE) {
+            vbits = vb_next;
+        } else {
+            if (!SL3D_MASK_PREFETCH && view > v_begin) mq = load_mask_quad(P, view, cq, row, interior);
+            vbits = valid_bits(mq);
+            if (SL3D_MASK_PREFETCH && view + 1 < v_end) mq = load_mask_quad(P, view + 1, cq, row, interior);
+        }
         const size_t px = (size_t)view * P.px_view_stride + (size_t)lane_off;  // first pixel of the quad
         unsigned vout = 0;
 
@@ -1174,9 +1365,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         }
         if (!COMPACT && (KEEP || vbits == 0)) fill_nan();
 
-        unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
         if (COMPACT && !SL3D_FLUSH_AFTER_LOADS && have_held) flush_held();
-        if (vbits != 0) {
+        if (!PIPE && vbits != 0) {
             // every load of the view is issued before the first one is consumed
             issue_fringe(view, f);
             issue_gray(view, g, iv);
@@ -1214,9 +1404,24 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                         }
                     }
                 }
+            } else if (SL3D_SPLIT) {
+                vout = phase_A(vbits, f, code);
             } else {
                 vout = pixel_pairs(px, vbits, f, code);
             }
+        }
+        if (PIPE && view + 1 < v_end) {
+            vb_next = valid_bits(mq);
+            if (view + 2 < v_end) mq = load_mask_quad(P, view + 2, cq, row, interior);
+            if (vb_next != 0) {
+                issue_fringe(view + 1, f);
+                issue_gray(view + 1, g, iv);
+            }
+        }
+        if (!KEEP && SL3D_SPLIT && vbits != 0) {
+            float2 d[4];
+            gather_B(d);
+            phase_B(vout, d);
         }
         if (!COMPACT) {
             store_quad(px, vout);
@@ -1322,6 +1527,13 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
     const int vpt = views_per_lane(bx, n_views);
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(SL3D_BLOCK, 1, 1);
+    // the timed kernels read the camera-side T1 from the per-calibration table whatever the batch is: with 8 views per lane it
+    // costs nothing (1 B/px/view), with 1..4 it saves the iteration (+2..13 %), and a view's result does not depend on the
+    // batch it was launched in
+    P.use_cam_table = P.cam_tab != nullptr ? P.cam_tab_kind : 0;
+#ifdef SL3D_MEASURE
+    if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 0) P.use_cam_table = 0;
+#endif
     if (compact) {
         // persistent blocks that draw (tile, view group) items from the context's ticket counter: as many as the GPU holds at
         // once (more would only queue), each draws one ticket per item plus the one that tells it to stop
@@ -1484,6 +1696,32 @@ __global__ __launch_bounds__(256) void k_proj_table(const DevCal *__restrict__ C
     double u, v;
     undistort_reproject((double)x, (double)y, C->proj, u, v);
     out[(size_t)y * PW + x] = make_float2((float)(u - (double)x), (float)(v - (double)y));
+}
+
+// T1 for the camera as a table: what the fused kernel's per-item prologue iterates (5 fixed-point iterations per pixel), once
+// per calibration for every pixel of the window (7/triangulation.cpp:252-307 builds cam_undist_points_mat the same way, per
+// scan), in a form from which the kernel recovers the SAME doubles: a purely radial model (kind 1, the reference's camera)
+// yields (x0*icd, y0*icd) with icd the factor of the last iteration -- one double per pixel; with tangential terms (kind 2)
+// the normalised point itself, two doubles per pixel.  The re-projection of the general rig is applied in the kernel.
+__global__ __launch_bounds__(256) void k_cam_table(const KParams P, const DevCal *__restrict__ C, int kind, double *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= P.pitch) return;
+    double u, v, icd;
+    undistort_normalized((double)(P.col0 + x), (double)(P.row0 + y), C->cam, u, v, &icd);
+    const size_t i = (size_t)y * P.pitch + x;
+    if (kind == 1) out[i] = icd;
+    else {
+        out[2 * i] = u;
+        out[2 * i + 1] = v;
+    }
+}
+
+int launch_cam_table(const KParams &P, const DevCal *d_cal, int kind, double *out, void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_cam_table, dim3((P.pitch + 255) / 256, P.H), dim3(256), 0, (hipStream_t)stream, P, d_cal, kind, out);
+    return (int)hipGetLastError();
 }
 
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream)

@@ -278,7 +278,13 @@ def test_12mp_fused_equals_staged_and_row_shards():
             parts.append(s2.points())
     xyz2 = np.concatenate([p[0] for p in parts]); val2 = np.concatenate([p[1] for p in parts])
     assert np.array_equal(val2, fused[0])
-    assert np.array_equal(xyz2[val2 == 1], fused[4][val2 == 1])
+    # the timed mode (camera-frame solve, camera-side T1 from its per-calibration table) against the parity mode: the same
+    # points to the last bit or two of the f32 output; two stripes against ONE timed-mode stripe: bit for bit
+    assert_points_close(xyz2, fused[4], val2 == 1, rel=1e-6)
+    with stripe(R0, RH, cap["planes_v"], cap["planes_h"], False) as s1:
+        s1.run()
+        xyz1, val1 = s1.points()
+    assert np.array_equal(val1, val2) and np.array_equal(xyz1[val1 == 1], xyz2[val2 == 1])
     # (c) oracle on the stripe (its own small image with the stripe origin): compare away from the stripe's top/bottom rows
     o = Oracle(W, RH, PW, PH, N, N, fw, fw, row0=R0)
     o.set_mask(full_mask[R0:R0 + RH])
