@@ -18,8 +18,18 @@ namespace {
 constexpr int W = Camera_imagewidth, H = Camera_imageheight;
 const char *kReferenceRoot = "/home/pranav/Desktop/M_tech_project_console";  // 3/wrapped_phase.cpp:39, 7/triangulation.cpp:152
 
+// One scan runs on one GPU (a single context) or, with SL3D_DEVICES=0,1,..., as row stripes on several (sl3d_group_*: one
+// context per listed device, stripe order = row order).  Every stage function below walks the parts; a part's results are
+// rows [row0, row0 + rows) of the row-major planes the reference's [col][row] globals are filled from.
+struct Part {
+    sl3d_ctx *ctx;
+    int row0, rows;
+};
+
 struct Shim {
-    sl3d_ctx *ctx = nullptr;
+    sl3d_ctx *ctx = nullptr;    // the first part's context (library-wide calls, error texts)
+    sl3d_group *group = nullptr;
+    std::vector<Part> parts;
     std::string root;
     bool root_set = false;
     bool write_debug = false;
@@ -189,14 +199,33 @@ bool read_xml_matrix(const std::string &rel, int count, double *out)
     return true;
 }
 
+void drop_ctx()
+{
+    if (g.group) sl3d_group_destroy(g.group);
+    else if (g.ctx) sl3d_destroy(g.ctx);
+    g.group = nullptr;
+    g.ctx = nullptr;
+    g.parts.clear();
+}
+
+// every part in turn; stops at the first failure (reported with that part's error text)
+template <typename Fn>
+bool each_part(const char *what, Fn fn)
+{
+    for (const Part &p : g.parts) {
+        const int rc = fn(p);
+        if (rc != SL3D_OK) return fail(rc, std::string(what) + ": " + sl3d_strerror(rc) + ": " + sl3d_last_error(p.ctx));
+    }
+    return true;
+}
+
 bool ensure_ctx()
 {
     const bool same = g.ctx && g.F == number_of_patterns_fringe && g.Nv == number_of_patterns_binary_vertical &&
                       g.Nh == number_of_patterns_binary_horizontal && g.fwv == fringe_width_pixels_vertical &&
                       g.fwh == fringe_width_pixels_horizontal && g.ncv == number_of_codes_vertical && g.nch == number_of_codes_horizontal;
     if (same) return true;
-    if (g.ctx) sl3d_destroy(g.ctx);
-    g.ctx = nullptr;
+    drop_ctx();
     sl3d_config c;
     memset(&c, 0, sizeof c);
     c.width = W; c.height = H; c.proj_width = Projector_imagewidth; c.proj_height = Projector_imageheight;
@@ -210,8 +239,31 @@ bool ensure_ctx()
     c.max_views = 1;
     c.device = getenv("SL3D_DEVICE") ? atoi(getenv("SL3D_DEVICE")) : 0;
     c.flags = SL3D_FLAG_KEEP_STAGES;
+    std::vector<int> devs;
+    if (const char *e = getenv("SL3D_DEVICES")) {  // "0,1,2,3": one row stripe per listed device (a device may repeat)
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const long d = strtol(q, &end, 10);
+            if (end == q) break;
+            devs.push_back((int)d);
+            q = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (devs.size() > 1) {
+        const int rc = sl3d_group_create(&c, devs.data(), (int)devs.size(), &g.group);
+        if (rc != SL3D_OK) return fail(rc, std::string("sl3d_group_create: ") + sl3d_strerror(rc) + ": " + sl3d_group_last_error(nullptr));
+        for (int i = 0; i < sl3d_group_size(g.group); i++) {
+            Part p{nullptr, 0, 0};
+            sl3d_group_stripe(g.group, i, &p.row0, &p.rows, nullptr, &p.ctx);
+            g.parts.push_back(p);
+        }
+        g.ctx = g.parts[0].ctx;
+        return true;
+    }
+    if (devs.size() == 1) c.device = devs[0];
     const int rc = sl3d_create(&c, &g.ctx);
     if (rc != SL3D_OK) return fail(rc, std::string("sl3d_create: ") + sl3d_strerror(rc) + ": " + sl3d_last_error(nullptr));
+    g.parts.push_back(Part{g.ctx, 0, H});
     return true;
 }
 
@@ -224,6 +276,16 @@ void to_col_row(const std::vector<T> &rowmajor, U (*dst)[Camera_imageheight])
 
 const char *axis_dir(int pattern_type) { return pattern_type == 0 ? "Vertical" : "Horizontal"; }
 
+// the frames of one axis to every part: a part takes its own rows of every plane (a contiguous byte range)
+bool upload_axis(const std::vector<std::vector<uint8_t>> &img, int pattern_type)
+{
+    return each_part("sl3d_set_frames", [&](const Part &q) {
+        std::vector<const uint8_t *> planes;
+        for (auto &v : img) planes.push_back(v.data() + (size_t)q.row0 * W);
+        return sl3d_set_frames(q.ctx, 0, pattern_type, planes.data(), (int)planes.size(), W);
+    });
+}
+
 }  // namespace
 
 extern "C" void sl3d_shim_set_data_root(const char *dir)
@@ -234,11 +296,7 @@ extern "C" void sl3d_shim_set_data_root(const char *dir)
 extern "C" void sl3d_shim_write_debug_images(int enable) { g.write_debug = enable != 0; }
 extern "C" int sl3d_shim_last_status(void) { return g.status; }
 extern "C" const char *sl3d_shim_last_error(void) { return g.err.c_str(); }
-extern "C" void sl3d_shim_reset(void)
-{
-    if (g.ctx) sl3d_destroy(g.ctx);
-    g.ctx = nullptr;
-}
+extern "C" void sl3d_shim_reset(void) { drop_ctx(); }
 
 // ---- stage 1: generate_pattern() ----------------------------------------------------------------------
 // 1/pattern_generator.cpp:513-544.  The reference's allocate_memory() asks for the number of fringe patterns and the two
@@ -295,7 +353,7 @@ void compute_wrapped_phase(int pattern_type)
     for (int r = 0; r < H; r++)
         for (int c = 0; c < W; c++)
             mask[(size_t)r * W + c] = selected_region ? (selected_region[c][r] == 1) : (r > 0 && r < H - 1 && c > 0 && c < W - 1);
-    if (!ok(sl3d_set_mask(g.ctx, 0, mask.data(), W), "sl3d_set_mask")) return;
+    if (!each_part("sl3d_set_mask", [&](const Part &p) { return sl3d_set_mask(p.ctx, 0, mask.data(), W); })) return;
 
     // read_image: F fringe frames (3/wrapped_phase.cpp:29-58); the Gray/inverse planes are supplied by stage 4
     const int F = number_of_patterns_fringe;
@@ -316,20 +374,18 @@ void compute_wrapped_phase(int pattern_type)
         snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
         read_bmp_gray(data_root() + "/" + name, img[F + N + i]) || read_bmp_gray(data_root() + "/" + alt, img[F + N + i]);
     }
-    std::vector<const uint8_t *> planes;
-    for (auto &v : img) planes.push_back(v.data());
-    if (!ok(sl3d_set_frames(g.ctx, 0, pattern_type, planes.data(), (int)planes.size(), W), "sl3d_set_frames")) return;
-    if (!ok(sl3d_compute_wrapped_phase(g.ctx, 0, pattern_type), "sl3d_compute_wrapped_phase")) return;
+    if (!upload_axis(img, pattern_type)) return;
+    if (!each_part("sl3d_compute_wrapped_phase", [&](const Part &p) { return sl3d_compute_wrapped_phase(p.ctx, 0, pattern_type); })) return;
 
     std::vector<uint8_t> v((size_t)W * H);
     std::vector<float> p((size_t)W * H);
-    if (!ok(sl3d_get_valid_map(g.ctx, 0, pattern_type, v.data(), W), "sl3d_get_valid_map")) return;
-    if (!ok(sl3d_get_wrapped_phase(g.ctx, 0, pattern_type, p.data(), W), "sl3d_get_wrapped_phase")) return;
+    if (!each_part("sl3d_get_valid_map", [&](const Part &q) { return sl3d_get_valid_map(q.ctx, 0, pattern_type, v.data() + (size_t)q.row0 * W, W); })) return;
+    if (!each_part("sl3d_get_wrapped_phase", [&](const Part &q) { return sl3d_get_wrapped_phase(q.ctx, 0, pattern_type, p.data() + (size_t)q.row0 * W, W); })) return;
     to_col_row(v, vm);
     to_col_row(p, wp);
     if (g.write_debug) {  // save_wrapped_image :346
         std::vector<uint8_t> d((size_t)W * H);
-        if (ok(sl3d_get_debug_image(g.ctx, 0, 3, pattern_type, d.data(), W), "sl3d_get_debug_image"))
+        if (each_part("sl3d_get_debug_image", [&](const Part &q) { return sl3d_get_debug_image(q.ctx, 0, 3, pattern_type, d.data() + (size_t)q.row0 * W, W); }))
             write_bmp_gray(data_root() + "/Wrapped_phase_images/" + axis_dir(pattern_type) + "/Wrapped_phase_image.bmp", d.data());
     }
 }
@@ -364,22 +420,20 @@ void unwrap_phase(int pattern_type)
         snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
         if (!load_frame({name, alt}, img[F + N + i])) return;
     }
-    std::vector<const uint8_t *> planes;
-    for (auto &v : img) planes.push_back(v.data());
-    if (!ok(sl3d_set_frames(g.ctx, 0, pattern_type, planes.data(), (int)planes.size(), W), "sl3d_set_frames")) return;
-    if (!ok(sl3d_unwrap_phase(g.ctx, 0, pattern_type), "sl3d_unwrap_phase")) return;
+    if (!upload_axis(img, pattern_type)) return;
+    if (!each_part("sl3d_unwrap_phase", [&](const Part &q) { return sl3d_unwrap_phase(q.ctx, 0, pattern_type); })) return;
 
     std::vector<int32_t> cd((size_t)W * H);
     std::vector<float> u((size_t)W * H), p((size_t)W * H);
-    if (!ok(sl3d_get_code(g.ctx, 0, pattern_type, cd.data(), W), "sl3d_get_code")) return;
-    if (!ok(sl3d_get_unwrapped_phase(g.ctx, 0, pattern_type, u.data(), W), "sl3d_get_unwrapped_phase")) return;
-    if (!ok(sl3d_get_wrapped_phase(g.ctx, 0, pattern_type, p.data(), W), "sl3d_get_wrapped_phase")) return;
+    if (!each_part("sl3d_get_code", [&](const Part &q) { return sl3d_get_code(q.ctx, 0, pattern_type, cd.data() + (size_t)q.row0 * W, W); })) return;
+    if (!each_part("sl3d_get_unwrapped_phase", [&](const Part &q) { return sl3d_get_unwrapped_phase(q.ctx, 0, pattern_type, u.data() + (size_t)q.row0 * W, W); })) return;
+    if (!each_part("sl3d_get_wrapped_phase", [&](const Part &q) { return sl3d_get_wrapped_phase(q.ctx, 0, pattern_type, p.data() + (size_t)q.row0 * W, W); })) return;
     to_col_row(cd, code);
     to_col_row(u, uw);
     if (wp) to_col_row(p, wp);  // stage 4 shifts wrapped_phi in place by +Pi (:290, :308)
     if (g.write_debug) {       // save_unwrap_phase_image :321-364
         std::vector<uint8_t> d((size_t)W * H);
-        if (ok(sl3d_get_debug_image(g.ctx, 0, 4, pattern_type, d.data(), W), "sl3d_get_debug_image"))
+        if (each_part("sl3d_get_debug_image", [&](const Part &q) { return sl3d_get_debug_image(q.ctx, 0, 4, pattern_type, d.data() + (size_t)q.row0 * W, W); }))
             write_bmp_gray(data_root() + (pattern_type == 0 ? "/Unwrapped_phase_images/Gray_coded/Vertical/Unwrapped_phase_vertical.bmp"
                                                             : "/Unwrapped_phase_images/Gray_coded/Horizontal/Unwrapped_phase_horizontal.bmp"),
                            d.data());
@@ -393,12 +447,12 @@ void compute_c_p_map()
     if (!g.ctx) { fail(SL3D_E_STATE, "compute_c_p_map before the phase stages"); return; }
     if (!valid_map) valid_map = new int[Camera_imagewidth][Camera_imageheight];  // 5/compute_correspondance.cpp:635
     if (!c_p_map) c_p_map = new long int[total_camera_pixels][2];                 // :640
-    if (!ok(sl3d_compute_c_p_map(g.ctx, 0), "sl3d_compute_c_p_map")) return;
+    if (!each_part("sl3d_compute_c_p_map", [&](const Part &q) { return sl3d_compute_c_p_map(q.ctx, 0); })) return;
     std::vector<uint8_t> v((size_t)W * H);
-    if (!ok(sl3d_get_valid_map(g.ctx, 0, SL3D_VALID_MERGED, v.data(), W), "sl3d_get_valid_map")) return;
+    if (!each_part("sl3d_get_valid_map", [&](const Part &q) { return sl3d_get_valid_map(q.ctx, 0, SL3D_VALID_MERGED, v.data() + (size_t)q.row0 * W, W); })) return;
     to_col_row(v, valid_map);
     static_assert(sizeof(long int) == sizeof(int64_t), "c_p_map is long[ ][2] on LP64");
-    ok(sl3d_get_c_p_map(g.ctx, 0, (int64_t *)c_p_map), "sl3d_get_c_p_map");
+    each_part("sl3d_get_c_p_map", [&](const Part &q) { return sl3d_get_c_p_map(q.ctx, 0, (int64_t *)c_p_map + 2 * (size_t)q.row0 * W); });
 }
 
 // ---- stage 7 ----------------------------------------------------------------------------------------
@@ -416,11 +470,11 @@ void triangulate()
         !read_xml_matrix("Triangulation/Projector_extrinsic_parametrs/world_to_proj_rot_vect.xml", 3, rp) ||  // :1077
         !read_xml_matrix("Triangulation/Projector_extrinsic_parametrs/world_to_proj_trans_vect.xml", 3, tp))  // :1082
         return;
-    if (!ok(sl3d_set_calibration(g.ctx, Kc, dc, rc, tc, Kp, dp, rp, tp), "sl3d_set_calibration")) return;
+    if (!each_part("sl3d_set_calibration", [&](const Part &q) { return sl3d_set_calibration(q.ctx, Kc, dc, rc, tc, Kp, dp, rp, tp); })) return;
     if (!intersection_points) intersection_points = new double[Camera_imagewidth][Camera_imageheight][3];  // :1513
-    if (!ok(sl3d_triangulate(g.ctx, 0), "sl3d_triangulate")) return;
+    if (!each_part("sl3d_triangulate", [&](const Part &q) { return sl3d_triangulate(q.ctx, 0); })) return;
     std::vector<double> pts((size_t)W * H * 3);
-    if (!ok(sl3d_get_intersection_points(g.ctx, 0, pts.data()), "sl3d_get_intersection_points")) return;
+    if (!each_part("sl3d_get_intersection_points", [&](const Part &q) { return sl3d_get_intersection_points(q.ctx, 0, pts.data() + 3 * (size_t)q.row0 * W); })) return;
     for (int r = 0; r < H; r++)
         for (int c = 0; c < W; c++) memcpy(intersection_points[c][r], &pts[3 * ((size_t)r * W + c)], 3 * sizeof(double));
 }
@@ -441,12 +495,23 @@ void save_point_cloud(unsigned cloud_index)
         fail(SL3D_E_INVALID_ARG, "cannot read " + data_root() + "/Point_cloud/texture.bmp (8/24-bit BMP of the camera size)");
         return;
     }
-    if (!ok(sl3d_set_texture(g.ctx, 0, tex.data(), (size_t)W * 3), "sl3d_set_texture")) return;
+    if (!each_part("sl3d_set_texture", [&](const Part &q) { return sl3d_set_texture(q.ctx, 0, tex.data() + 3 * (size_t)q.row0 * W, (size_t)W * 3); })) return;
+    // the parts' clouds one after the other: stripe order = row order = the scan order of :85-104
     int64_t n = 0;
-    if (!ok(sl3d_get_cloud_rgb(g.ctx, 0, nullptr, nullptr, 0, &n), "sl3d_get_cloud_rgb")) return;
+    std::vector<int64_t> cnt(g.parts.size(), 0);
+    size_t k = 0;
+    if (!each_part("sl3d_get_cloud_rgb", [&](const Part &q) { const int rc = sl3d_get_cloud_rgb(q.ctx, 0, nullptr, nullptr, 0, &cnt[k]); n += cnt[k++]; return rc; })) return;
     std::vector<float> xyz((size_t)n * 3);
     std::vector<uint8_t> rgb((size_t)n * 3);
-    if (!ok(sl3d_get_cloud_rgb(g.ctx, 0, xyz.data(), rgb.data(), n, &n), "sl3d_get_cloud_rgb")) return;
+    int64_t off = 0;
+    k = 0;
+    if (!each_part("sl3d_get_cloud_rgb", [&](const Part &q) {
+            int64_t m = 0;
+            const int rc = sl3d_get_cloud_rgb(q.ctx, 0, xyz.data() + 3 * off, rgb.data() + 3 * off, cnt[k], &m);
+            off += cnt[k++];
+            return rc;
+        }))
+        return;
     mkdir((data_root() + "/Point_cloud").c_str(), 0777);
     const std::string base = data_root() + "/Point_cloud/point_cloud_" + std::to_string(cloud_index);
     FILE *f = fopen((base + ".pcd").c_str(), "w");

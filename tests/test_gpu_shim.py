@@ -22,7 +22,10 @@ def _xml(path, name, rows, cols, vals):
                 % (name, rows, cols, " ".join("%.17e" % v for v in vals), name))
 
 
-def test_shim_matches_oracle(tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_shim_matches_oracle(tmp_path, devices):
+    """devices = "0,0,0": SL3D_DEVICES splits the scan into three row stripes (sl3d_group_*; here all on GPU 0): every
+    reference-layout global and both cloud files must come out exactly as on one context."""
     syn = pkg("synth")
     cap = syn.make_capture(W, H, PW, PH, NV, NH, FWV, FWH, noise=2)
     rng = np.random.default_rng(5)
@@ -72,7 +75,10 @@ def test_shim_matches_oracle(tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
     out = f"{root}/out.bin"
     ncv, nch = -(-PW // FWV), -(-PH // FWH)
-    r = subprocess.run([exe, root, out, str(NV), str(NH), str(FWV), str(FWH), str(ncv), str(nch)], capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "SL3D_DEVICES"}
+    if devices:
+        env["SL3D_DEVICES"] = devices
+    r = subprocess.run([exe, root, out, str(NV), str(NH), str(FWV), str(FWH), str(ncv), str(nch)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
 
     n = W * H
