@@ -11,7 +11,9 @@ What it does
  2. PINS THE ORACLE: replays oracle stages 3 and 4 on the full frames and requires the debug
     images to equal the reference's KAT images on every pixel (358,580 valid px per axis).
  3. Runs oracle stages 5 and 7 on the full frames with the reference's 8 calibration XMLs
-    (unpinned stages: these outputs are regression goldens, not reference answers).
+    (unpinned stages: these outputs are regression goldens, not reference answers) and CORROBORATES them with an
+    independent fp64 NumPy restatement of the same stages (independent_stage_5_7: no code shared with oracle/):
+    identical 355,608 correspondences and 3-D points within 1e-12 of their norm are required on the full scan.
  4. Writes small crops (inputs + expected outputs) to tests/golden/*.npz and the calibration
     to tests/golden/calibration.json.  Only derived data is written: no reference source.
  5. PINS THE PATTERN GENERATOR (N1): the oracle's fringe / Gray / inverse-Gray / binary patterns must equal the 45
@@ -69,6 +71,77 @@ def shift(m, dx, dy):
     h, w = m.shape
     out[max(dy, 0):h + min(dy, 0), max(dx, 0):w + min(dx, 0)] = m[max(-dy, 0):h + min(-dy, 0), max(-dx, 0):w + min(-dx, 0)]
     return out
+
+
+def independent_stage_5_7(phi_v, phi_h, valid_v, valid_h, cal):
+    """An INDEPENDENT fp64 NumPy restatement of stage 5 (C1, C2) and stage 7 (T0-T3), written from the reference's source
+    (5/compute_correspondance.cpp:60-77,642-679; 7/triangulation.cpp:252-307,352-378,1061-1126,1134-1218) and the published
+    algorithms of the five OpenCV 2.4 routines it calls -- it shares NO code with oracle/ (different language, vectorised,
+    the 4x3 systems solved by LAPACK instead of the adjugate).  Nothing in the reference tree can pin these stages (the
+    artefacts that would are missing blobs), so this is corroboration, not a pin: two restatements written separately agree.
+    phi_*: unwrapped phase planes (float32, stage 4 -- pinned by the KATs); valid_*: per-axis valid maps.
+    Returns (valid [H,W] bool, c_p_map [H,W,2] int64, points [H,W,3] float64)."""
+    f64 = np.float64
+    # C1: merge_valid_maps
+    valid = (valid_v == 1) & (valid_h == 1)
+    # C2: x = lrint(fw * (phi / (2.0*Pi))), Pi = 22.0/7.0 unparenthesised -> (2.0*22.0)/7.0; round-half-even
+    two_pi = (2.0 * 22.0) / 7.0
+    with np.errstate(invalid="ignore"):
+        x = np.rint(f64(FW) * (phi_v.astype(f64) / two_pi))
+        y = np.rint(f64(FW) * (phi_h.astype(f64) / two_pi))
+    finite = np.isfinite(x) & np.isfinite(y)                       # lrint raising FE_INVALID clears the pixel
+    in_range = finite & (x >= 0) & (y >= 0) & (x <= PW - 1) & (y <= PH - 1)
+    valid = valid & in_range
+    cp = np.zeros(phi_v.shape + (2,), dtype=np.int64)
+    cp[valid, 0] = x[valid].astype(np.int64)
+    cp[valid, 1] = y[valid].astype(np.int64)
+
+    # T0: Rodrigues (cvRodrigues2, vector -> matrix) and A = K [R|t]
+    def rodrigues(r):
+        r = np.asarray(r, f64)
+        th = np.sqrt(r @ r)
+        if th < np.finfo(f64).eps:
+            return np.eye(3)
+        k = r / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
+
+    def proj_matrix(K, r, t):
+        return np.asarray(K, f64).reshape(3, 3) @ np.hstack([rodrigues(r), np.asarray(t, f64).reshape(3, 1)])
+
+    Ac, Ap = proj_matrix(cal["Kc"], cal["rc"], cal["tc"]), proj_matrix(cal["Kp"], cal["rp"], cal["tp"])
+
+    # T1: cvUndistortPoints (5 fixed-point iterations, no R / P) then K (x, y, 1) and the division by w
+    def undistort_reproject(u, v, K, d):
+        K = np.asarray(K, f64).reshape(3, 3)
+        k1, k2, p1, p2, k3 = [f64(c) for c in d]
+        x0 = (u - K[0, 2]) / K[0, 0]
+        y0 = (v - K[1, 2]) / K[1, 1]
+        xx, yy = x0.copy(), y0.copy()
+        for _ in range(5):
+            r2 = xx * xx + yy * yy
+            icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            dx = 2 * p1 * xx * yy + p2 * (r2 + 2 * xx * xx)
+            dy = p1 * (r2 + 2 * yy * yy) + 2 * p2 * xx * yy
+            xx = (x0 - dx) * icdist
+            yy = (y0 - dy) * icdist
+        h = np.stack([xx, yy, np.ones_like(xx)], -1) @ K.T
+        return h[..., 0] / h[..., 2], h[..., 1] / h[..., 2]
+
+    rows, cols = np.nonzero(valid)
+    uc, vc = undistort_reproject(cols.astype(f64), rows.astype(f64), cal["Kc"], cal["dc"])
+    up, vp = undistort_reproject(cp[rows, cols, 0].astype(f64), cp[rows, cols, 1].astype(f64), cal["Kp"], cal["dp"])
+    # T2: P (4x3), F (4)
+    P = np.stack([Ac[0, :3] - uc[:, None] * Ac[2, :3], Ac[1, :3] - vc[:, None] * Ac[2, :3],
+                  Ap[0, :3] - up[:, None] * Ap[2, :3], Ap[1, :3] - vp[:, None] * Ap[2, :3]], axis=1)
+    Fv = np.stack([Ac[2, 3] * uc - Ac[0, 3], Ac[2, 3] * vc - Ac[1, 3], Ap[2, 3] * up - Ap[0, 3], Ap[2, 3] * vp - Ap[1, 3]], axis=1)
+    # T3: V = (P^T P)^-1 P^T F, here through LAPACK's solver on the normal equations
+    PtP = np.einsum("nki,nkj->nij", P, P)
+    PtF = np.einsum("nki,nk->ni", P, Fv)
+    V = np.linalg.solve(PtP, PtF[..., None])[..., 0]
+    pts = np.zeros(phi_v.shape + (3,), dtype=f64)
+    pts[rows, cols] = V
+    return valid, cp, pts
 
 
 def main():
@@ -151,6 +224,16 @@ def main():
     cp = orc.c_p_map()
     pts = orc.intersection_points()
     print("in-range correspondences:", int(valid.sum()), "mean xyz:", pts[valid == 1].mean(axis=0))
+    # corroboration of the unpinned stages: the independent NumPy restatement on the SAME full 1600x1200 scan must give the
+    # identical correspondences and the same points before any golden is written
+    iv, icp, ipts = independent_stage_5_7(orc.unwrapped_phi(0), orc.unwrapped_phi(1), orc.valid_map(0), orc.valid_map(1), cal)
+    assert np.array_equal(iv, valid == 1), "independent restatement: valid map after stage 5 differs"
+    assert np.array_equal(icp[iv], cp[iv]), "independent restatement: correspondences differ"
+    rel = np.linalg.norm(ipts[iv] - pts[iv], axis=-1) / np.linalg.norm(pts[iv], axis=-1)
+    print(f"independent NumPy restatement of stages 5 + 7: {int(iv.sum())} identical correspondences, "
+          f"max relative point difference {rel.max():.3e} (median {np.median(rel):.1e})")
+    assert int(iv.sum()) == 355608, "SURVEY's count of in-range correspondences on the real scan"
+    assert rel.max() <= 1e-12, "independent restatement: 3-D points differ by more than 1e-12 of their norm"
     A_cam, A_proj = orc.projection_matrices()
 
     ys, xs = np.nonzero(E)
