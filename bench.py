@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--devices", default="", help="comma-separated HIP device per rank (default: LOCAL_RANK). Repeating a device "
                                                   "is refused with nccl and allowed with gloo (plumbing tests on one GPU)")
     ap.add_argument("--chunks", type=int, default=4, help="chunks of views the assembly pipeline works in")
+    ap.add_argument("--assembly-timeout", type=float, default=240.0, help="seconds the assembly legs (N>1) may take before the line is printed without them")
     ap.add_argument("--check", action="store_true", help="add SHA-256 digests of the assembled results (dense and compacted) to the line")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of one view timed on the CPU (0 = whole view)")
     return ap.parse_args()
@@ -368,7 +369,22 @@ def main():
 
     digests = {}
     if world > 1 and not args.no_assemble:
+        # The assembly legs talk RCCL point to point between all ranks; `value` above is already measured.  Should a leg ever
+        # stall (a fabric problem on the node), the line is still printed: after --assembly-timeout seconds every rank leaves,
+        # rank 0 with the line it has.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["with_assembly"] = {"error": f"assembly legs did not finish within {args.assembly_timeout} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.assembly_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         out["with_assembly"] = measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, V, rows, W, H, rank, world, px_per_step, digests)
+        watchdog.cancel()
     elif args.check:
         digests = single_rank_digests(np, sc, n_views)
     if args.check:

@@ -12,8 +12,8 @@ EXTRA="$*"
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 200 --warmup 50 --precondition-ms 0 --no-cpu-baseline $EXTRA"   # PMC passes: counters do not depend on the clocks
-BENCH_STEADY="python3 bench.py --no-cpu-baseline $EXTRA"                    # stats pass: the steady-state defaults (300 + 2000 launches)
+BENCH="python3 bench.py --steps 200 --warmup 50 --precondition-ms 0 --no-cpu-baseline --no-side $EXTRA"   # PMC passes: counters do not depend on the clocks
+BENCH_STEADY="python3 bench.py --no-cpu-baseline --no-side $EXTRA"                    # stats pass: the steady-state defaults (300 + 2000 launches)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH_STEADY > $OUT/stats_bench.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   n=$(echo $c | tr " " "_" | cut -c1-30)

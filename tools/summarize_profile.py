@@ -36,8 +36,19 @@ def counters(prefix, kernel_substr):
     return vals
 
 
-bench = counters("bench", "k_fused")
-out = {"kernel": "sl3d::k_fused", "per_dispatch_mean": bench}
+# the bench command launches two instantiations of k_fused: the dense kernel the bench line's `value` / `roofline` are about
+# (last template argument false) and the compacting one of its `to_compacted_clouds` leg (true): kept apart
+def dense_name():
+    try:
+        return json.loads(open(f"{src}/stats_bench.json").read())["roofline"]["kernel"].replace("sl3d::", "")
+    except Exception:
+        return "k_fused<false, 10, false, true, 1, false>"
+
+
+dense = dense_name()
+bench = counters("bench", dense)
+compact = counters("bench", dense[:-len("false>")] + "true>")
+out = {"kernel": "sl3d::" + dense, "per_dispatch_mean": bench, "compacting_kernel_per_dispatch_mean": compact}
 # 2. calibration of FETCH_SIZE / WRITE_SIZE on tools/membench mode 0 (one dword per lane per plane, 47 planes;
 #    three 16-B stores + one dword per lane): the same access widths as the fused kernel, with KNOWN byte counts.
 mem = counters("membench", "k_dword")
