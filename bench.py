@@ -401,17 +401,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, cap0, cal, valid, xyz)
             # what the C ABI delivers when the boundary hands over HOST buffers (never `value`):
             # (a) serial: upload of the 46 frames of one view, one launch, download of xyz + valid, pageable numpy memory
+            stack_v, stack_h = np.stack(cap0["planes_v"]), np.stack(cap0["planes_h"])   # planes back to back: one 2-D copy per axis
             ts = []
             for _ in range(5):
                 t0 = time.perf_counter()
-                sc.set_frames(0, cap0["planes_v"], view=0)
-                sc.set_frames(1, cap0["planes_h"], view=0)
+                sc.set_frames(0, list(stack_v), view=0)
+                sc.set_frames(1, list(stack_h), view=0)
                 sc.run(0, 1)
                 sc.points(0)
                 ts.append(time.perf_counter() - t0)
             t = sorted(ts)[2]
             out["host_buffers_one_view"] = {"value": round(W * rows / t / 1e6, 1), "unit": "Mpixels/s", "ms": round(t * 1e3, 2),
-                                            "note": "H2D of 46 frames + launch + D2H of xyz and valid for ONE view, pageable host memory"}
+                                            "note": "H2D of 46 frames (one 2-D copy per axis) + launch + D2H of xyz and valid for ONE view, pageable host memory"}
             # (b) pipelined: sl3d_process_views, 12 host-resident views through the view slots on three HIP streams, pinned memory
             nv = 12
             fr = sc.pinned((nv, 2 * (3 + 2 * N), rows, W), np.uint8)

@@ -76,3 +76,24 @@ def test_pattern_counts_host_function():
     for extent in (1, 2, 255, 256, 257, 720, 1024, 1280, 1920, 4096, 8192):
         for fw in (1, 2, 3, 4, 8, 32, 100):
             assert scm.pattern_counts(extent, fw) == O.pattern_counts(extent, fw), (extent, fw)
+
+
+def test_group_create_rejects_bad_arguments(scanner_mod):
+    """sl3d_group_create: argument errors come back as status codes before any device is touched; without a HIP device a
+    valid request fails with SL3D_E_NO_DEVICE (no CPU fallback for groups either)."""
+    L = scanner_mod.load_library()
+    h = ctypes.c_void_p()
+    cfg = scanner_mod.Config(64, 32, 0, 0, 0, 0, 64, 64, 3, 3, 3, 8, 8, 0, 0, 1, 0, 0, None)
+    devs = (ctypes.c_int * 2)(0, 0)
+    assert L.sl3d_group_create(None, devs, 2, ctypes.byref(h)) == -1
+    assert L.sl3d_group_create(ctypes.byref(cfg), None, 2, ctypes.byref(h)) == -1
+    assert L.sl3d_group_create(ctypes.byref(cfg), devs, 0, ctypes.byref(h)) == -1
+    many = (ctypes.c_int * 40)(*([0] * 40))
+    assert L.sl3d_group_create(ctypes.byref(cfg), many, 40, ctypes.byref(h)) == -1      # more stripes than rows
+    assert b"stripes" in L.sl3d_group_last_error(None)
+    rc = L.sl3d_group_create(ctypes.byref(cfg), devs, 2, ctypes.byref(h))
+    if rc == 0:
+        L.sl3d_group_destroy(h)
+        pytest.skip("a HIP device is present")
+    assert rc == -2 and h.value is None
+    assert L.sl3d_group_size(None) == 0 and L.sl3d_group_transport(None) == b"copy"
