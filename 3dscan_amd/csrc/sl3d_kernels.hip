@@ -59,10 +59,6 @@
 #ifndef SL3D_XCD_BANDS
 #define SL3D_XCD_BANDS 0
 #endif
-// COMPACT kernel: 1 = the previous view's look-back and stores run behind the current view's plane loads, 0 = before them
-#ifndef SL3D_FLUSH_AFTER_LOADS
-#define SL3D_FLUSH_AFTER_LOADS 1
-#endif
 // timed kernels: 1 = the pixel loop is cut in two phases (correspondences of all 4 pixels, then stage 7), 0 = one chain per pixel
 #ifndef SL3D_SPLIT
 #define SL3D_SPLIT 1
@@ -650,11 +646,6 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 #ifndef SL3D_LB_WORDS
 #define SL3D_LB_WORDS 1
 #endif
-// COMPACT kernel: 1 = the pending view's points wait in registers for a whole iteration (more slack for the look-back, +12 VGPRs),
-// 0 = they stay in the LDS staging area and leave right behind the next view's plane loads
-#ifndef SL3D_HOLD
-#define SL3D_HOLD 1
-#endif
 // COMPACT kernel, where a block's work item comes from: 0 = blockIdx (relies on in-order dispatch), 1 = one ticket per block
 // (blocks come and go as in the dense kernel, but a look-back can never wait for a tile that has not started), 2 = persistent
 // blocks that keep drawing tickets
@@ -674,8 +665,20 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 #define SL3D_LB_STATS_ARG
 #define SL3D_LB_STATS_PASS
 #endif
-__device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row, int tile, unsigned epoch, int *err SL3D_LB_STATS_ARG)
+// the lane's status word of the first look-back window of tile `tile` (SL3D_LB_WORDS == 1): requested early, consumed later
+__device__ __forceinline__ unsigned long long lookback_poll(const unsigned long long *row, int tile, unsigned epoch)
 {
+    const int lane = (int)(threadIdx.x & 63u), idx = tile - 1 - lane;
+    unsigned long long w = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
+    if (idx >= 0 && lane < SL3D_LB_LANES) w = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return w;
+}
+
+// have_first: `first` holds the words lookback_poll fetched for the first window (no load for that round)
+__device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row, int tile, unsigned epoch, int *err, bool have_first,
+                                                  unsigned long long first SL3D_LB_STATS_ARG)
+{
+    static_assert(SL3D_LB_WORDS == 1 || true, "");
     const int lane = (int)(threadIdx.x & 63u);
     unsigned sum = 0;
     int hi = tile - 1;  // nearest predecessor of the current window
@@ -705,8 +708,10 @@ __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row,
             const int idx = hi - SL3D_LB_LANES * k - lane;  // word k of every lane: one contiguous run of tiles per load
             // tiles before the first one: an inclusive prefix of 0; lanes beyond the polling window: an empty aggregate
             w[k] = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
-            if (idx >= 0 && lane < SL3D_LB_LANES) w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (SL3D_LB_WORDS == 1 && have_first) w[k] = first;
+            else if (idx >= 0 && lane < SL3D_LB_LANES) w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        have_first = false;
         if (SL3D_CX & 32) return (unsigned)w[0];  // measurement: one round of polls, no waiting
         // nearest first = word 0 of lanes 0..L-1, then word 1 of lanes 0..L-1, ...: walk the words until one holds a prefix
         bool done = false, retry = false;
@@ -1263,20 +1268,29 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     unsigned long long lb_stats[6] = {0, 0, 0, 0, 0, 0};
 #endif
     bool have_fresh = false, have_held = false;
+    bool draining = false;  // (measurement builds: -DSL3D_CX=512 skips the look-back of the block's last view)
     int fview = 0, hview = 0;
     unsigned ftile = 0, htile = 0;
     unsigned fvout = 0, frank = 0, ftotal = 0;  // valid bytes of the lane's quad, its exclusive rank inside the tile, the tile's count
     unsigned hvout = 0, hrank = 0, htotal = 0;
     float held[12];
+    unsigned long long lb_first = 0;  // wave 0: the held view's first look-back window, requested by poll_held
+    bool poll_pending = false;
     auto hold_fresh = [&]() {
         const float4 *sx = (const float4 *)my_xyz;
-        float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-        if (SL3D_HOLD) { a = sx[0]; b = sx[1]; c = sx[2]; }
+        const float4 a = sx[0], b = sx[1], c = sx[2];
         held[0] = a.x; held[1] = a.y; held[2] = a.z; held[3] = a.w; held[4] = b.x; held[5] = b.y; held[6] = b.z; held[7] = b.w;
         held[8] = c.x; held[9] = c.y; held[10] = c.z; held[11] = c.w;
         hview = fview; htile = ftile; hvout = fvout; hrank = frank; htotal = ftotal;
         have_held = true;
         have_fresh = false;
+    };
+    // the first look-back window of the held view is REQUESTED right behind a batch of plane loads and CONSUMED (flush_held)
+    // right behind the decode that waits for those planes anyway: its round trip costs nothing unless it has to be repeated
+    auto poll_held = [&]() {
+        if (wave == 0 && SL3D_LB_WORDS == 1 && !(SL3D_CX & 1))
+            lb_first = lookback_poll(P.tile_status + (size_t)hview * (size_t)P.n_tiles, (int)htile, P.epoch);
+        poll_pending = SL3D_LB_WORDS == 1;
     };
     auto flush_held = [&]() {
         unsigned long long *row_st = P.tile_status + (size_t)hview * (size_t)P.n_tiles;
@@ -1284,7 +1298,9 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
 #if SL3D_CX & 128
             if (lane == 0) P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 1] = wall_clock64();
 #endif
-            const unsigned base = (SL3D_CX & 1) ? htile * 1024u : tile_lookback(row_st, (int)htile, P.epoch, P.lookback_err SL3D_LB_STATS_PASS);
+            const unsigned base = ((SL3D_CX & 1) || ((SL3D_CX & 512) && draining))
+                                      ? htile * 1024u
+                                      : tile_lookback(row_st, (int)htile, P.epoch, P.lookback_err, poll_pending, lb_first SL3D_LB_STATS_PASS);
             if (lane == 0) {
 #if SL3D_CX & 128
                 P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 2] = wall_clock64();
@@ -1295,6 +1311,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                 if ((int)htile == P.n_tiles - 1) P.cloud_totals[hview] = (unsigned long long)(base + htotal);
             }
         }
+        poll_pending = false;
         if (!(SL3D_CX & 2)) __syncthreads();
         float *dst = P.clouds + 3 * ((size_t)hview * P.px_view_stride + (size_t)(((SL3D_CX & 2) ? htile * 1024u : s_base) + hrank));
         typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
@@ -1302,8 +1319,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         for (int k = 0; k < 4; k++)
             if ((hvout >> (8 * k)) & 1u) {
                 f32x3 pt;
-                if (SL3D_HOLD) { pt.x = held[3 * k + 0]; pt.y = held[3 * k + 1]; pt.z = held[3 * k + 2]; }
-                else { pt.x = my_xyz[3 * k + 0]; pt.y = my_xyz[3 * k + 1]; pt.z = my_xyz[3 * k + 2]; }
+                pt.x = held[3 * k + 0]; pt.y = held[3 * k + 1]; pt.z = held[3 * k + 2];
                 *(f32x3 *)dst = pt;
                 dst += 3;
             }
@@ -1365,7 +1381,6 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         }
         if (!COMPACT && (KEEP || vbits == 0)) fill_nan();
 
-        if (COMPACT && !SL3D_FLUSH_AFTER_LOADS && have_held) flush_held();
         if (!PIPE && vbits != 0) {
             // every load of the view is issued before the first one is consumed
             issue_fringe(view, f);
@@ -1375,12 +1390,16 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         // other waves through LDS; they read it after the view loop (a block barrier per view lies in between)
         if (COMPACT && SL3D_PERSIST == 2 && view == v_begin && threadIdx.x == 0) next_ticket = take_ticket();
         // COMPACT: the previous view's points leave now, behind this view's loads (its look-back overlaps their latency)
-        if (COMPACT && !SL3D_HOLD && have_fresh) hold_fresh();  // (no registers involved: the fresh view becomes the one to flush)
-        if (COMPACT && SL3D_FLUSH_AFTER_LOADS && have_held) flush_held();
-        if (COMPACT && SL3D_HOLD && have_fresh) hold_fresh();  // the staging area is about to be overwritten
+        if (COMPACT && !PIPE && have_held && !poll_pending) poll_held();  // behind this view's plane loads
         if (COMPACT && SL3D_PERSIST == 2 && view == v_begin && threadIdx.x == 0) s_ticket[(item_parity + 1u) & 1u] = next_ticket;
+        if (vbits != 0) decode(g, iv, code);  // waits for the planes of this view
+        if (COMPACT) {
+            // the view computed two steps ago leaves (its look-back window arrived with the planes), then the previous view's
+            // points move from the staging area -- about to be overwritten -- into registers
+            if (have_held) flush_held();
+            if (have_fresh) hold_fresh();
+        }
         if (vbits != 0) {
-            decode(g, iv, code);
             if (KEEP) {
 #pragma unroll 1
                 for (int k = 0; k < 4; k++) {
@@ -1418,6 +1437,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                 issue_gray(view + 1, g, iv);
             }
         }
+        if (COMPACT && PIPE && have_held && !poll_pending) poll_held();  // behind the next view's plane loads
         if (!KEEP && SL3D_SPLIT && vbits != 0) {
             float2 d[4];
             gather_B(d);
@@ -1456,6 +1476,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     if (COMPACT) {  // drain: the view before last, then the last one
         if (have_held) flush_held();
         if (have_fresh) {
+            draining = true;
             hold_fresh();
             flush_held();
         }
