@@ -353,12 +353,19 @@ static int group_exchange(sl3d_group *g, const std::vector<Xfer> &xs)
         if (g->use_rccl && (S.gpu != 0 || (g->force_rccl && x.stripe != 0))) any_rccl = true;
     }
     if (any_rccl) GNCCL(g, rccl().GroupStart());
+    int in_group = 0;
     for (const Xfer &x : xs) {
         if (x.count == 0) continue;
         const Stripe &S = g->st[(size_t)x.stripe];
         const bool by_rccl = g->use_rccl && (S.gpu != 0 || (g->force_rccl && x.stripe != 0));
         if (by_rccl) {
             GpuSide &u = g->gpus[(size_t)S.gpu];
+            if (in_group == 256) {  // a very large batch goes out as several RCCL groups (same order on both sides)
+                GNCCL(g, rccl().GroupEnd());
+                GNCCL(g, rccl().GroupStart());
+                in_group = 0;
+            }
+            in_group++;
             GNCCL(g, rccl().Send(x.src, x.count, x.type, 0, u.nccl, u.comm));
             GNCCL(g, rccl().Recv(x.dst, x.count, x.type, S.gpu, root.nccl, root.comm));
         } else if (S.gpu == 0) {

@@ -920,7 +920,7 @@ template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, bool COMPACT = fa
 __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     static_assert(!(KEEP && COMPACT), "the parity mode writes dense planes");
-    static_assert(!COMPACT || (SL3D_BLOCK == 256 && !SL3D_XCD_BANDS), "the look-back chains 1024-pixel tiles in blockIdx.x order");
+    static_assert(!COMPACT || SL3D_BLOCK != 256 || !SL3D_XCD_BANDS, "the look-back chains 1024-pixel tiles in ticket order");  // (other block sizes: A/B builds of the dense kernel only)
     __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];
     __shared__ unsigned s_wtot[4], s_base;  // COMPACT: valid pixels per wave of the current view; exclusive prefix of the tile
     __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels

@@ -71,6 +71,7 @@ def parse():
                          "projector distortion and camera tangential terms (table path); general = skewed camera matrix as well "
                          "(everything evaluated in the kernel) -- the other two are sweeps / side figures only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clouds", action="store_true", help="skip the frames -> compacted clouds leg (A/B builds of the dense kernel only)")
     ap.add_argument("--no-side", action="store_true", help="skip the side figures (1 view latency, other rigs, N=9)")
     ap.add_argument("--no-assemble", action="store_true", help="skip the assembly measurements (N>1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
@@ -343,6 +344,8 @@ def main():
     # 8/save_point_cloud.cpp:85-104 happens inside the fused kernel (sl3d_run_clouds), plus the read-back of the counts;
     # a side figure, never `value`
     try:
+        if args.no_clouds:
+            raise RuntimeError("skipped (--no-clouds)")
         for _ in range(20):
             sc.run_clouds(0, n_views)
         counts = sc.cloud_counts(0, n_views)[2]
