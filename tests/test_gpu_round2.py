@@ -184,6 +184,33 @@ def test_group_stripes_equal_single_context(n_stripes, H, transport):
         g.synchronize()
 
 
+def test_group_many_messages_rccl_path():
+    """A gather of 40 views x 7 stripes x (xyz + valid) = 560 messages through the forced RCCL path: the exchange is cut into
+    several RCCL groups of at most 256 send/recv pairs, in the same order on both sides."""
+    S, syn = _S(), pkg("synth")
+    W, H, PW, PH, N, fw, NV, NS = 64, 28, 128, 96, 6, 4, 40, 7
+    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw, noise=1)
+    cal = syn.cal_tuple(cap["cal"])
+    rng = np.random.default_rng(3)
+    masks = [_random_mask(rng, W, H, holes=3) for _ in range(NV)]
+    ref = _single_context_reference(W, H, PW, PH, N, fw, cal, masks, [cap] * NV)
+    with S.Group(W, H, PW, PH, N, N, fw, fw, devices=[0] * NS, max_views=NV, flags=S.SL3D_FLAG_GROUP_FORCE_RCCL) as g:
+        g.set_calibration(*cal)
+        for v in range(NV):
+            g.set_mask(masks[v], view=v)
+            g.set_frames(0, cap["planes_v"], view=v)
+            g.set_frames(1, cap["planes_h"], view=v)
+        g.run(0, NV)
+        g.gather(0, NV)
+        for v in range(NV):
+            xyz, val = g.points(v)
+            assert np.array_equal(val, ref[v][1]) and np.array_equal(xyz, ref[v][0], equal_nan=True), v
+        g.run_clouds(0, NV)
+        counts = g.gather_clouds(0, NV)
+        for v in range(NV):
+            assert np.array_equal(g.cloud(v), ref[v][0][ref[v][1] == 1]) and counts[v] == int((ref[v][1] == 1).sum())
+
+
 # ---- BASELINE configs at their full sizes ---------------------------------------------------------------------------------
 def _oracle_stripe(W, RH, PW, PH, N, fw, cal, full_mask, R0, planes_v, planes_h, exact=False):
     o = Oracle(W, RH, PW, PH, N, N, fw, fw, row0=R0, exact_index=exact)
