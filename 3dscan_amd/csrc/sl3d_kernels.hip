@@ -77,9 +77,11 @@
 #undef SL3D_ABLATE
 #define SL3D_ABLATE 0
 #endif
-// measurement builds only: bits that switch parts of the in-kernel compaction off (results wrong by construction)
-//   1 no look-back (prefix 0)   2 no barrier before the stores   4 no barrier / wave totals after the pixel loop
-//   8 points leave as three 16-byte stores per lane at the tile's dense position   16 no status words published
+// measurement builds only (-DSL3D_MEASURE -DSL3D_CX=bits): parts of the in-kernel compaction switched off or instrumented
+// (results wrong by construction for 1 / 2 / 4 / 512; the A/B tables of DESIGN.md 4b come from these)
+//   1 no look-back (prefix = tile * 1024)     2 no barrier before the stores     4 no barrier after the pixel loop
+//   64 look-back counters (calls, rounds, re-polls, ticks) printed at sl3d_destroy     128 clock stamps per tile (tools/lb_trace.py)
+//   512 no look-back for the LAST view of a block
 #if !defined(SL3D_MEASURE) || !defined(SL3D_CX)
 #undef SL3D_CX
 #define SL3D_CX 0
@@ -712,7 +714,6 @@ __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row,
             else if (idx >= 0 && lane < SL3D_LB_LANES) w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         have_first = false;
-        if (SL3D_CX & 32) return (unsigned)w[0];  // measurement: one round of polls, no waiting
         // nearest first = word 0 of lanes 0..L-1, then word 1 of lanes 0..L-1, ...: walk the words until one holds a prefix
         bool done = false, retry = false;
         unsigned add = 0;
@@ -1307,7 +1308,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                 P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF814 /* HW_REG_XCC_ID */) | ((unsigned long long)base << 32);
 #endif
                 s_base = base;
-                if (htile != 0u && !(SL3D_CX & 16)) status_publish(row_st + htile, status_word(P.epoch, SL3D_ST_PREFIX, base + htotal));
+                if (htile != 0u) status_publish(row_st + htile, status_word(P.epoch, SL3D_ST_PREFIX, base + htotal));
                 if ((int)htile == P.n_tiles - 1) P.cloud_totals[hview] = (unsigned long long)(base + htotal);
             }
         }
@@ -1455,7 +1456,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         const unsigned rank_w = below(b0) + below(b1) + below(b2) + below(b3);
         if (lane == 0) s_wtot[wave] = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
         if (!(SL3D_CX & 4)) __syncthreads();
-        const unsigned t0 = (SL3D_CX & 4) ? 256u : s_wtot[0], t1 = (SL3D_CX & 4) ? 256u : s_wtot[1], t2 = (SL3D_CX & 4) ? 256u : s_wtot[2], t3 = (SL3D_CX & 4) ? 256u : s_wtot[3];
+        const unsigned t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
         ftotal = t0 + t1 + t2 + t3;
         frank = rank_w + (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
         fvout = vout;
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
 #if SL3D_CX & 128
         if (threadIdx.x == 0) P.dbg[((size_t)view * P.n_tiles + tile) * 4 + 0] = wall_clock64();
 #endif
-        if (threadIdx.x == 0 && !(SL3D_CX & 16))
+        if (threadIdx.x == 0)
             status_publish(P.tile_status + (size_t)view * (size_t)P.n_tiles + tile, status_word(P.epoch, tile == 0u ? SL3D_ST_PREFIX : SL3D_ST_AGG, ftotal));
     }
     if (!COMPACT || SL3D_PERSIST != 2) break;
