@@ -79,6 +79,8 @@ def _run_both(W, H, PW, PH, Nv, Nh, fwv, fwh, cap, mask, F=3):
         v = o.valid_map(2) == 1
         assert np.array_equal(valid == 1, v)
         assert_points_close(xyz, o.intersection_points(), v)
+        # ... and the cloud compacted inside the kernel is exactly those points in scan order
+        assert np.array_equal(sc.fused_clouds(0, 1)[0], xyz[v])
     return o
 
 
