@@ -164,83 +164,34 @@ __device__ __forceinline__ MaskView mask_view(const KParams &P, int view)
 }
 
 // Valid bits of the 4 pixels (cq*4 .. cq*4+3, row) of a window; bit k = pixel k.
-// Fast path: 3 rows x 3 aligned dwords of 0/1 bytes, byte-parallel logic (all neighbours are
-// interior pixels of the frame, so B == false and interior == true).  Quads within 3 pixels of the frame
-// border read the band plane instead: their valid bytes were evaluated by sl3d_set_mask (host, generic
-// closed form).  Loading (MaskQuad) and evaluating are separate so the fused kernel can request the
-// next view's mask while it works on the current one.
+// Validity after stage 3's boundary removal is a function of the selection mask alone, so it is evaluated once per
+// sl3d_set_mask for every pixel of the window (k_mask_prepare: the generic closed form above, MaskView::valid) into the
+// `band` plane -- one 0/1 byte per pixel, 0 in the pitch padding -- and the fused kernel reads ONE dword per quad and view
+// instead of 3 rows x 12 mask bytes plus ~45 instructions of byte-parallel logic (round 1 evaluated only the quads within
+// 3 pixels of the frame border ahead of time).  The load (MaskQuad) is separate from its use so that the next view's
+// dword can be requested a view ahead.
 struct MaskQuad {
-    unsigned bP, bC, bN, cP, cC, cN, dP, dC, dN;  // rows y-1, y, y+1 at columns c-4, c, c+4
     unsigned band;
 };
 
-__device__ __forceinline__ bool quad_is_interior(const KParams &P, int cq, int row)
+__device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, int cq, int row)
 {
-    const int gx = P.col0 + cq * 4, gy = P.row0 + row;
-    return gy >= 3 && gy <= P.fullH - 4 && gx >= 4 && gx + 3 <= P.fullW - 5;
-}
-
-// the 9 mask dwords are inside the allocation for every quad of the window (2-row halo, 16-B pads), so they are
-// loaded unconditionally; the band dword only where it is used
-__device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, int cq, int row, bool interior)
-{
-    const uint8_t *mb = P.mask + (size_t)view * P.mask_view_stride + (size_t)SL3D_MASK_HALO * P.mpitch + SL3D_MASK_LPAD;
-    const uint8_t *r1 = mb + (ptrdiff_t)row * P.mpitch + cq * 4;
-    const uint8_t *r0 = r1 - P.mpitch, *r2 = r1 + P.mpitch;
     MaskQuad m;
-    // 12 contiguous bytes per row: one dwordx3 load (dword alignment is all it needs) instead of three dword loads
-    typedef unsigned u32x3 __attribute__((ext_vector_type(3), aligned(4)));
-    const u32x3 b = *(const u32x3 *)(r0 - 4), c = *(const u32x3 *)(r1 - 4), d = *(const u32x3 *)(r2 - 4);
-    m.bP = b.x; m.bC = b.y; m.bN = b.z;
-    m.cP = c.x; m.cC = c.y; m.cN = c.z;
-    m.dP = d.x; m.dC = d.y; m.dN = d.z;
-    m.band = 0;
-    if (!interior) m.band = *(const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + cq * 4);
+    m.band = *(const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + cq * 4);
     return m;
 }
 
-__device__ __forceinline__ unsigned mask_quad_bits(const KParams &P, const MaskQuad &m, int cq, bool interior)
+__device__ __forceinline__ unsigned mask_quad_bits(const MaskQuad &m)
 {
-    // Inside a selected region every one of the 36 bytes is 1 and all 4 pixels are valid: when that holds for the whole
-    // wave (the usual case away from the region's outline) the closed form below is skipped (4 v_bitop3 + a compare
-    // instead of ~45 instructions per quad).  Wave-uniform branch, same result.
-    {
-        const unsigned a = __builtin_amdgcn_bitop3_b32(m.bP, m.bC, m.bN, 0x80), b = __builtin_amdgcn_bitop3_b32(m.cP, m.cC, m.cN, 0x80),
-                       c = __builtin_amdgcn_bitop3_b32(m.dP, m.dC, m.dN, 0x80);
-        const bool all_selected = interior && __builtin_amdgcn_bitop3_b32(a, b, c, 0x80) == 0x01010101u && P.W - cq * 4 >= 4;
-        if (__all(all_selected)) return 0xfu;
-    }
-    // X(d): bytes of row X at columns c+k+d, k=0..3
-#define SHL2(Pw, Cw) __builtin_amdgcn_alignbyte(Cw, Pw, 2)
-#define SHL1(Pw, Cw) __builtin_amdgcn_alignbyte(Cw, Pw, 3)
-#define SHR1(Cw, Nw) __builtin_amdgcn_alignbyte(Nw, Cw, 1)
-#define SHR2(Cw, Nw) __builtin_amdgcn_alignbyte(Nw, Cw, 2)
-    const unsigned ONE = 0x01010101u;
-    const unsigned Bm1 = SHL1(m.bP, m.bC), B0 = m.bC, B1 = SHR1(m.bC, m.bN), B2 = SHR2(m.bC, m.bN);
-    const unsigned Cm2 = SHL2(m.cP, m.cC), Cm1 = SHL1(m.cP, m.cC), C0 = m.cC, C1 = SHR1(m.cC, m.cN), C2 = SHR2(m.cC, m.cN);
-    const unsigned Dm2 = SHL2(m.dP, m.dC), Dm1 = SHL1(m.dP, m.dC), D0 = m.dC, D1 = SHR1(m.dC, m.dN);
-    unsigned v = C0 & C1 & Dm1 & D0 & D1;                 // V(p) & !L(p)
-    v &= Bm1 | ((B0 & Cm2 & Cm1) ^ ONE);                   // OK(NW) given the line above
-    v &= B0 | ((B1 & Cm1) ^ ONE);                          // OK(N)
-    v &= B1 | ((B2 & C2) ^ ONE);                           // OK(NE)
-    v &= Cm1 | (Dm2 ^ ONE);                                // OK(W)
-#undef SHL2
-#undef SHL1
-#undef SHR1
-#undef SHR2
-    const unsigned w = interior ? v : m.band;
-    unsigned bits = (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
-    // pixels of the pitch padding are not part of the window
-    const int inside = P.W - cq * 4;  // number of window pixels in this quad (may be <= 0 or >= 4)
-    if (inside < 4) bits &= inside <= 0 ? 0u : ((1u << inside) - 1u);
-    return bits;
+    const unsigned w = m.band;
+    return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u);
 }
 
 // sl3d_set_mask on the device: `raw` holds the caller's bytes of the window + 2-pixel halo (clipped to the frame) in the
 // layout of the mask plane itself (row r of the plane = window row r - 2, byte SL3D_MASK_LPAD + c = window column c).
-// One lane per dword of the plane: normalises the bytes to 0/1 (selected iff byte == 1; outside the frame or the halo: 0) and,
-// for the quads within 3 pixels of the frame border, evaluates the generic closed form of the boundary removal
-// (MaskView::valid on the raw bytes) into the band plane the fused kernel reads there.
+// One lane per dword of the plane: normalises the bytes to 0/1 (selected iff byte == 1; outside the frame or the halo: 0; the
+// per-stage kernel k_wrap evaluates the boundary removal on this plane) and evaluates the generic closed form of the
+// boundary removal (MaskView::valid on the raw bytes) for EVERY pixel of the window into the band plane the fused kernel reads.
 __global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int view, const uint8_t *__restrict__ raw)
 {
     const int dwords_per_row = P.mpitch >> 2;
@@ -262,14 +213,11 @@ __global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int view,
     uint8_t *dst = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
     *(unsigned *)(dst + (size_t)r * P.mpitch + (size_t)x * 4) = norm;
     if (wr >= 0 && wr < P.H && c0 >= 0 && c0 < P.pitch) {
-        const int cq = c0 >> 2;
-        if (!quad_is_interior(P, cq, wr)) {
-            unsigned band = 0;
+        unsigned band = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (c0 + k < P.W && m.valid(P.col0 + c0 + k, gy)) band |= 1u << (8 * k);
-            *(unsigned *)((uint8_t *)P.band + (size_t)view * P.px_view_stride + (size_t)wr * P.pitch + (size_t)c0) = band;
-        }
+        for (int k = 0; k < 4; k++)
+            if (c0 + k < P.W && m.valid(P.col0 + c0 + k, gy)) band |= 1u << (8 * k);
+        *(unsigned *)((uint8_t *)P.band + (size_t)view * P.px_view_stride + (size_t)wr * P.pitch + (size_t)c0) = band;
     }
 }
 
@@ -942,7 +890,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     //                   its predecessors' last counts only once, at the very end of the kernel
     unsigned tile = 0;
     int row_q = 0, cq = 0, row = 0, gx0 = 0, gy = 0, v_begin = 0, v_end = 0;
-    bool alive = true, interior = false;
+    bool alive = true;
     unsigned lane_off = 0;  // byte offset of the quad inside any plane
     const float nanv = __builtin_nanf("");
     float *my_xyz = s_xyz + threadIdx.x * 12;
@@ -977,7 +925,6 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         gx0 = P.col0 + cq * 4;
         gy = P.row0 + row;
         lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;
-        interior = quad_is_interior(P, cq, row);
         // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
         // index it (each lane reads back only what it wrote: no barrier)
         if (P.use_cam_table) {
@@ -1257,7 +1204,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
     auto valid_bits = [&](const MaskQuad &m) -> unsigned {
         if (COMPACT && !alive) return 0u;
-        return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(P, m, cq, interior);
+        return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(m);
     };
     // ---- COMPACT: two views of this lane's loop are in flight behind the one being computed ----------------------------------
     //   fresh : the view computed last; its points are still in the LDS staging area (my_xyz), its tile count is published
@@ -1339,7 +1286,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         return;
     }
     unsigned next_ticket = 0;
-    MaskQuad mq = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row, interior);
+    MaskQuad mq = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row);
     // PIPE (timed kernels): the planes of view v+1 are requested in the middle of view v -- after phase A, when the plane
     // registers of view v are dead, before stage 7 -- so a wave's own arithmetic runs under its own memory requests
     // (the general rig's stage 7 is too register-hungry for it: 44 bytes of scratch per lane, -9 %)
@@ -1348,7 +1295,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     unsigned vb_next = 0;
     if (PIPE) {
         vb_next = valid_bits(mq);
-        if (v_begin + 1 < v_end) mq = load_mask_quad(P, v_begin + 1, cq, row, interior);
+        if (v_begin + 1 < v_end) mq = load_mask_quad(P, v_begin + 1, cq, row);
         if (vb_next != 0) {
             issue_fringe(v_begin, f);
             issue_gray(v_begin, g, iv);
@@ -1359,9 +1306,9 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         if (PIPE) {
             vbits = vb_next;
         } else {
-            if (!SL3D_MASK_PREFETCH && view > v_begin) mq = load_mask_quad(P, view, cq, row, interior);
+            if (!SL3D_MASK_PREFETCH && view > v_begin) mq = load_mask_quad(P, view, cq, row);
             vbits = valid_bits(mq);
-            if (SL3D_MASK_PREFETCH && view + 1 < v_end) mq = load_mask_quad(P, view + 1, cq, row, interior);
+            if (SL3D_MASK_PREFETCH && view + 1 < v_end) mq = load_mask_quad(P, view + 1, cq, row);
         }
         const size_t px = (size_t)view * P.px_view_stride + (size_t)lane_off;  // first pixel of the quad
         unsigned vout = 0;
@@ -1432,7 +1379,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         }
         if (PIPE && view + 1 < v_end) {
             vb_next = valid_bits(mq);
-            if (view + 2 < v_end) mq = load_mask_quad(P, view + 2, cq, row, interior);
+            if (view + 2 < v_end) mq = load_mask_quad(P, view + 2, cq, row);
             if (vb_next != 0) {
                 issue_fringe(view + 1, f);
                 issue_gray(view + 1, g, iv);
