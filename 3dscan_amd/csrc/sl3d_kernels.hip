@@ -67,6 +67,9 @@
 #ifndef SL3D_PIPE
 #define SL3D_PIPE 1
 #endif
+#ifndef SL3D_PIPE_RIG0
+#define SL3D_PIPE_RIG0 0 /* the general rig's stage 7 is register-hungry: pipelined it spills (measured below) */
+#endif
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
@@ -599,6 +602,11 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 // COMPACT kernel, where a block's work item comes from: 0 = blockIdx (relies on in-order dispatch), 1 = one ticket per block
 // (blocks come and go as in the dense kernel, but a look-back can never wait for a tile that has not started), 2 = persistent
 // blocks that keep drawing tickets
+// COMPACT kernel: views between a tile's count and its look-back: 1 = one (points wait in registers), 2 = two (a second LDS
+// staging area in between; fits beside the first at 3 blocks per CU)
+#ifndef SL3D_SLACK
+#define SL3D_SLACK 2
+#endif
 #ifndef SL3D_PERSIST
 #define SL3D_PERSIST 1
 #endif
@@ -615,20 +623,27 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 #define SL3D_LB_STATS_ARG
 #define SL3D_LB_STATS_PASS
 #endif
-// the lane's status word of the first look-back window of tile `tile` (SL3D_LB_WORDS == 1): requested early, consumed later
-__device__ __forceinline__ unsigned long long lookback_poll(const unsigned long long *row, int tile, unsigned epoch)
+// the lane's status words of the first look-back window of tile `tile`: requested early, consumed later
+struct LbWords {
+    unsigned long long w[SL3D_LB_WORDS];
+};
+__device__ __forceinline__ LbWords lookback_poll(const unsigned long long *row, int tile, unsigned epoch)
 {
-    const int lane = (int)(threadIdx.x & 63u), idx = tile - 1 - lane;
-    unsigned long long w = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
-    if (idx >= 0 && lane < SL3D_LB_LANES) w = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return w;
+    const int lane = (int)(threadIdx.x & 63u);
+    LbWords r;
+#pragma unroll
+    for (int k = 0; k < SL3D_LB_WORDS; k++) {
+        const int idx = tile - 1 - SL3D_LB_LANES * k - lane;
+        r.w[k] = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
+        if (idx >= 0 && lane < SL3D_LB_LANES) r.w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return r;
 }
 
 // have_first: `first` holds the words lookback_poll fetched for the first window (no load for that round)
 __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row, int tile, unsigned epoch, int *err, bool have_first,
-                                                  unsigned long long first SL3D_LB_STATS_ARG)
+                                                  const LbWords &first SL3D_LB_STATS_ARG)
 {
-    static_assert(SL3D_LB_WORDS == 1 || true, "");
     const int lane = (int)(threadIdx.x & 63u);
     unsigned sum = 0;
     int hi = tile - 1;  // nearest predecessor of the current window
@@ -658,7 +673,7 @@ __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row,
             const int idx = hi - SL3D_LB_LANES * k - lane;  // word k of every lane: one contiguous run of tiles per load
             // tiles before the first one: an inclusive prefix of 0; lanes beyond the polling window: an empty aggregate
             w[k] = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
-            if (SL3D_LB_WORDS == 1 && have_first) w[k] = first;
+            if (have_first) w[k] = first.w[k];
             else if (idx >= 0 && lane < SL3D_LB_LANES) w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         have_first = false;
@@ -872,6 +887,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     static_assert(!COMPACT || SL3D_BLOCK != 256 || !SL3D_XCD_BANDS, "the look-back chains 1024-pixel tiles in ticket order");  // (other block sizes: A/B builds of the dense kernel only)
     __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];
     __shared__ unsigned s_wtot[4], s_base;  // COMPACT: valid pixels per wave of the current view; exclusive prefix of the tile
+    // COMPACT with SL3D_SLACK == 2: a second staging area, for the view that waits between the pixel loop and the registers
+    __shared__ __attribute__((aligned(16))) float s_mid[COMPACT && SL3D_SLACK == 2 ? SL3D_BLOCK * 12 : 4];
     __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_LDS ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
     if (SL3D_RCP_LDS) {
@@ -1217,14 +1234,40 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
 #endif
     bool have_fresh = false, have_held = false;
     bool draining = false;  // (measurement builds: -DSL3D_CX=512 skips the look-back of the block's last view)
-    int fview = 0, hview = 0;
-    unsigned ftile = 0, htile = 0;
+    int fview = 0, hview = 0, mview = 0;
+    unsigned ftile = 0, htile = 0, mtile = 0;
     unsigned fvout = 0, frank = 0, ftotal = 0;  // valid bytes of the lane's quad, its exclusive rank inside the tile, the tile's count
     unsigned hvout = 0, hrank = 0, htotal = 0;
+    unsigned mvout = 0, mrank = 0, mtotal = 0;  // SL3D_SLACK == 2: the view in between (points in s_mid)
+    bool have_mid = false;
+    float *my_mid = s_mid + (COMPACT && SL3D_SLACK == 2 ? threadIdx.x * 12 : 0);
     float held[12];
-    unsigned long long lb_first = 0;  // wave 0: the held view's first look-back window, requested by poll_held
+    LbWords lb_first = {};  // wave 0: the held view's first look-back window, requested by poll_held
     bool poll_pending = false;
+    // fresh (staging area) -> [mid (second staging area) ->] held (registers): called when the held slot is free and the staging
+    // area is about to be overwritten.  With the middle stage a view's look-back starts two whole iterations after its count
+    // was published instead of one.
     auto hold_fresh = [&]() {
+        if (SL3D_SLACK == 2) {
+            if (have_mid) {
+                const float4 *sm = (const float4 *)my_mid;
+                const float4 a = sm[0], b = sm[1], c = sm[2];
+                held[0] = a.x; held[1] = a.y; held[2] = a.z; held[3] = a.w; held[4] = b.x; held[5] = b.y; held[6] = b.z; held[7] = b.w;
+                held[8] = c.x; held[9] = c.y; held[10] = c.z; held[11] = c.w;
+                hview = mview; htile = mtile; hvout = mvout; hrank = mrank; htotal = mtotal;
+                have_held = true;
+                have_mid = false;
+            }
+            if (have_fresh) {
+                const float4 *sx = (const float4 *)my_xyz;
+                float4 *sm = (float4 *)my_mid;
+                sm[0] = sx[0]; sm[1] = sx[1]; sm[2] = sx[2];
+                mview = fview; mtile = ftile; mvout = fvout; mrank = frank; mtotal = ftotal;
+                have_mid = true;
+                have_fresh = false;
+            }
+            return;
+        }
         const float4 *sx = (const float4 *)my_xyz;
         const float4 a = sx[0], b = sx[1], c = sx[2];
         held[0] = a.x; held[1] = a.y; held[2] = a.z; held[3] = a.w; held[4] = b.x; held[5] = b.y; held[6] = b.z; held[7] = b.w;
@@ -1236,9 +1279,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     // the first look-back window of the held view is REQUESTED right behind a batch of plane loads and CONSUMED (flush_held)
     // right behind the decode that waits for those planes anyway: its round trip costs nothing unless it has to be repeated
     auto poll_held = [&]() {
-        if (wave == 0 && SL3D_LB_WORDS == 1 && !(SL3D_CX & 1))
-            lb_first = lookback_poll(P.tile_status + (size_t)hview * (size_t)P.n_tiles, (int)htile, P.epoch);
-        poll_pending = SL3D_LB_WORDS == 1;
+        if (wave == 0 && !(SL3D_CX & 1)) lb_first = lookback_poll(P.tile_status + (size_t)hview * (size_t)P.n_tiles, (int)htile, P.epoch);
+        poll_pending = true;
     };
     auto flush_held = [&]() {
         unsigned long long *row_st = P.tile_status + (size_t)hview * (size_t)P.n_tiles;
@@ -1290,7 +1332,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     // PIPE (timed kernels): the planes of view v+1 are requested in the middle of view v -- after phase A, when the plane
     // registers of view v are dead, before stage 7 -- so a wave's own arithmetic runs under its own memory requests
     // (the general rig's stage 7 is too register-hungry for it: 44 bytes of scratch per lane, -9 %)
-    constexpr bool PIPE = SL3D_PIPE && SL3D_SPLIT && !KEEP && RIG != 0;
+    constexpr bool PIPE = SL3D_PIPE && SL3D_SPLIT && !KEEP && (RIG != 0 || SL3D_PIPE_RIG0);
     unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     unsigned vb_next = 0;
     if (PIPE) {
@@ -1345,7 +1387,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
             // the view computed two steps ago leaves (its look-back window arrived with the planes), then the previous view's
             // points move from the staging area -- about to be overwritten -- into registers
             if (have_held) flush_held();
-            if (have_fresh) hold_fresh();
+            if (have_fresh || have_mid) hold_fresh();
         }
         if (vbits != 0) {
             if (KEEP) {
@@ -1423,10 +1465,10 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     }
     if (COMPACT) {  // drain: the view before last, then the last one
         if (have_held) flush_held();
-        if (have_fresh) {
-            draining = true;
+        while (have_fresh || have_mid) {  // (block-uniform)
+            draining = !have_fresh;
             hold_fresh();
-            flush_held();
+            if (have_held) flush_held();
         }
 #if SL3D_CX & 64
         if (threadIdx.x == 0)
