@@ -72,12 +72,40 @@ def main():
                 e = close(xyz, o.intersection_points(), v)
                 if e > 1e-5:
                     msg.append(f"keep={keep}: point error {e:.3g}")
+                if not keep:
+                    # the cloud compacted inside the kernel is exactly xyz[valid], in scan order
+                    cl = sc.fused_clouds(0, 1)[0]
+                    if not np.array_equal(cl, xyz[valid == 1]):
+                        msg.append("fused compaction != xyz[valid]")
+                    if not np.array_equal(sc.valid_map(), valid):
+                        msg.append("valid map changed by run_clouds")
                 if keep:
                     for a in (0, 1):
                         va = (o.valid_map(a) == 1) & inner
                         if not np.array_equal(sc.code(a)[va], o.code(a)[va]): msg.append(f"code axis {a}")
                         if not np.array_equal(sc.unwrapped_phase(a)[va], o.unwrapped_phi(a)[va]): msg.append(f"unwrapped axis {a}")
                     if not np.array_equal(sc.c_p_map()[v], o.c_p_map()[v]): msg.append("c_p_map")
+        # the same window as row stripes behind sl3d_group_* (random stripe count, both transports) == the single context
+        if H >= 2 and not msg:
+            ns = int(rng.integers(1, min(H, 6) + 1))
+            flags = S.SL3D_FLAG_GROUP_FORCE_RCCL if rng.random() < 0.5 else S.SL3D_FLAG_GROUP_NO_RCCL
+            with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, n_fringe=F, full_size=(fullW, fullH), origin=(col0, row0)) as sc, \
+                 S.Group(W, H, PW, PH, Nv, Nh, fwv, fwh, devices=[0] * ns, n_fringe=F, full_size=(fullW, fullH), origin=(col0, row0), flags=flags) as g:
+                for x in (sc, g):
+                    x.set_calibration(*ct)
+                    x.set_mask(full_mask)
+                    x.set_frames(0, cap["planes_v"])
+                    x.set_frames(1, cap["planes_h"])
+                sc.run()
+                g.run(0, 1)
+                g.gather(0, 1)
+                a_, b_ = sc.points(), g.points(0)
+                if not (np.array_equal(a_[1], b_[1]) and np.array_equal(a_[0], b_[0], equal_nan=True)):
+                    msg.append(f"group of {ns} stripes ({g.transport}) != single context")
+                g.run_clouds(0, 1)
+                g.gather_clouds(0, 1)
+                if not np.array_equal(g.cloud(0), a_[0][a_[1] == 1]):
+                    msg.append(f"group cloud of {ns} stripes != xyz[valid]")
         tag = f"case {case}: full {fullW}x{fullH} window {W}x{H}@({col0},{row0}) proj {PW}x{PH} N {Nv}/{Nh} fw {fwv}/{fwh} F {F} noise {noise} rig {rig} valid {int((o.valid_map(2) == 1).sum())}"
         if msg:
             bad += 1
