@@ -325,6 +325,52 @@ def test_config3_shape_8_stripes_of_135_rows():
     assert_points_close(whole[2][0], o.intersection_points(), vo)
 
 
+def test_config3_full_batch_64_views_8_stripes():
+    """configs[3] at its full size: 64 views of 1920x1080, every view cut into 8 stripes of 135 rows (the 8 GPUs of the node;
+    here 8 contexts on one GPU behind sl3d_group_*), inputs generated on the device inside every stripe, computed and
+    gathered chunk by chunk (16 views per launch, the next chunk computing while the previous one is gathered): the 64
+    assembled views equal a whole-frame context's results bit for bit, dense and compacted."""
+    import ctypes as C
+    S, syn = _S(), pkg("synth")
+    W, H, N, fw, NV, CH = 1920, 1080, 10, 2, 64, 16
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    mask = syn.default_mask(W, H)
+    L = S.load_library()
+
+    def synth(handle, v):
+        pl = np.asarray((0.75 * (v % 16), 0.05, 0.05 - 0.003 * (v % 16)), dtype=np.float64)
+        assert L.sl3d_synth_view(handle, v, pl.ctypes.data, 0x3D5CA11, v, 2, C.c_float(0.8), C.c_float(10.0)) == 0
+
+    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV) as whole, \
+         S.Group(W, H, W, H, N, N, fw, fw, devices=[0] * 8, max_views=NV, flags=S.SL3D_FLAG_GROUP_NO_RCCL) as g:
+        whole.set_calibration(*cal)
+        g.set_calibration(*cal)
+        stripes = g.stripes()
+        assert [s[1] for s in stripes] == [135] * 8
+        for v in range(NV):
+            whole.set_mask(mask, view=v)
+            g.set_mask(mask, view=v)
+            synth(whole._h, v)
+            for (_, _, _, h) in stripes:
+                synth(h, v)
+        for c in range(0, NV, CH):
+            g.run(c, CH)
+            g.gather(c, CH)
+        whole.run(0, NV)
+        for v in range(NV):
+            xyz, val = g.points(v)
+            wx, wv = whole.points(v)
+            assert np.array_equal(val, wv), v
+            assert np.array_equal(xyz, wx, equal_nan=True), v
+        for c in range(0, NV, CH):
+            g.run_clouds(c, CH)
+            counts = g.gather_clouds(c, CH)
+            for k in (0, CH - 1):
+                wx, wv = whole.points(c + k)
+                assert counts[k] == int((wv == 1).sum())
+                assert np.array_equal(g.cloud(c + k), wx[wv == 1]), c + k
+
+
 @pytest.mark.parametrize("rank", [0, 7])
 def test_config4_stripes_at_frame_top_and_bottom(rank):
     """configs[4]: 8192x6144, N = 12, two axes; the stripes of rank 0 (frame top) and rank 7 (frame bottom), 768 rows each.
