@@ -593,7 +593,7 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 // run).  Measured on the 16 x 1080p batch (profiles/README.md, round 2): the nearest known prefix is ~10-20 tiles back, so a
 // small window suffices, and what a look-back costs is its polls -- agent-scope 8-byte loads that go to the memory side of the
 // L2 every time -- and above all WAITING for predecessor tiles that are still computing the view: with the look-back right
-// behind the tile's own count 57 % of the calls had to wait (3.6 us per call); deferred by one whole view (SL3D_HOLD) 19 %
+// behind the tile's own count 57 % of the calls had to wait (3.6 us per call); deferred by one whole view (the points wait in registers) 19 %
 // (1.5 us, one round trip that rides behind the next view's plane loads).  Wider windows only add polls: 64 lanes -3 %,
 // 256 tiles per round -25 %.
 #ifndef SL3D_LB_WORDS
@@ -875,7 +875,7 @@ __device__ __forceinline__ void triangulate_from(const KParams &P, CalP Cp, cons
 // every view -- the valid points in row-major scan order (8/save_point_cloud.cpp:85-104) -- in the same pass: a block is a
 // 1024-pixel tile of the scan, tile prefixes come from a decoupled look-back (tile_lookback), and the points of view v
 // leave while the planes of view v+1 are in flight (their look-back overlaps that latency).  The valid map is still written.
-// the COMPACT kernel keeps a second view's points in registers (SL3D_HOLD): 3 waves per SIMD leave it 168 VGPRs (150 used,
+// the COMPACT kernel keeps a second view's points in registers: 3 waves per SIMD leave it 168 VGPRs (150 used,
 // no scratch); squeezed into the 128 of 4 waves per SIMD it spills 88 bytes per lane and loses 15 %
 #ifndef SL3D_OCC_COMPACT
 #define SL3D_OCC_COMPACT 3
@@ -1223,11 +1223,13 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         if (COMPACT && !alive) return 0u;
         return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(m);
     };
-    // ---- COMPACT: two views of this lane's loop are in flight behind the one being computed ----------------------------------
+    // ---- COMPACT: up to three views of this lane's loop are in flight behind the one being computed ----------------------------
     //   fresh : the view computed last; its points are still in the LDS staging area (my_xyz), its tile count is published
-    //   held  : the view before it; its points sit in 12 registers while the next view is computed, so that by the time its
-    //           look-back runs (after the NEXT view's plane loads have been issued) every predecessor tile has had a whole
-    //           iteration to publish its count -- the look-back then finds its words ready instead of polling for them
+    //   mid   : (SL3D_SLACK == 2) the view before it, parked in a second staging area (s_mid)
+    //   held  : the oldest; its points sit in 12 registers.  Its first look-back window is requested behind a batch of plane
+    //           loads and consumed behind the decode that waits for those planes, one or two whole iterations after its count
+    //           was published -- by then its predecessors have normally published theirs, so the look-back finds its words
+    //           ready instead of polling for them; then its points are stored at their final, compacted position.
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
 #if SL3D_CX & 64
     unsigned long long lb_stats[6] = {0, 0, 0, 0, 0, 0};
