@@ -126,6 +126,36 @@ def test_device_mask_preparation_windows_and_borders():
                     assert np.array_equal(sc.valid_map(2), vo[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
 
 
+def test_set_frames_one_copy_per_axis_and_download():
+    """Planes that follow each other in host memory go up as ONE 2-D copy per axis (pageable and pinned sources); the result
+    equals plane-by-plane uploads.  sl3d_download returns device addresses the library hands out."""
+    S, syn = _S(), pkg("synth")
+    W, H, PW, PH, N, fw = 203, 77, 256, 192, 6, 8     # width != device pitch: the copy really is 2-D
+    cap = syn.make_capture(W, H, PW, PH, N, 5, fw, fw, noise=2)
+    cal = syn.cal_tuple(cap["cal"])
+    with S.Scanner(W, H, PW, PH, N, 5, fw, fw, max_views=3) as sc:
+        sc.set_calibration(*cal)
+        stack_v, stack_h = np.stack(cap["planes_v"]), np.stack(cap["planes_h"])
+        pin_v, pin_h = sc.pinned(stack_v.shape, np.uint8), sc.pinned(stack_h.shape, np.uint8)
+        pin_v[:], pin_h[:] = stack_v, stack_h
+        for v, (pv, ph) in enumerate(((cap["planes_v"], cap["planes_h"]), (list(stack_v), list(stack_h)), (list(pin_v), list(pin_h)))):
+            sc.set_mask(cap["mask"], view=v)
+            sc.set_frames(0, pv, view=v)
+            sc.set_frames(1, ph, view=v)
+        sc.run(0, 3)
+        ref = sc.points(0)
+        for v in (1, 2):
+            got = sc.points(v)
+            assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0], equal_nan=True), v
+            for a in (0, 1):
+                for x, y in zip(sc.frames(a, v), sc.frames(a, 0)):
+                    assert np.array_equal(x, y)
+        b = sc.device_buffers()
+        row = np.empty(W, dtype=np.uint8)
+        sc._d2h(row, b.valid + 5 * b.valid_pitch)
+        assert np.array_equal(row, ref[1][5])
+
+
 # ---- row-stripe groups behind the C ABI -----------------------------------------------------------------------------------
 def _single_context_reference(W, H, PW, PH, N, fw, cal, masks, caps):
     S = _S()
