@@ -217,8 +217,11 @@ extern "C" int sl3d_group_create(const sl3d_config *cfg, const int *devices, int
             std::vector<int> devs;
             for (auto &u : g->gpus) devs.push_back(u.device);
             std::vector<ncclComm_t> comms(devs.size(), nullptr);
+            (void)hipGetLastError();  // RCCL reports any stale (non-fatal) HIP error of this thread as its own: start clean
             const ncclResult_t r = R.CommInitAll(comms.data(), (int)devs.size(), devs.data());
-            if (r != ncclSuccess) return bail(SL3D_E_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r));
+            if (r != ncclSuccess)
+                return bail(SL3D_E_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r) +
+                                            " (a process that also loads torch must import it BEFORE this library: one ROCm stack per process)");
             for (size_t k = 0; k < devs.size(); k++) g->gpus[k].nccl = comms[k];
             g->use_rccl = true;
         }

@@ -927,6 +927,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         }
     }
     // everything of an item that depends on the pixel only; false if this lane has nothing to do in a dense kernel
+    MaskQuad mq_first = {0u};
     auto begin_item = [&](unsigned tile_, int group) -> bool {
         tile = tile_;
         v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
@@ -942,6 +943,9 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         gx0 = P.col0 + cq * 4;
         gy = P.row0 + row;
         lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;
+        // the valid bits of the item's first view are requested now, so that they travel together with the camera table
+        // entries below instead of after them (one round trip less before the first plane loads can leave)
+        mq_first = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row);
         // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
         // index it (each lane reads back only what it wrote: no barrier)
         if (P.use_cam_table) {
@@ -1330,7 +1334,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         return;
     }
     unsigned next_ticket = 0;
-    MaskQuad mq = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row);
+    MaskQuad mq = mq_first;
     // PIPE (timed kernels): the planes of view v+1 are requested in the middle of view v -- after phase A, when the plane
     // registers of view v are dead, before stage 7 -- so a wave's own arithmetic runs under its own memory requests
     // (the general rig's stage 7 is too register-hungry for it: 44 bytes of scratch per lane, -9 %)

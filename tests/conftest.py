@@ -5,6 +5,13 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # torch first: its bundled ROCm stack (HIP runtime, HSA, RCCL) must be the one libsl3d.so binds to when both live in one
+    # process; loading libsl3d.so first and torch later mixes two HSA instances and RCCL then finds "no ROCm-capable device"
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
