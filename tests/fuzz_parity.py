@@ -106,6 +106,34 @@ def main():
                 g.gather_clouds(0, 1)
                 if not np.array_equal(g.cloud(0), a_[0][a_[1] == 1]):
                     msg.append(f"group cloud of {ns} stripes != xyz[valid]")
+        # a batch launch over several views with different masks (empty and full ones included) == the views one by one,
+        # dense and compacted: exercises the view loop (views per lane, the pipelined plane loads, skipped views)
+        if not msg:
+            V = int(rng.integers(2, 10))
+            with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, n_fringe=F, max_views=V, full_size=(fullW, fullH), origin=(col0, row0)) as sc:
+                sc.set_calibration(*ct)
+                for v in range(V):
+                    m = full_mask.copy()
+                    r = rng.random()
+                    if r < 0.2:
+                        m[:] = 0
+                    elif r < 0.4:
+                        m[:] = 1
+                    elif r < 0.7:
+                        m[rng.random(m.shape) < 0.5] = 0
+                    sc.set_mask(m, view=v)
+                    sc.set_frames(0, cap["planes_v"], view=v)
+                    sc.set_frames(1, cap["planes_h"], view=v)
+                sc.run(0, V)
+                batch = [sc.points(v) for v in range(V)]
+                bclouds = sc.fused_clouds(0, V)
+                for v in range(V):
+                    sc.run(v, 1)
+                    one = sc.points(v)
+                    if not (np.array_equal(one[1], batch[v][1]) and np.array_equal(one[0], batch[v][0], equal_nan=True)):
+                        msg.append(f"batch of {V}: view {v} differs from its single launch")
+                    if not np.array_equal(bclouds[v], one[0][one[1] == 1]):
+                        msg.append(f"batch of {V}: cloud of view {v} != xyz[valid]")
         tag = f"case {case}: full {fullW}x{fullH} window {W}x{H}@({col0},{row0}) proj {PW}x{PH} N {Nv}/{Nh} fw {fwv}/{fwh} F {F} noise {noise} rig {rig} valid {int((o.valid_map(2) == 1).sum())}"
         if msg:
             bad += 1
