@@ -97,3 +97,12 @@ def test_group_create_rejects_bad_arguments(scanner_mod):
         pytest.skip("a HIP device is present")
     assert rc == -2 and h.value is None
     assert L.sl3d_group_size(None) == 0 and L.sl3d_group_transport(None) == b"copy"
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/sl3d.h is the C ABI: it must compile as C99 with nothing but the standard headers (no C++, no HIP, no torch types)."""
+    import subprocess
+    src = tmp_path / "inc.c"
+    src.write_text('#include "sl3d.h"\nint main(void) { sl3d_config c; sl3d_device_buffers b; (void)c; (void)b; return sl3d_group_size(0); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "inc.o")])
