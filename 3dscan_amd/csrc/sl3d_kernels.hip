@@ -887,11 +887,14 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     static_assert(!COMPACT || SL3D_BLOCK != 256 || !SL3D_XCD_BANDS, "the look-back chains 1024-pixel tiles in ticket order");  // (other block sizes: A/B builds of the dense kernel only)
     __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];
     __shared__ unsigned s_wtot[4], s_base;  // COMPACT: valid pixels per wave of the current view; exclusive prefix of the tile
-    // COMPACT with SL3D_SLACK == 2: a second staging area, for the view that waits between the pixel loop and the registers
-    __shared__ __attribute__((aligned(16))) float s_mid[COMPACT && SL3D_SLACK == 2 ? SL3D_BLOCK * 12 : 4];
+    // COMPACT with SL3D_SLACK >= 2: SL3D_SLACK - 1 more staging areas, for the views that wait between the pixel loop and the registers
+    constexpr int NMID = COMPACT ? SL3D_SLACK - 1 : 0;
+    __shared__ __attribute__((aligned(16))) float s_mid[NMID > 0 ? NMID * SL3D_BLOCK * 12 : 4];
     __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
-    __shared__ __attribute__((aligned(16))) double s_rcp[SL3D_RCP_LDS ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
-    if (SL3D_RCP_LDS) {
+    // (the compacting kernel with three views of slack gives the table's 6 KB to its staging areas and computes 1/d: -1 %)
+    constexpr bool RCP_TAB = SL3D_RCP_LDS != 0 && !(COMPACT && SL3D_SLACK >= 3);
+    __shared__ __attribute__((aligned(16))) double s_rcp[RCP_TAB ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
+    if (RCP_TAB) {
         fill_rcp_table(s_rcp);
         __syncthreads();
     }
@@ -1094,8 +1097,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         const int code_v = (int)((code[0][0] >> (16 * i)) & 0xffffu);
         const int code_h = (int)((code[1][0] >> (16 * i)) & 0xffffu);
         const AtanK AK = atan_consts<true>();
-        float wv = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
-        float wh = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+        float wv = wrapped_phase<RCP_TAB>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+        float wh = wrapped_phase<RCP_TAB>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
         // stage 4 shifts by +Pi only inside its loop range (4/phase_unwrap.cpp:285,290,304,308); outside it the
         // unwrapped value is 0 whatever the wrapped one is (pixel_chain), and the timed mode does not keep wrapped
         wv = shift_pi(wv);
@@ -1138,8 +1141,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         const int code_v = (int)((code[0][0] >> (16 * i)) & 0xffffu);
         const int code_h = (int)((code[1][0] >> (16 * i)) & 0xffffu);
         const AtanK AK = atan_consts<true>();
-        float wv = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
-        float wh = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+        float wv = wrapped_phase<RCP_TAB>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+        float wh = wrapped_phase<RCP_TAB>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
         wv = shift_pi(wv);
         wh = shift_pi(wh);
         int cx, cy;
@@ -1229,7 +1232,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     };
     // ---- COMPACT: up to three views of this lane's loop are in flight behind the one being computed ----------------------------
     //   fresh : the view computed last; its points are still in the LDS staging area (my_xyz), its tile count is published
-    //   mid   : (SL3D_SLACK == 2) the view before it, parked in a second staging area (s_mid)
+    //   mid   : (SL3D_SLACK >= 2) the view(s) before it, parked in further staging areas (s_mid)
     //   held  : the oldest; its points sit in 12 registers.  Its first look-back window is requested behind a batch of plane
     //           loads and consumed behind the decode that waits for those planes, one or two whole iterations after its count
     //           was published -- by then its predecessors have normally published theirs, so the look-back finds its words
@@ -1240,13 +1243,21 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
 #endif
     bool have_fresh = false, have_held = false;
     bool draining = false;  // (measurement builds: -DSL3D_CX=512 skips the look-back of the block's last view)
-    int fview = 0, hview = 0, mview = 0;
-    unsigned ftile = 0, htile = 0, mtile = 0;
+    int fview = 0, hview = 0;
+    unsigned ftile = 0, htile = 0;
     unsigned fvout = 0, frank = 0, ftotal = 0;  // valid bytes of the lane's quad, its exclusive rank inside the tile, the tile's count
     unsigned hvout = 0, hrank = 0, htotal = 0;
-    unsigned mvout = 0, mrank = 0, mtotal = 0;  // SL3D_SLACK == 2: the view in between (points in s_mid)
-    bool have_mid = false;
-    float *my_mid = s_mid + (COMPACT && SL3D_SLACK == 2 ? threadIdx.x * 12 : 0);
+    // SL3D_SLACK >= 2: the views in between, oldest last (points in s_mid[k])
+    int mview[NMID > 0 ? NMID : 1] = {0};
+    unsigned mtile[NMID > 0 ? NMID : 1] = {0}, mvout[NMID > 0 ? NMID : 1] = {0}, mrank[NMID > 0 ? NMID : 1] = {0}, mtotal[NMID > 0 ? NMID : 1] = {0};
+    bool have_mid[NMID > 0 ? NMID : 1] = {false};
+    float *my_mid = s_mid + (NMID > 0 ? threadIdx.x * 12 : 0);  // area k at my_mid + k * SL3D_BLOCK * 12
+    auto any_mid = [&]() {
+        bool a = false;
+#pragma unroll
+        for (int k = 0; k < NMID; k++) a = a || have_mid[k];
+        return a;
+    };
     float held[12];
     LbWords lb_first = {};  // wave 0: the held view's first look-back window, requested by poll_held
     bool poll_pending = false;
@@ -1254,22 +1265,34 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     // area is about to be overwritten.  With the middle stage a view's look-back starts two whole iterations after its count
     // was published instead of one.
     auto hold_fresh = [&]() {
-        if (SL3D_SLACK == 2) {
-            if (have_mid) {
-                const float4 *sm = (const float4 *)my_mid;
+        if (NMID > 0) {
+            // the oldest parked view moves into the (free) registers, the others move up one area, the fresh one is parked
+            if (have_mid[NMID - 1]) {
+                const float4 *sm = (const float4 *)(my_mid + (NMID - 1) * SL3D_BLOCK * 12);
                 const float4 a = sm[0], b = sm[1], c = sm[2];
                 held[0] = a.x; held[1] = a.y; held[2] = a.z; held[3] = a.w; held[4] = b.x; held[5] = b.y; held[6] = b.z; held[7] = b.w;
                 held[8] = c.x; held[9] = c.y; held[10] = c.z; held[11] = c.w;
-                hview = mview; htile = mtile; hvout = mvout; hrank = mrank; htotal = mtotal;
+                hview = mview[NMID - 1]; htile = mtile[NMID - 1]; hvout = mvout[NMID - 1]; hrank = mrank[NMID - 1]; htotal = mtotal[NMID - 1];
                 have_held = true;
-                have_mid = false;
+                have_mid[NMID - 1] = false;
+            }
+#pragma unroll
+            for (int k = NMID - 1; k > 0; k--) {
+                if (have_mid[k - 1]) {
+                    const float4 *src = (const float4 *)(my_mid + (k - 1) * SL3D_BLOCK * 12);
+                    float4 *dst = (float4 *)(my_mid + k * SL3D_BLOCK * 12);
+                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+                    mview[k] = mview[k - 1]; mtile[k] = mtile[k - 1]; mvout[k] = mvout[k - 1]; mrank[k] = mrank[k - 1]; mtotal[k] = mtotal[k - 1];
+                    have_mid[k] = true;
+                    have_mid[k - 1] = false;
+                }
             }
             if (have_fresh) {
                 const float4 *sx = (const float4 *)my_xyz;
                 float4 *sm = (float4 *)my_mid;
                 sm[0] = sx[0]; sm[1] = sx[1]; sm[2] = sx[2];
-                mview = fview; mtile = ftile; mvout = fvout; mrank = frank; mtotal = ftotal;
-                have_mid = true;
+                mview[0] = fview; mtile[0] = ftile; mvout[0] = fvout; mrank[0] = frank; mtotal[0] = ftotal;
+                have_mid[0] = true;
                 have_fresh = false;
             }
             return;
@@ -1393,7 +1416,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
             // the view computed two steps ago leaves (its look-back window arrived with the planes), then the previous view's
             // points move from the staging area -- about to be overwritten -- into registers
             if (have_held) flush_held();
-            if (have_fresh || have_mid) hold_fresh();
+            if (have_fresh || any_mid()) hold_fresh();
         }
         if (vbits != 0) {
             if (KEEP) {
@@ -1405,8 +1428,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                         const int code_h = (int)((code[1][k >> 1] >> (16 * (k & 1))) & 0xffffu);
                         // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
                         const AtanK AK = atan_consts<true>();
-                        float wv = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
-                        float wh = wrapped_phase<SL3D_RCP_LDS != 0>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+                        float wv = wrapped_phase<RCP_TAB>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+                        float wh = wrapped_phase<RCP_TAB>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
                         wv = shift_pi_if(wv, gx0 + k >= 1 && gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
                         wh = shift_pi_if(wh, gy >= 1 && gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
                         const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
@@ -1471,7 +1494,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     }
     if (COMPACT) {  // drain: the view before last, then the last one
         if (have_held) flush_held();
-        while (have_fresh || have_mid) {  // (block-uniform)
+        while (have_fresh || any_mid()) {  // (block-uniform)
             draining = !have_fresh;
             hold_fresh();
             if (have_held) flush_held();
