@@ -228,6 +228,8 @@ def side_figures(args, scm, syn, np, dev_index):
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+        os.environ["NCCL_DEBUG"] = "WARN"   # no RCCL version banner on stdout next to the JSON line
     dmod = importlib.import_module("3dscan_amd.distributed")   # imports neither torch nor the HIP runtime
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process stays off the GPU and starts the N ranks as fresh children
