@@ -1496,6 +1496,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         if (have_held) flush_held();
         while (have_fresh || any_mid()) {  // (block-uniform)
             draining = !have_fresh;
+            __syncthreads();  // (inside the view loop a barrier separates two flushes: every wave has read s_base of the previous one)
             hold_fresh();
             if (have_held) flush_held();
         }
