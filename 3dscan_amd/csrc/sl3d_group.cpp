@@ -356,6 +356,11 @@ static int group_exchange(sl3d_group *g, const std::vector<Xfer> &xs)
         if (g->use_rccl && (S.gpu != 0 || (g->force_rccl && x.stripe != 0))) any_rccl = true;
     }
     if (any_rccl) GNCCL(g, rccl().GroupStart());
+    // an error between GroupStart and GroupEnd must not leave this thread inside an open RCCL group
+    struct GroupCloser {
+        bool open;
+        ~GroupCloser() { if (open) (void)rccl().GroupEnd(); }
+    } closer{any_rccl};
     int in_group = 0;
     for (const Xfer &x : xs) {
         if (x.count == 0) continue;
@@ -379,6 +384,7 @@ static int group_exchange(sl3d_group *g, const std::vector<Xfer> &xs)
             GHIP(g, hipMemcpyPeerAsync(x.dst, root.device, x.src, S.device, x.bytes(), root.comm));
         }
     }
+    closer.open = false;
     if (any_rccl) GNCCL(g, rccl().GroupEnd());
     for (auto &u : g->gpus) {
         DeviceGuard dg(u.device);
