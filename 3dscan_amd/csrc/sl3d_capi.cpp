@@ -827,7 +827,16 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
     P.ticket = x->d_ticket;
     P.clouds = x->d_clouds;
     P.tile_status = x->d_tile_status;
-    P.cloud_totals = x->d_totals;
+    // the per-view counts and the error flag live in pinned HOST memory the kernel writes directly (one 8-byte store per view):
+    // sl3d_get_cloud_counts then only has to wait for the stream, no device-to-host copy in the launch -> counts path
+    if (!x->h_counts) {
+        HIPCHK(x, hipHostMalloc((void **)&x->h_counts, (mv + 1) * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(x->h_counts, 0, (mv + 1) * sizeof(unsigned long long));
+    }
+    void *mapped = nullptr;
+    HIPCHK(x, hipHostGetDevicePointer(&mapped, x->h_counts, 0));
+    P.cloud_totals = (unsigned long long *)mapped;
+    P.lookback_flag = (int *)((unsigned long long *)mapped + mv);
     P.lookback_err = x->d_lookback_err;
 #ifdef SL3D_MEASURE
     rc = dev_alloc(x, &x->P.dbg, mv * (size_t)P.n_tiles * 4);
@@ -864,14 +873,15 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->d_tile_status) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
     ON_DEVICE(x);
-    // the counts and the error flag land in pinned memory (two small DMA copies, no staging)
-    if (!x->h_counts) HIPCHK(x, hipHostMalloc((void **)&x->h_counts, ((size_t)x->cfg.max_views + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-    unsigned long long *t = x->h_counts;
-    HIPCHK(x, hipMemcpyAsync(t, x->d_totals + first_view, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipMemcpyAsync(t + n_views, x->d_lookback_err, sizeof(int), hipMemcpyDeviceToHost, x->stream));
+    // the kernel stored the counts (and, never expected, the error flag) into pinned host memory itself: wait for it, read them
     HIPCHK(x, hipStreamSynchronize(x->stream));
-    if (*(const int *)(t + n_views)) return fail(x, SL3D_E_HIP, "fused compaction: a tile look-back timed out");
-    for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[v];
+    volatile unsigned long long *t = x->h_counts;
+    volatile int *flag = (volatile int *)(x->h_counts + (size_t)x->cfg.max_views);
+    if (*flag) {
+        *flag = 0;
+        return fail(x, SL3D_E_HIP, "fused compaction: a tile look-back timed out");
+    }
+    for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[first_view + v];
     if (device_xyz) *device_xyz = x->d_clouds + 3 * (size_t)first_view * x->P.px_view_stride;
     if (view_stride_points) *view_stride_points = x->P.px_view_stride;
     return SL3D_OK;

@@ -81,8 +81,10 @@ struct KParams {
     // compacted clouds written by the fused kernel itself (sl3d_run_clouds; NULL until first used)
     float *clouds;             // [view][px_view_stride][3]: the valid points of a view in row-major scan order
     unsigned long long *tile_status;   // [view][n_tiles] decoupled look-back words: epoch << 34 | flag << 32 | count
-    unsigned long long *cloud_totals;  // [view] number of valid points
-    int *lookback_err;         // set if a look-back gave up waiting (never expected; reported by sl3d_get_cloud_counts)
+    unsigned long long *cloud_totals;  // [view] number of valid points -- HOST memory mapped into the device: the last tile of a view stores
+                                       // the count where sl3d_get_cloud_counts reads it after the stream has drained (no copy)
+    int *lookback_flag;        // host-mapped too: set if a look-back gave up waiting (never expected; reported by sl3d_get_cloud_counts)
+    int *lookback_err;         // device: measurement builds (-DSL3D_CX=64) keep their look-back counters at [2..]
     unsigned epoch;            // launch generation of tile_status (words of older generations read as "not ready")
     unsigned *ticket;          // work-item counter of the persistent COMPACT kernel (never reset: ticket_base is its value at launch)
     unsigned ticket_base;

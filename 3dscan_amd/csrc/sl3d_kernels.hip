@@ -704,7 +704,7 @@ __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row,
             continue;
         }
         if (++spins > SL3D_LOOKBACK_SPINS) {  // never expected: report instead of hanging the GPU
-            if (lane == 0) atomicExch(err, 1);
+            if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped flag)
             return sum;
         }
         __builtin_amdgcn_s_sleep(SL3D_LB_SLEEP);
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
 #endif
             const unsigned base = ((SL3D_CX & 1) || ((SL3D_CX & 512) && draining))
                                       ? htile * 1024u
-                                      : tile_lookback(row_st, (int)htile, P.epoch, P.lookback_err, poll_pending, lb_first SL3D_LB_STATS_PASS);
+                                      : tile_lookback(row_st, (int)htile, P.epoch, P.lookback_flag, poll_pending, lb_first SL3D_LB_STATS_PASS);
             if (lane == 0) {
 #if SL3D_CX & 128
                 P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 2] = wall_clock64();
