@@ -433,3 +433,59 @@ def test_config4_stripes_at_frame_top_and_bottom(rank):
         assert np.array_equal(valid[r:r + RH][I] == 1, vo), (rank, r)
         assert_points_close(xyz[r:r + RH][I], o.intersection_points()[I], vo, rel=1e-5)
         assert vo.sum() > 50_000
+
+
+def test_config4_full_frame_8_stripes_vs_oracle():
+    """configs[4] whole: ONE 8192x6144 view (50.3 Mpx, N = 12, two axes) as 8 row stripes of 768 rows behind sl3d_group_*
+    (all on device 0, RCCL path forced), gathered dense and compacted == one 50-Mpx context bit for bit, and the whole frame
+    against the oracle (fused row-major restatement on all host cores; exact pixel indices -- the frame exceeds 2^24 pixels)."""
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max" and int(lim) < (24 << 30):
+            pytest.skip("needs ~6 GB of host memory beside the rest of the session")
+    except OSError:
+        pass
+    S, syn = _S(), pkg("synth")
+    W, H, N, fw = 8192, 6144, 12, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    mask = syn.default_mask(W, H)
+    mask[0:6, 4000:5000] = 1          # selected pixels on the frame's top border row
+    mask[H - 5:H, 100:300] = 1        # ... and on its bottom rows
+    mask[767:770, 1000:3000] = 0      # a hole across the first stripe boundary (boundary removal needs the neighbour stripe's mask rows)
+    with S.Scanner(W, H, W, H, N, N, fw, fw) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        sc.synth_view(0, plane=(0.0, 0.05, 0.05), view_id=0, noise=2)
+        sc.run()
+        xyz, valid = sc.points()
+        pv, ph = sc.frames(0), sc.frames(1)
+        cl = sc.fused_clouds(0, 1)[0]
+    assert np.array_equal(cl, xyz[valid == 1])
+    with S.Group(W, H, W, H, N, N, fw, fw, devices=[0] * 8, flags=S.SL3D_FLAG_GROUP_FORCE_RCCL) as g:
+        assert [(r0, n) for r0, n, _, _ in g.stripes()] == [(768 * k, 768) for k in range(8)]
+        g.set_calibration(*cal)
+        g.set_mask(mask)
+        g.set_frames(0, pv)
+        g.set_frames(1, ph)
+        g.run()
+        g.gather()
+        gx, gv = g.points()
+        assert np.array_equal(gv, valid) and np.array_equal(gx, xyz, equal_nan=True)
+        del gx, gv
+        g.run_clouds()
+        assert g.gather_clouds() == [int((valid == 1).sum())]
+        assert np.array_equal(g.cloud(), cl)
+    del cl
+    o = Oracle(W, H, W, H, N, N, fw, fw, exact_index=True)
+    o.set_mask(mask)
+    o.set_calibration(*cal)
+    oxyz, ovalid, _ = o.run_scan_rowmajor(pv, ph)
+    vo = ovalid == 1
+    assert np.array_equal(valid == 1, vo)
+    assert vo.sum() > 49_000_000
+    worst = 0.0
+    for r in range(0, H, 512):   # (in slabs: fp64 copies of 50 M points at once would double the footprint of the test)
+        m = vo[r:r + 512]
+        a, b = xyz[r:r + 512][m].astype(np.float64), oxyz[r:r + 512][m].astype(np.float64)
+        worst = max(worst, float((np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)).max()))
+    assert worst <= 1e-5, worst
