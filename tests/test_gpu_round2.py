@@ -255,7 +255,7 @@ def test_config2_full_12mp_frame():
     frame, (b) the oracle on 64-row stripes at the top border, mid frame and the bottom border (the oracle treats a stripe
     as its own image, so rows next to an artificial stripe edge are skipped, rows at the TRUE frame border are compared),
     (c) 8 row stripes (375 rows: configs[3]/[4]'s decomposition) reproduce the whole frame bit for bit, as a group with
-    the gather, (d) the compacted cloud of the whole frame."""
+    the gather, (d) the compacted cloud of the whole frame, (b') the whole frame against the oracle's row-major restatement."""
     S, syn = _S(), pkg("synth")
     W, H, PW, PH, N, fw, RH = 4096, 3000, 2048, 2048, 10, 2, 64
     cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
@@ -287,6 +287,14 @@ def test_config2_full_12mp_frame():
         assert_points_close(fused["xyz"][sl][I], o.intersection_points()[I], vo)
         assert vo.sum() > 100_000
     v = fused["valid"] == 1
+    # (b') ALL 12.3 Mpx against the oracle's fused row-major restatement (bit-identical to the stage functions, tests/test_oracle.py)
+    o = Oracle(W, H, PW, PH, N, N, fw, fw)
+    o.set_mask(mask)
+    o.set_calibration(*cal)
+    oxyz, ovalid, _ = o.run_scan_rowmajor(pv, ph)
+    assert np.array_equal(ovalid == 1, v)
+    assert_points_close(fused["xyz"], oxyz.astype(np.float64), v)
+    del o, oxyz, ovalid
     # the timed mode on the whole frame (camera-frame solve: equal to the parity mode's general solve to ~1e-12, not bit for bit)
     with S.Scanner(W, H, PW, PH, N, N, fw, fw) as sc:
         sc.set_calibration(*cal)
