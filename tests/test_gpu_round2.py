@@ -89,6 +89,21 @@ def test_fused_compaction_full_hd_batch():
                 xyz, val = dense[v]
                 assert np.array_equal(clouds[v], xyz[val == 1]), v
         assert len(clouds[3]) == 0 and len(clouds[0]) > 1_900_000
+        # the batched launch (the benchmark's exact shape) against the oracle, view by view: full, empty, holes, every other column, last
+        for v in (0, 3, 5, 7, 15):
+            m = syn.default_mask(W, H)
+            if v == 3:
+                m[:] = 0
+            elif v == 5:
+                m = _random_mask(np.random.default_rng(5), W, H, holes=30)
+            elif v == 7:
+                m[:, ::2] = 0
+            o = Oracle(W, H, W, H, N, N, fw, fw)
+            o.set_mask(m)
+            o.set_calibration(*cal)
+            oxyz, ovalid, _ = o.run_scan_rowmajor(sc.frames(0, v), sc.frames(1, v))
+            assert np.array_equal(dense[v][1], ovalid), v
+            assert_points_close(dense[v][0], oxyz, ovalid == 1)
 
 
 # ---- mask preparation on the device -------------------------------------------------------------------------------------
