@@ -512,3 +512,39 @@ def test_config4_full_frame_8_stripes_vs_oracle():
         a, b = xyz[r:r + 512][m].astype(np.float64), oxyz[r:r + 512][m].astype(np.float64)
         worst = max(worst, float((np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-300)).max()))
     assert worst <= 1e-5, worst
+
+
+@pytest.mark.parametrize("rig", ["distorted", "general"])
+def test_other_rigs_full_hd_vs_oracle(rig):
+    """The instantiations bench.py reports as side figures -- distorted projector (RIG 2: projector table) and general rig (RIG 0:
+    skewed camera matrix, tangential camera distortion) -- at 1920x1080, 3 views in one launch, timed mode and fused compaction,
+    against the oracle on every pixel."""
+    S, syn = _S(), pkg("synth")
+    W, H, N, fw, NV = 1920, 1080, 10, 2, 3
+    cal_d = syn.synth_rig(W, H, W, H)
+    cal_d["dp"] = np.array([-0.05, 0.02, 0.001, -0.0005, 0.0])
+    cal_d["dc"] = np.array(cal_d["dc"], dtype=np.float64) + np.array([0.0, 0.0, 0.0008, -0.0006, 0.0])
+    if rig == "general":
+        Kc = np.array(cal_d["Kc"], dtype=np.float64).reshape(3, 3).copy()
+        Kc[0, 1] = 0.35
+        cal_d["Kc"] = Kc.ravel()
+    cal = syn.cal_tuple(cal_d)
+    mask = syn.default_mask(W, H)
+    mask[300:340, 500:900] = 0
+    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV) as sc:
+        sc.set_calibration(*cal)
+        for v in range(NV):
+            sc.set_mask(mask, view=v)
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=2)
+        sc.run(0, NV)
+        dense = [sc.points(v) for v in range(NV)]
+        clouds = sc.fused_clouds(0, NV)
+        for v in range(NV):
+            assert np.array_equal(clouds[v], dense[v][0][dense[v][1] == 1]), v
+            o = Oracle(W, H, W, H, N, N, fw, fw)
+            o.set_mask(mask)
+            o.set_calibration(*cal)
+            oxyz, ovalid, _ = o.run_scan_rowmajor(sc.frames(0, v), sc.frames(1, v))
+            assert np.array_equal(dense[v][1], ovalid), v
+            assert int((ovalid == 1).sum()) > 1_500_000
+            assert_points_close(dense[v][0], oxyz, ovalid == 1)
