@@ -548,3 +548,30 @@ def test_other_rigs_full_hd_vs_oracle(rig):
             assert np.array_equal(dense[v][1], ovalid), v
             assert int((ovalid == 1).sum()) > 1_500_000
             assert_points_close(dense[v][0], oxyz, ovalid == 1)
+
+
+@pytest.mark.parametrize("nv,nh,fwv,fwh", [(10, 9, 2, 4), (9, 9, 4, 4), (12, 11, 1, 1)])
+def test_gray_depths_full_hd_vs_oracle(nv, nh, fwv, fwh):
+    """Gray depths other than the benchmark's 10/10 (the kernel is instantiated per max(N_v, N_h); unequal depths take the
+    shorter axis at run time) at 1920x1080, 2 views per launch, timed mode and fused compaction, every pixel against the oracle."""
+    S, syn = _S(), pkg("synth")
+    W, H, NV = 1920, 1080, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    mask = syn.default_mask(W, H)
+    with S.Scanner(W, H, W, H, nv, nh, fwv, fwh, max_views=NV) as sc:
+        sc.set_calibration(*cal)
+        for v in range(NV):
+            sc.set_mask(mask, view=v)
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=2)
+        sc.run(0, NV)
+        dense = [sc.points(v) for v in range(NV)]
+        clouds = sc.fused_clouds(0, NV)
+        for v in range(NV):
+            assert np.array_equal(clouds[v], dense[v][0][dense[v][1] == 1]), v
+            o = Oracle(W, H, W, H, nv, nh, fwv, fwh)
+            o.set_mask(mask)
+            o.set_calibration(*cal)
+            oxyz, ovalid, _ = o.run_scan_rowmajor(sc.frames(0, v), sc.frames(1, v))
+            assert np.array_equal(dense[v][1], ovalid), v
+            assert int((ovalid == 1).sum()) > 1_500_000
+            assert_points_close(dense[v][0], oxyz, ovalid == 1)
