@@ -575,3 +575,31 @@ def test_gray_depths_full_hd_vs_oracle(nv, nh, fwv, fwh):
             assert np.array_equal(dense[v][1], ovalid), v
             assert int((ovalid == 1).sum()) > 1_500_000
             assert_points_close(dense[v][0], oxyz, ovalid == 1)
+
+
+@pytest.mark.parametrize("F", [4, 5])
+def test_fringe_counts_full_hd_vs_oracle(F):
+    """4- and 5-step fringe sets (3/wrapped_phase.cpp:188-229; with 5 the reference's validity assignment is commented out,
+    :117-129: nothing is valid) at 1920x1080 in the timed mode, against the oracle on every pixel."""
+    S, syn = _S(), pkg("synth")
+    W, H, N, fw = 1920, 1080, 10, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
+    mask = syn.default_mask(W, H)
+    with S.Scanner(W, H, W, H, N, N, fw, fw, n_fringe=F) as sc:
+        sc.set_calibration(*cal)
+        sc.set_mask(mask)
+        sc.synth_view(0, plane=(0.0, 0.05, 0.05), view_id=0, noise=2)
+        sc.run()
+        xyz, valid = sc.points()
+        cl = sc.fused_clouds(0, 1)[0]
+        assert np.array_equal(cl, xyz[valid == 1])
+        if F == 5:
+            assert not valid.any() and len(cl) == 0
+            return
+        o = Oracle(W, H, W, H, N, N, fw, fw, F=F)
+        o.set_mask(mask)
+        o.set_calibration(*cal)
+        oxyz, ovalid, _ = o.run_scan_rowmajor(sc.frames(0), sc.frames(1))
+        assert np.array_equal(valid, ovalid)
+        assert int((ovalid == 1).sum()) > 1_500_000
+        assert_points_close(xyz, oxyz, ovalid == 1)
