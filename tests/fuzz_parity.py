@@ -19,9 +19,11 @@ def close(xyz, ref, v):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    # FUZZ_MAXW / FUZZ_MAXH: larger frames (thousands of 1024-pixel tiles per view: long look-back chains of the fused compaction)
+    MAXW, MAXH = int(os.environ.get("FUZZ_MAXW", 400)), int(os.environ.get("FUZZ_MAXH", 200))
     bad = 0
     for case in range(cases):
-        fullW, fullH = int(rng.integers(5, 400)), int(rng.integers(5, 200))
+        fullW, fullH = int(rng.integers(5, MAXW)), int(rng.integers(5, MAXH))
         if rng.random() < 0.5:
             W, H, col0, row0 = fullW, fullH, 0, 0
         else:  # a window: column origin multiple of 4 (one lane = 4 pixels), any row origin
