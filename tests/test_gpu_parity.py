@@ -688,7 +688,7 @@ def test_randomised_configurations():
     """tests/fuzz_parity.py: 120 random combinations of frame / window / projector sizes, Gray depths, fringe widths and
     counts, masks (including bytes other than 0/1), noise and rigs, timed and parity mode against the oracle
     (1200 cases over three other seeds were run clean when this was written; in round 2, with the fused compaction, the
-    row-stripe groups on both transports and multi-view batches added to every case, 4750 more over six seeds, and 120 with frames up to 2600x1500 -- FUZZ_MAXW / FUZZ_MAXH)."""
+    row-stripe groups on both transports and multi-view batches added to every case, 4750 more over six seeds, and 370 with frames up to 4200x2200 -- FUZZ_MAXW / FUZZ_MAXH)."""
     import importlib.util
     import os
     import sys
