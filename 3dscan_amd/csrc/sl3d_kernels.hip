@@ -1564,6 +1564,7 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
                  unsigned *tickets_drawn)
 {
     KParams P = P_;
+    unsigned drawn = 0;
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
     const int vpt = views_per_lane(bx, n_views);
@@ -1581,7 +1582,8 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
         const unsigned n_items = (unsigned)P.n_tiles * grid.y, slots = (unsigned)(P.n_cus > 0 ? P.n_cus : 256) * SL3D_OCC_COMPACT;
         grid = dim3(SL3D_PERSIST == 2 && slots < n_items ? slots : n_items, 1, 1);
         P.ticket_base = *tickets_drawn;
-        *tickets_drawn += SL3D_PERSIST == 2 ? n_items + grid.x : SL3D_PERSIST == 1 ? n_items : 0u;
+        drawn = SL3D_PERSIST == 2 ? n_items + grid.x : SL3D_PERSIST == 1 ? n_items : 0u;
+        *tickets_drawn += drawn;
     }
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's
@@ -1595,7 +1597,9 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
         if (compact) launch_fused_rig<false, true>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
         else launch_fused_rig<false, false>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
-    return (int)hipGetLastError();
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && tickets_drawn) *tickets_drawn -= drawn;  // a launch that did not happen drew no tickets
+    return (int)e;
 }
 
 // ------------------------------------------------------------------------------------------------
