@@ -192,6 +192,23 @@ def steady_rate(sc, n_views, px_per_launch, alg_bytes_px, launches, precondition
     return round(px_per_launch / ms / 1e3, 1), round(alg_bytes_px * px_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(ms, 4)
 
 
+def device_copy_rate(torch, dev, nbytes=1 << 30, reps=20):
+    """What a plain device-to-device copy reaches on this box (the roofline also against a measured copy bandwidth):
+    read + written bytes / time of `reps` copies of 1 GiB, torch events on the current stream."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    src.fill_(7)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def side_figures(args, scm, syn, np, dev_index):
     """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
@@ -397,6 +414,12 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_side:
         out["side"] = side_figures(args, scm, syn, np, dev_index)
+        try:   # the same roofline against what a device copy reaches on this very box, right now (never `frac`)
+            copy = device_copy_rate(torch, dev)
+            out["roofline"]["device_copy"] = {"GBps": round(copy, 1), "frac_of_it": round(achieved / copy, 4),
+                                              "how": "torch copy_ of 1 GiB device to device, (read + written bytes) / time, 20 copies"}
+        except Exception as e:
+            out["roofline"]["device_copy"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sc.run(0, n_views)
