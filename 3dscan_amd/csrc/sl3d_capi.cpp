@@ -816,11 +816,11 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
         if (rc) return rc;
     }
     P.n_tiles = fused_tiles(P);
-    rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles);
+    rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE);
     if (!rc) rc = dev_alloc(x, &x->d_ticket, (size_t)1);
     if (!rc) rc = dev_alloc(x, &x->d_lookback_err, (size_t)16);  // [0] = error flag; measurement builds keep counters behind it
     if (rc) return rc;
-    HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, mv * (size_t)P.n_tiles * sizeof(unsigned long long), x->stream));
+    HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE * sizeof(unsigned long long), x->stream));
     HIPCHK(x, hipMemsetAsync(x->d_lookback_err, 0, 16 * sizeof(int), x->stream));
     HIPCHK(x, hipMemsetAsync(x->d_ticket, 0, sizeof(unsigned), x->stream));
     x->tickets_drawn = 0;
@@ -859,7 +859,7 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
     if (++x->P.epoch >= (1u << 30)) {  // the generation tag is 30 bits: start over with cleared words
-        HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * sizeof(unsigned long long), x->stream));
+        HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * SL3D_ST_STRIDE * sizeof(unsigned long long), x->stream));
         x->P.epoch = 1;
     }
     return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, true, x->stream, &x->tickets_drawn));

@@ -80,7 +80,7 @@ struct KParams {
     size_t px_view_stride;     // pitch * H   (elements per view of every per-pixel plane)
     // compacted clouds written by the fused kernel itself (sl3d_run_clouds; NULL until first used)
     float *clouds;             // [view][px_view_stride][3]: the valid points of a view in row-major scan order
-    unsigned long long *tile_status;   // [view][n_tiles] decoupled look-back words: epoch << 34 | flag << 32 | count
+    unsigned long long *tile_status;   // [view][n_tiles][SL3D_ST_STRIDE] decoupled look-back words (the first of each group): epoch << 34 | flag << 32 | count
     unsigned long long *cloud_totals;  // [view] number of valid points -- HOST memory mapped into the device: the last tile of a view stores
                                        // the count where sl3d_get_cloud_counts reads it after the stream has drained (no copy)
     int *lookback_flag;        // host-mapped too: set if a look-back gave up waiting (never expected; reported by sl3d_get_cloud_counts)
@@ -106,6 +106,13 @@ struct KParams {
 // tickets_drawn (compact only): host mirror of *KParams::ticket, advanced by what this launch will draw
 int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream,
                  unsigned *tickets_drawn = nullptr);
+// 8-byte words between the look-back status words of two neighbouring tiles.  8 = every word in a 64-byte line of its own:
+// neighbouring tiles publish from different XCDs at about the same time, and with the words packed those write-through
+// 8-byte stores (and the polls of them) contend for one line -- measured on the 16 x 1080p batch, three alternating runs:
+// packed 71.0-71.3 Gpx/s kernel-only, 64-byte stride 72.6-73.3, 128-byte 72.6-73.0
+#ifndef SL3D_ST_STRIDE
+#define SL3D_ST_STRIDE 8
+#endif
 int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)
 int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream);  // raw: staged bytes in the layout of one mask plane
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);

@@ -635,7 +635,7 @@ __device__ __forceinline__ LbWords lookback_poll(const unsigned long long *row, 
     for (int k = 0; k < SL3D_LB_WORDS; k++) {
         const int idx = tile - 1 - SL3D_LB_LANES * k - lane;
         r.w[k] = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
-        if (idx >= 0 && lane < SL3D_LB_LANES) r.w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (idx >= 0 && lane < SL3D_LB_LANES) r.w[k] = __hip_atomic_load(row + (size_t)idx * SL3D_ST_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return r;
 }
@@ -674,7 +674,7 @@ __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row,
             // tiles before the first one: an inclusive prefix of 0; lanes beyond the polling window: an empty aggregate
             w[k] = lane < SL3D_LB_LANES ? status_word(epoch, SL3D_ST_PREFIX, 0u) : status_word(epoch, SL3D_ST_AGG, 0u);
             if (have_first) w[k] = first.w[k];
-            else if (idx >= 0 && lane < SL3D_LB_LANES) w[k] = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (idx >= 0 && lane < SL3D_LB_LANES) w[k] = __hip_atomic_load(row + (size_t)idx * SL3D_ST_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         have_first = false;
         // nearest first = word 0 of lanes 0..L-1, then word 1 of lanes 0..L-1, ...: walk the words until one holds a prefix
@@ -1308,11 +1308,11 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     // the first look-back window of the held view is REQUESTED right behind a batch of plane loads and CONSUMED (flush_held)
     // right behind the decode that waits for those planes anyway: its round trip costs nothing unless it has to be repeated
     auto poll_held = [&]() {
-        if (wave == 0 && !(SL3D_CX & 1)) lb_first = lookback_poll(P.tile_status + (size_t)hview * (size_t)P.n_tiles, (int)htile, P.epoch);
+        if (wave == 0 && !(SL3D_CX & 1)) lb_first = lookback_poll(P.tile_status + (size_t)hview * (size_t)P.n_tiles * SL3D_ST_STRIDE, (int)htile, P.epoch);
         poll_pending = true;
     };
     auto flush_held = [&]() {
-        unsigned long long *row_st = P.tile_status + (size_t)hview * (size_t)P.n_tiles;
+        unsigned long long *row_st = P.tile_status + (size_t)hview * (size_t)P.n_tiles * SL3D_ST_STRIDE;
         if (wave == 0) {
 #if SL3D_CX & 128
             if (lane == 0) P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 1] = wall_clock64();
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                 P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF814 /* HW_REG_XCC_ID */) | ((unsigned long long)base << 32);
 #endif
                 s_base = base;
-                if (htile != 0u) status_publish(row_st + htile, status_word(P.epoch, SL3D_ST_PREFIX, base + htotal));
+                if (htile != 0u) status_publish(row_st + (size_t)htile * SL3D_ST_STRIDE, status_word(P.epoch, SL3D_ST_PREFIX, base + htotal));
                 if ((int)htile == P.n_tiles - 1) P.cloud_totals[hview] = (unsigned long long)(base + htotal);
             }
         }
@@ -1486,7 +1486,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
         if (threadIdx.x == 0) P.dbg[((size_t)view * P.n_tiles + tile) * 4 + 0] = wall_clock64();
 #endif
         if (threadIdx.x == 0)
-            status_publish(P.tile_status + (size_t)view * (size_t)P.n_tiles + tile, status_word(P.epoch, tile == 0u ? SL3D_ST_PREFIX : SL3D_ST_AGG, ftotal));
+            status_publish(P.tile_status + ((size_t)view * (size_t)P.n_tiles + tile) * SL3D_ST_STRIDE, status_word(P.epoch, tile == 0u ? SL3D_ST_PREFIX : SL3D_ST_AGG, ftotal));
     }
     if (!COMPACT || SL3D_PERSIST != 2) break;
     item_parity ^= 1u;
