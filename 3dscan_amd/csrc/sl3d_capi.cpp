@@ -374,6 +374,15 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     return SL3D_OK;
 }
 
+extern "C" int sl3d_get_projection_matrices(sl3d_ctx *x, double A_cam[12], double A_proj[12])
+{
+    if (!x || !A_cam || !A_proj) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
+    memcpy(A_cam, x->C.Ac, sizeof x->C.Ac);
+    memcpy(A_proj, x->C.Ap, sizeof x->C.Ap);
+    return SL3D_OK;
+}
+
 static int launched(sl3d_ctx *x, int hip_err);
 
 static int check_view(sl3d_ctx *x, int view, int n = 1)

@@ -20,7 +20,7 @@ VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
 # every symbol include/sl3d.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
-    "sl3d_set_calibration", "sl3d_set_mask", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
+    "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
     "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
@@ -78,6 +78,7 @@ def load_library(path=None):
     L.sl3d_destroy.argtypes = [vp]
     L.sl3d_destroy.restype = None
     L.sl3d_set_calibration.argtypes = [vp] + [vp] * 8
+    L.sl3d_get_projection_matrices.argtypes = [vp, vp, vp]
     L.sl3d_set_mask.argtypes = [vp, i, vp, C.c_size_t]
     L.sl3d_set_frames.argtypes = [vp, i, i, vp, i, C.c_size_t]
     for n in ("sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_copy_view"):
@@ -199,6 +200,12 @@ class Scanner:
         a = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel()) for v in (Kc, dc, rc, tc, Kp, dp, rp, tp)]
         assert [v.size for v in a] == [9, 5, 3, 3, 9, 5, 3, 3]
         self._chk(self.L.sl3d_set_calibration(self._h, *[v.ctypes.data for v in a]), "sl3d_set_calibration")
+
+    def projection_matrices(self):
+        """(A_cam, A_proj): the 3x4 matrices K [R|t] the library derived from the calibration (T0, compute_A)."""
+        a, b = np.zeros(12), np.zeros(12)
+        self._chk(self.L.sl3d_get_projection_matrices(self._h, a.ctypes.data, b.ctypes.data), "sl3d_get_projection_matrices")
+        return a.reshape(3, 4), b.reshape(3, 4)
 
     def set_mask(self, full_frame_mask, view=0):
         m = np.ascontiguousarray(full_frame_mask, dtype=np.uint8)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL3D_VERSION_STRING "0.2.0"
+#define SL3D_VERSION_STRING "0.3.0"
 
 typedef struct sl3d_ctx sl3d_ctx;
 
@@ -127,6 +127,12 @@ void sl3d_destroy(sl3d_ctx *ctx);
 int sl3d_set_calibration(sl3d_ctx *ctx,
                          const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
                          const double Kp[9], const double dp[5], const double rp[3], const double tp[3]);
+
+/* T0 as the library computed it from the last sl3d_set_calibration: the two 3x4 projection matrices A = K*[R|t] of compute_A()
+ * (7/triangulation.cpp:1061-1126: cvRodrigues2 :1072,1080, [R|t] :1090-1099,1105-1114, cvMatMul :1101,1116), row-major doubles.
+ * Host only.  With K = I the left 3x3 block is cvRodrigues2's matrix itself -- which is how tests/ compare the product's T0 with
+ * the reference-held OpenCV answer (the two XML files under Triangulation/Relative_geometry, written by 6/system_calibration.cpp:1488-1516). */
+int sl3d_get_projection_matrices(sl3d_ctx *ctx, double A_cam[12], double A_proj[12]);
 
 /* selected_region of image_scissor() m_tech_project_console.cpp:146-238, handed over as a
  * FULL-FRAME row-major u8 plane (full_width x full_height); a pixel is selected iff byte == 1

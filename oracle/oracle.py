@@ -55,6 +55,7 @@ def _load():
         L.orc_get_debug_image.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orc_get_projection_matrices.argtypes = [vp, vp, vp]
         L.orc_get_undist_point.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_relative_geometry.argtypes = [vp] * 6
         L.orc_run_scan.argtypes = [vp, vp, vp, C.c_size_t]
         L.orc_run_scan_rowmajor.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, vp]
         L.orc_undistort.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t]
@@ -203,6 +204,16 @@ class Oracle:
         out = np.empty((n, 3), dtype=np.float32)
         L.orc_save_point_cloud(self._s, out.ctypes.data, n)
         return out
+
+
+def relative_geometry(rc, tc, rp, tp):
+    """Rc * Rp^T (3x3) and tc - (Rc * Rp^T) * tp (3,) through the oracle's cvRodrigues2 / cvTranspose / cvGEMM restatements, in
+    the order 6/system_calibration.cpp:1488-1503 applies them (the reference saved OpenCV's own answer: the T0 known answer)."""
+    a = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel()) for x in (rc, tc, rp, tp)]
+    assert all(x.size == 3 for x in a)
+    R, t = np.zeros(9), np.zeros(3)
+    _load().orc_relative_geometry(*[x.ctypes.data for x in a], R.ctypes.data, t.ctypes.data)
+    return R.reshape(3, 3), t
 
 
 def pattern_counts(proj_extent, fringe_width):

@@ -10,11 +10,17 @@
  *   stage 3 (wrapped phase)  : PINNED  by the reference's own known-answer image
  *                              M_tech_project_console/Wrapped_phase_images/{Vertical,Horizontal}/Wrapped_phase_image.bmp
  *   stage 4 (decode + unwrap): PINNED  by Unwrapped_phase_images/Gray_coded/{Vertical,Horizontal}/Unwrapped_phase_*.bmp
- *   stage 5, 7, 8            : PARITY UNPINNED -- the artefacts that would pin them
+ *   stage 7, T0 (cvRodrigues2, cvTranspose, cvGEMM: rodrigues(), mat_mul(), hence compute_A()'s A = K[R|t])
+ *                            : PINNED  by reference-held OpenCV 2.4 output: the 12 doubles of
+ *                              Triangulation/Relative_geometry/proj_cam_rot_mat.xml + proj_cam_trans_vect.xml, which the
+ *                              reference's stage 6 computed with those very routines from the rotation / translation
+ *                              vectors stage 7 reads (6/system_calibration.cpp:1488-1516); orc_relative_geometry()
+ *                              reproduces them BIT FOR BIT (make_golden.py refuses to write goldens otherwise).
+ *   stage 5 (C2), stage 7 T1 (cvUndistortPoints) and T3 (cvInvert), stage 8 (O1)
+ *                            : PARITY UNPINNED -- the artefacts that would pin them
  *                              (c_p_map.xml, depth_map.xml, point_cloud_0.ply) are missing
  *                              blobs of the reference tree and the reference has no tests.
- *                              The five OpenCV 2.4.0 routines stage 7 calls (cvUndistortPoints,
- *                              cvRodrigues2, cvGEMM, cvInvert, cvTranspose) are NOT in the
+ *                              The OpenCV 2.4.0 routines stage 7 calls are NOT in the
  *                              reference tree (un-vendored dependency, opencv 2.4.0 per
  *                              M_tech_project_console.cbp:55-58); they are restated here from
  *                              their published algorithms.
@@ -642,6 +648,25 @@ void orc_get_projection_matrices(orc_state *s, double *A_cam, double *A_proj)
     orc_prepare_triangulation(s);
     memcpy(A_cam, s->A_cam, sizeof s->A_cam);
     memcpy(A_proj, s->A_proj, sizeof s->A_proj);
+}
+
+/* T0 known answer.  The reference's stage 6 runs the SAME OpenCV routines stage 7's T0 uses, on the SAME two rotation
+   vectors stage 7 reads (7/triangulation.cpp:1069-1083), and saved the result -- real OpenCV 2.4 output -- in the tree:
+   6/system_calibration.cpp:1488-1489 cvRodrigues2 of both vectors, :1493 cvTranspose (in place), :1494 cvMatMul
+   -> Triangulation/Relative_geometry/proj_cam_rot_mat.xml (Rc * Rp^T); :1502 cvMatMul, :1503 cvSub
+   -> proj_cam_trans_vect.xml (tc - (Rc * Rp^T) * tp).  Evaluated here through the very rodrigues() / mat_mul() that
+   compute_A() uses; tests/golden/make_golden.py requires all 12 doubles to equal the two files bit for bit, which pins
+   the restatements of cvRodrigues2, cvTranspose and cvGEMM on reference-held data. */
+void orc_relative_geometry(const double *rc, const double *tc, const double *rp, const double *tp, double *R_out /*9*/, double *t_out /*3*/)
+{
+    double Rc[9], Rp[9], RpT[9], Rt[3];
+    rodrigues(rc, Rc);                        /* :1488 */
+    rodrigues(rp, Rp);                        /* :1489 */
+    for (int i = 0; i < 3; i++)               /* :1493 cvTranspose(proj_world_rot_mat, proj_world_rot_mat) */
+        for (int j = 0; j < 3; j++) RpT[i * 3 + j] = Rp[j * 3 + i];
+    mat_mul(Rc, RpT, R_out, 3, 3, 3);         /* :1494 */
+    mat_mul(R_out, tp, Rt, 3, 3, 1);          /* :1502 */
+    for (int i = 0; i < 3; i++) t_out[i] = tc[i] - Rt[i]; /* :1503 cvSub */
 }
 
 /* undistorted pixel coordinates of one camera (dev=0) / projector (dev=1) pixel: (u,v) of T1 */

@@ -10,6 +10,9 @@ What it does
     known-answer images the reference wrote (Wrapped_phase_image.bmp, Unwrapped_phase_*.bmp).
  2. PINS THE ORACLE: replays oracle stages 3 and 4 on the full frames and requires the debug
     images to equal the reference's KAT images on every pixel (358,580 valid px per axis).
+ 2b. PINS T0: the oracle's cvRodrigues2 / cvTranspose / cvGEMM restatements must reproduce, bit for bit, the 12 doubles of
+    Triangulation/Relative_geometry/proj_cam_rot_mat.xml + proj_cam_trans_vect.xml that the reference's stage 6 computed with
+    OpenCV itself from the rotation / translation vectors stage 7 reads (6/system_calibration.cpp:1488-1516).
  3. Runs oracle stages 5 and 7 on the full frames with the reference's 8 calibration XMLs
     (unpinned stages: these outputs are regression goldens, not reference answers) and CORROBORATES them with an
     independent fp64 NumPy restatement of the same stages (independent_stage_5_7: no code shared with oracle/):
@@ -214,6 +217,21 @@ def main():
     cal["_source"] = "values of the 8 calibration XMLs read by 7/triangulation.cpp:152-168,1069-1083"
     cal["_dims"] = {"W": W, "H": H, "PW": PW, "PH": PH, "N_v": N_V, "N_h": N_H, "fw_v": FW, "fw_h": FW,
                     "ncodes_v": NCODES_V, "ncodes_h": NCODES_H}
+    # PINS T0 (cvRodrigues2, cvTranspose, cvGEMM): stage 6 ran the same OpenCV routines on the same two rotation vectors
+    # stage 7 reads and saved the result (6/system_calibration.cpp:1488-1516): Rc*Rp^T and tc - (Rc*Rp^T)*tp.  The oracle's
+    # restatements must reproduce all 12 doubles of the two files BIT FOR BIT before any golden is written.
+    from oracle import oracle as O
+    kat_R = np.array(xml_data("Triangulation/Relative_geometry/proj_cam_rot_mat.xml"))
+    kat_t = np.array(xml_data("Triangulation/Relative_geometry/proj_cam_trans_vect.xml"))
+    got_R, got_t = O.relative_geometry(cal["rc"], cal["tc"], cal["rp"], cal["tp"])
+    same = int((got_R.ravel().view(np.uint64) == kat_R.view(np.uint64)).sum() + (got_t.view(np.uint64) == kat_t.view(np.uint64)).sum())
+    print(f"T0 known answer (Relative_geometry/*.xml, OpenCV 2.4's own output): {same} of 12 doubles bit-identical")
+    assert same == 12, "oracle rodrigues / transpose / mat_mul do not reproduce the reference's saved relative geometry"
+    cal["_relative_geometry"] = {
+        "proj_cam_rot_mat": [float(x) for x in kat_R], "proj_cam_trans_vect": [float(x) for x in kat_t],
+        "_source": "Triangulation/Relative_geometry/proj_cam_rot_mat.xml + proj_cam_trans_vect.xml, written by "
+                   "6/system_calibration.cpp:1488-1516 (cvRodrigues2 x2, cvTranspose, cvMatMul x2, cvSub) from the same rc/rp/tc/tp "
+                   "7/triangulation.cpp:1069-1083 reads: the reference-held known answer for T0"}
     with open(os.path.join(HERE, "calibration.json"), "w") as f:
         json.dump(cal, f, indent=1)
 

@@ -31,6 +31,14 @@ def test_version_and_strerror(scanner_mod):
     assert b"no CPU fallback" in L.sl3d_strerror(-2)
 
 
+def test_versions_agree(scanner_mod):
+    """One version: SL3D_VERSION_STRING of include/sl3d.h == sl3d_version() of the library == the package's __version__."""
+    txt = open(os.path.join(ROOT, "include", "sl3d.h")).read()
+    hdr = re.search(r'#define\s+SL3D_VERSION_STRING\s+"([^"]+)"', txt).group(1)
+    assert scanner_mod.load_library().sl3d_version().decode().split()[0] == hdr
+    assert pkg().__version__ == hdr
+
+
 def test_create_rejects_bad_config(scanner_mod):
     L = scanner_mod.load_library()
     h = ctypes.c_void_p()

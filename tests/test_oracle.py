@@ -304,6 +304,57 @@ def test_undistort_restatement_sanity():
     assert far[H // 2, W // 2] == 200
 
 
+def golden_relative_geometry():
+    import json, os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "calibration.json")) as f:
+        c = json.load(f)
+    g = c["_relative_geometry"]
+    return np.array(g["proj_cam_rot_mat"], dtype=np.float64).reshape(3, 3), np.array(g["proj_cam_trans_vect"], dtype=np.float64)
+
+
+def test_T0_kat():
+    """T0 is pinned by reference-held OpenCV 2.4 output: stage 6 ran cvRodrigues2 on the two rotation vectors stage 7 reads, then
+    cvTranspose, cvMatMul, cvMatMul, cvSub, and saved Rc*Rp^T and tc - (Rc*Rp^T)*tp (6/system_calibration.cpp:1488-1516 ->
+    Triangulation/Relative_geometry/proj_cam_rot_mat.xml, proj_cam_trans_vect.xml).  The oracle's restatements of those
+    routines -- the same ones compute_A() uses for A = K[R|t] (7/triangulation.cpp:1069-1116) -- reproduce all 12 doubles BIT FOR BIT."""
+    from oracle import oracle as O
+    ct, _ = golden_calibration()
+    cal = dict(zip(("Kc", "dc", "rc", "tc", "Kp", "dp", "rp", "tp"), ct))
+    kat_R, kat_t = golden_relative_geometry()
+    R, t = O.relative_geometry(cal["rc"], cal["tc"], cal["rp"], cal["tp"])
+    assert np.array_equal(R.view(np.uint64), kat_R.view(np.uint64)), "Rc * Rp^T differs from the reference's proj_cam_rot_mat.xml"
+    assert np.array_equal(t.view(np.uint64), kat_t.view(np.uint64)), "tc - (Rc Rp^T) tp differs from the reference's proj_cam_trans_vect.xml"
+    # the rotation blocks the KAT pins are the ones inside the oracle's projection matrices: with K = I, A = [R|t]
+    o = Oracle(16, 16, 1280, 720, 6, 5, 32, 32)
+    I3, z5 = np.eye(3).ravel(), np.zeros(5)
+    o.set_calibration(I3, z5, cal["rc"], cal["tc"], I3, z5, cal["rp"], cal["tp"])
+    A_cam, A_proj = (np.array(a).reshape(3, 4) for a in o.projection_matrices())
+    assert np.array_equal(A_cam[:, 3], cal["tc"]) and np.array_equal(A_proj[:, 3], cal["tp"])
+    assert np.array_equal(relative_from_projection(A_cam, A_proj)[0].view(np.uint64), kat_R.view(np.uint64))
+    assert np.array_equal(relative_from_projection(A_cam, A_proj)[1].view(np.uint64), kat_t.view(np.uint64))
+
+
+def relative_from_projection(A_cam, A_proj):
+    """Rc * Rp^T and tc - (Rc Rp^T) tp from two [R|t] matrices with cvGEMM's summation order (double accumulator from 0, k
+    ascending), so that bit-identical rotation blocks give the bit-identical known answer."""
+    Rc, Rp, tc, tp = A_cam[:, :3], A_proj[:, :3], A_cam[:, 3], A_proj[:, 3]
+    R = np.zeros((3, 3))
+    for i in range(3):
+        for j in range(3):
+            acc = 0.0
+            for k in range(3):
+                acc += float(Rc[i, k]) * float(Rp[j, k])
+            R[i, j] = acc
+    t = np.zeros(3)
+    for i in range(3):
+        acc = 0.0
+        for k in range(3):
+            acc += float(R[i, k]) * float(tp[k])
+        t[i] = float(tc[i]) - acc
+    return R, t
+
+
 def test_restated_opencv_routines_against_independent_implementations():
     """Stage 7 calls OpenCV routines that are not in the reference tree; the oracle restates them.  Independent checks:
     cvRodrigues2 + cvGEMM (T0: A = K [R|t]) against scipy's rotation-vector conversion, cvUndistortPoints against the
