@@ -812,22 +812,22 @@ extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const
 // ---- compacted clouds straight from the fused kernel ----------------------------------------------------------------
 static int ensure_cloud_buffers(sl3d_ctx *x)
 {
-    if (x->d_clouds && x->d_tile_status) return SL3D_OK;
+    // one flag, set at the very end: a set-up that failed half way (out of memory on a later buffer) is retried by the next
+    // call instead of being mistaken for a finished one (every step below skips what an earlier attempt already allocated)
+    if (x->clouds_ready) return SL3D_OK;
     KParams &P = x->P;
     const size_t mv = (size_t)x->cfg.max_views;
     int rc = SL3D_OK;
-    if (!x->d_clouds) {
-        const size_t nb = (P.px_view_stride + 1023) / 1024;
-        rc = dev_alloc(x, &x->d_clouds, mv * P.px_view_stride * 3);
-        if (!rc) rc = dev_alloc(x, &x->d_blk_cnt_all, mv * nb);
-        if (!rc) rc = dev_alloc(x, &x->d_blk_off_all, mv * nb);
-        if (!rc) rc = dev_alloc(x, &x->d_totals, mv);
-        if (rc) return rc;
-    }
+    const size_t nb = (P.px_view_stride + 1023) / 1024;
+    if (!x->d_clouds) rc = dev_alloc(x, &x->d_clouds, mv * P.px_view_stride * 3);
+    if (!rc && !x->d_blk_cnt_all) rc = dev_alloc(x, &x->d_blk_cnt_all, mv * nb);
+    if (!rc && !x->d_blk_off_all) rc = dev_alloc(x, &x->d_blk_off_all, mv * nb);
+    if (!rc && !x->d_totals) rc = dev_alloc(x, &x->d_totals, mv);
+    if (rc) return rc;
     P.n_tiles = fused_tiles(P);
-    rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE);
-    if (!rc) rc = dev_alloc(x, &x->d_ticket, (size_t)1);
-    if (!rc) rc = dev_alloc(x, &x->d_lookback_err, (size_t)16);  // [0] = error flag; measurement builds keep counters behind it
+    if (!x->d_tile_status) rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE);
+    if (!rc && !x->d_ticket) rc = dev_alloc(x, &x->d_ticket, (size_t)1);
+    if (!rc && !x->d_lookback_err) rc = dev_alloc(x, &x->d_lookback_err, (size_t)16);  // [0] = error flag; measurement builds keep counters behind it
     if (rc) return rc;
     HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE * sizeof(unsigned long long), x->stream));
     HIPCHK(x, hipMemsetAsync(x->d_lookback_err, 0, 16 * sizeof(int), x->stream));
@@ -848,11 +848,12 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
     P.lookback_flag = (int *)((unsigned long long *)mapped + mv);
     P.lookback_err = x->d_lookback_err;
 #ifdef SL3D_MEASURE
-    rc = dev_alloc(x, &x->P.dbg, mv * (size_t)P.n_tiles * 4);
+    if (!x->P.dbg) rc = dev_alloc(x, &x->P.dbg, mv * (size_t)P.n_tiles * 4);
     if (rc) return rc;
     HIPCHK(x, hipMemsetAsync(x->P.dbg, 0, mv * (size_t)P.n_tiles * 4 * sizeof(unsigned long long), x->stream));
 #endif
     P.epoch = 0;
+    x->clouds_ready = true;
     return SL3D_OK;
 }
 
@@ -880,7 +881,7 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
-    if (!x->d_tile_status) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
+    if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
     ON_DEVICE(x);
     // the kernel stored the counts (and, never expected, the error flag) into pinned host memory itself: wait for it, read them
     HIPCHK(x, hipStreamSynchronize(x->stream));

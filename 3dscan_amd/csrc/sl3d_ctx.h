@@ -46,6 +46,7 @@ struct sl3d_ctx {
     unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
     unsigned long long *d_tile_status = nullptr;  // sl3d_run_clouds: look-back words [view][tile] of the fused compaction
     int *d_lookback_err = nullptr;
+    bool clouds_ready = false;                // ensure_cloud_buffers ran to its end: every pointer sl3d_run_clouds needs is set
     unsigned *d_ticket = nullptr;             // work-item counter of the persistent compacting kernel
     unsigned long long *h_counts = nullptr;   // pinned: the per-view counts (+ error flag) sl3d_get_cloud_counts reads back
     unsigned tickets_drawn = 0;               // its value once every enqueued launch has run

@@ -309,8 +309,13 @@ static int group_launch(sl3d_group *g, int first, int n, RunFn run)
     for (size_t s = 0; s < g->st.size(); s++) {
         Stripe &S = g->st[s];
         DeviceGuard dg(S.device);
-        // results the communication streams may still be reading are not overwritten
-        if (overlaps(g, first, n)) GHIP(g, hipStreamWaitEvent(S.ctx->stream, g->gpus[(size_t)S.gpu].ev_comm, 0));
+        // results the communication streams may still be reading are not overwritten.  Who reads a stripe depends on the
+        // transport: an RCCL send sits on the communication stream of the stripe's OWN GPU, a (peer) device copy on the
+        // ROOT's (group_exchange) -- the stripe waits for both, so the rule cannot go stale when a transport is added
+        if (overlaps(g, first, n)) {
+            GHIP(g, hipStreamWaitEvent(S.ctx->stream, g->gpus[(size_t)S.gpu].ev_comm, 0));
+            if (S.gpu != 0) GHIP(g, hipStreamWaitEvent(S.ctx->stream, g->gpus[0].ev_comm, 0));
+        }
         GCTX(g, s, run(S.ctx));
         GHIP(g, hipEventRecord(S.ev_run, S.ctx->stream));
     }

@@ -572,6 +572,8 @@ __device__ __forceinline__ unsigned ldg32(const GLOBAL_AS uint8_t *base, unsigne
 // ------------------------------------------------------------------------------------------------
 #define SL3D_ST_AGG 1ull
 #define SL3D_ST_PREFIX 2ull
+#define SL3D_ST_FAILED 3ull /* a look-back gave up (time-out): published INSTEAD of a prefix, and contagious -- whoever sees it gives up
+                               at once and passes it on, so a failed launch ends quickly and never hands out a made-up prefix */
 #define SL3D_LOOKBACK_SPINS (1 << 22) /* polls before a look-back gives up and raises KParams::lookback_err (seconds) */
 
 __device__ __forceinline__ unsigned long long status_word(unsigned epoch, unsigned long long flag, unsigned count)
@@ -641,9 +643,12 @@ __device__ __forceinline__ LbWords lookback_poll(const unsigned long long *row, 
 }
 
 // have_first: `first` holds the words lookback_poll fetched for the first window (no load for that round)
+// failed: the look-back timed out or met a SL3D_ST_FAILED word; the return value is then meaningless (the launch is void and
+// reported through KParams::lookback_flag) and the caller publishes SL3D_ST_FAILED instead of a prefix
 __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row, int tile, unsigned epoch, int *err, bool have_first,
-                                                  const LbWords &first SL3D_LB_STATS_ARG)
+                                                  const LbWords &first, bool &failed SL3D_LB_STATS_ARG)
 {
+    failed = false;
     const int lane = (int)(threadIdx.x & 63u);
     unsigned sum = 0;
     int hi = tile - 1;  // nearest predecessor of the current window
@@ -686,6 +691,11 @@ __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row,
                 const unsigned flag = (unsigned)(w[k] >> 32) & 3u;
                 const bool ready = (unsigned)(w[k] >> 34) == epoch && flag != 0u;
                 const unsigned long long R = __ballot(ready), Pm = __ballot(ready && flag == (unsigned)SL3D_ST_PREFIX);
+                if (__ballot(ready && flag == (unsigned)SL3D_ST_FAILED) != 0ull) {  // a predecessor gave up: so does this tile
+                    failed = true;
+                    if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return stats(0u);
+                }
                 if (Pm != 0ull) {
                     const int p = __ffsll((long long)Pm) - 1;  // the lane that holds the nearest known inclusive prefix
                     const unsigned long long need = p == 63 ? ~0ull : ((1ull << (p + 1)) - 1ull);
@@ -705,6 +715,7 @@ __device__ __forceinline__ unsigned tile_lookback(const unsigned long long *row,
         }
         if (++spins > SL3D_LOOKBACK_SPINS) {  // never expected: report instead of hanging the GPU
             if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-mapped flag)
+            failed = true;
             return sum;
         }
         __builtin_amdgcn_s_sleep(SL3D_LB_SLEEP);
@@ -886,7 +897,11 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
     static_assert(!(KEEP && COMPACT), "the parity mode writes dense planes");
     static_assert(!COMPACT || SL3D_BLOCK != 256 || !SL3D_XCD_BANDS, "the look-back chains 1024-pixel tiles in ticket order");  // (other block sizes: A/B builds of the dense kernel only)
     __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];
-    __shared__ unsigned s_wtot[4], s_base;  // COMPACT: valid pixels per wave of the current view; exclusive prefix of the tile
+    // COMPACT: valid pixels per wave of the current view, double-buffered by the parity of the block's view counter (a wave that
+    // runs ahead into the next view writes the OTHER half; it cannot reach the view after that before every wave has passed the
+    // next view's barrier, i.e. has read this half); exclusive prefix of the tile being flushed
+    __shared__ unsigned s_wtot[2][4], s_base;
+    unsigned wt_par = 0;
     // COMPACT with SL3D_SLACK >= 2: SL3D_SLACK - 1 more staging areas, for the views that wait between the pixel loop and the registers
     constexpr int NMID = COMPACT ? SL3D_SLACK - 1 : 0;
     __shared__ __attribute__((aligned(16))) float s_mid[NMID > 0 ? NMID * SL3D_BLOCK * 12 : 4];
@@ -1317,16 +1332,18 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
 #if SL3D_CX & 128
             if (lane == 0) P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 1] = wall_clock64();
 #endif
+            bool lb_failed = false;
             const unsigned base = ((SL3D_CX & 1) || ((SL3D_CX & 512) && draining))
                                       ? htile * 1024u
-                                      : tile_lookback(row_st, (int)htile, P.epoch, P.lookback_flag, poll_pending, lb_first SL3D_LB_STATS_PASS);
+                                      : tile_lookback(row_st, (int)htile, P.epoch, P.lookback_flag, poll_pending, lb_first, lb_failed SL3D_LB_STATS_PASS);
             if (lane == 0) {
 #if SL3D_CX & 128
                 P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 2] = wall_clock64();
                 P.dbg[((size_t)hview * P.n_tiles + htile) * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF814 /* HW_REG_XCC_ID */) | ((unsigned long long)base << 32);
 #endif
                 s_base = base;
-                if (htile != 0u) status_publish(row_st + (size_t)htile * SL3D_ST_STRIDE, status_word(P.epoch, SL3D_ST_PREFIX, base + htotal));
+                if (htile != 0u)
+                    status_publish(row_st + (size_t)htile * SL3D_ST_STRIDE, lb_failed ? status_word(P.epoch, SL3D_ST_FAILED, 0u) : status_word(P.epoch, SL3D_ST_PREFIX, base + htotal));
                 if ((int)htile == P.n_tiles - 1) P.cloud_totals[hview] = (unsigned long long)(base + htotal);
             }
         }
@@ -1472,9 +1489,10 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                                  b2 = __ballot((vout & 0x00010000u) != 0u), b3 = __ballot((vout & 0x01000000u) != 0u);
         auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
         const unsigned rank_w = below(b0) + below(b1) + below(b2) + below(b3);
-        if (lane == 0) s_wtot[wave] = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+        if (lane == 0) s_wtot[wt_par][wave] = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
         if (!(SL3D_CX & 4)) __syncthreads();
-        const unsigned t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
+        const unsigned t0 = s_wtot[wt_par][0], t1 = s_wtot[wt_par][1], t2 = s_wtot[wt_par][2], t3 = s_wtot[wt_par][3];
+        wt_par ^= 1u;
         ftotal = t0 + t1 + t2 + t3;
         frank = rank_w + (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
         fvout = vout;

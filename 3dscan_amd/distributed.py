@@ -47,11 +47,17 @@ def free_port():
     return p
 
 
-def spawn_ranks(script, argv, world, extra_env=None):
+def spawn_ranks(script, argv, world, extra_env=None, timeout=None, poll_s=0.2):
     """Start `world` FRESH python processes of `script argv...`, one per rank, with the environment torch.distributed.run
     would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  The caller must not have touched the GPU
     (and never exec's): the children are ordinary subprocesses.  Rank 0's stdout is returned; every rank's stderr is
-    inherited.  Raises SystemExit with the first non-zero exit code."""
+    inherited (ranks > 0 send their stdout there too, so nothing a rank says is lost).
+
+    The ranks are SUPERVISED: all of them are polled; the first non-zero exit, `timeout` seconds without completion, or an
+    interrupt of the parent terminates (then kills) the survivors -- a rank that died before or inside a collective never
+    leaves the others holding their GPUs in init_process_group or an RCCL call.  Raises SystemExit naming the failed ranks."""
+    import threading
+    import time
     port = free_port()
     procs = []
     for r in range(world):
@@ -61,14 +67,49 @@ def spawn_ranks(script, argv, world, extra_env=None):
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stdout.write(out.decode(errors="replace"))
-        raise SystemExit(f"rank(s) failed: {bad}")
-    return out.decode()
+                                      stdout=subprocess.PIPE if r == 0 else 2))   # fd 2: the parent's stderr
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # the pipe never fills up
+    reader.start()
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    why = None
+    t0 = time.monotonic()
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                why = f"rank(s) failed: {bad}"
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                why = f"ranks did not finish within {timeout} s (still running: {[r for r, rc in enumerate(rcs) if rc is None]})"
+                break
+            time.sleep(poll_s)
+    except BaseException:   # KeyboardInterrupt included: no orphaned ranks
+        stop_all()
+        raise
+    if why:
+        stop_all()
+    reader.join(timeout=5.0)
+    out = b"".join(chunks).decode(errors="replace")
+    if why:
+        sys.stdout.write(out)
+        raise SystemExit(why)
+    return out
 
 
 def max_over_ranks(seconds, device=None):

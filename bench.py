@@ -38,17 +38,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def measured_traffic(px_per_launch):
-    """HBM bytes per launch of the fused kernel from the latest COMMITTED PMC run (tools/profile.sh +
-    tools/summarize_profile.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, scaled by the factors
-    calibrated on tools/membench in the same session), scaled to the pixels of this launch.  Not measured in this run:
-    the source file is named beside the number.  (None, None) if no profile has been committed."""
+def measured_traffic(px_per_launch, kernel="dense"):
+    """HBM bytes per launch of the fused kernel (kernel = "dense") or of its compacting instantiation ("clouds") from the latest
+    COMMITTED PMC run (tools/profile.sh + tools/summarize_profile.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes,
+    scaled by the factors calibrated on tools/membench in the same session), scaled to the pixels of this launch.  Not
+    measured in this run: the source file is named beside the number.  (None, None) if no profile has been committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    pat = "r[0-9]*_traffic.json" if kernel == "dense" else "r[0-9]*_traffic_clouds.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
         return None, None
     t = json.load(open(files[-1]))
-    scale = px_per_launch / (t["algorithmic_bytes_per_launch"] / 60.0)
+    scale = px_per_launch / float(t.get("pixels_per_launch") or (t["algorithmic_bytes_per_launch"] / 60.0))
     return round(t["hbm_bytes_per_launch"] * scale), os.path.relpath(files[-1], ROOT)
 
 
@@ -79,6 +80,7 @@ def parse():
                                                   "is refused with nccl and allowed with gloo (plumbing tests on one GPU)")
     ap.add_argument("--chunks", type=int, default=4, help="chunks of views the assembly pipeline works in")
     ap.add_argument("--assembly-timeout", type=float, default=240.0, help="seconds the assembly legs (N>1) may take before the line is printed without them")
+    ap.add_argument("--rendezvous-timeout", type=float, default=180.0, help="seconds init_process_group / a collective may wait for the other ranks (N>1)")
     ap.add_argument("--check", action="store_true", help="add SHA-256 digests of the assembled results (dense and compacted) to the line")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of one view timed on the CPU (0 = whole view)")
     return ap.parse_args()
@@ -277,11 +279,26 @@ def main():
     dev_index = devs[rank]
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rank_report = [{"rank": 0, "device": dev_index, "gpu": torch.cuda.get_device_name(dev_index), "comm_size": 1}]
     if world > 1:
+        import datetime
+        # a bounded rendezvous: a rank that never shows up (partial node, a rank that died on start) fails the others within
+        # --rendezvous-timeout seconds, with a non-zero exit, instead of leaving them in init_process_group
+        tmo = datetime.timedelta(seconds=args.rendezvous_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
+        # what every rank really got: its device and the size of the communicator it is part of, on stderr per rank and
+        # (gathered) in rank 0's line -- the first collective of the run, so a broken fabric shows up here, not in the timing
+        mine = {"rank": rank, "device": dev_index, "gpu": torch.cuda.get_device_name(dev_index), "comm_size": dist.get_world_size(),
+                "backend": dist.get_backend(), "pid": os.getpid()}
+        print(f"[bench rank {rank}/{world}] device {dev_index} ({mine['gpu']}), communicator of {mine['comm_size']} ranks, backend {mine['backend']}",
+              file=sys.stderr, flush=True)
+        rank_report = [None] * world
+        dist.all_gather_object(rank_report, mine)
+        if any(r["comm_size"] != world for r in rank_report) or (args.backend == "nccl" and len({r["device"] for r in rank_report}) != world):
+            raise SystemExit(f"rank {rank}: inconsistent job: {rank_report}")
     red_dev = dev if args.backend == "nccl" else None  # where the tiny timing reductions live
 
     syn = importlib.import_module("3dscan_amd.synth")
@@ -362,32 +379,62 @@ def main():
     # end to end from device-resident frames to compacted clouds: ONE launch, the compaction of
     # 8/save_point_cloud.cpp:85-104 happens inside the fused kernel (sl3d_run_clouds), plus the read-back of the counts;
     # a side figure, never `value`
-    try:
-        if args.no_clouds:
-            raise RuntimeError("skipped (--no-clouds)")
-        for _ in range(20):
-            sc.run_clouds(0, n_views)
-        counts = sc.cloud_counts(0, n_views)[2]
-        barrier()
-        reps = max(20, args.steps // 10)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            sc.run_clouds(0, n_views)
+    # Every collective of this leg (barrier, MAX over ranks, the all-ranks-ok vote) sits OUTSIDE the per-rank try blocks and is
+    # executed by every rank in the same order whatever happened locally: an exception on one rank can never leave the others
+    # in a mismatched collective.
+    def all_ok(ok):
+        return dmod.max_over_ranks(0.0 if ok else 1.0, red_dev) == 0.0
+
+    cl_err, counts, te, kms = None, [], 0.0, 0.0
+    reps = max(20, args.steps // 10)
+    if args.no_clouds:
+        cl_err = "skipped (--no-clouds)"
+    else:
+        try:
+            for _ in range(20):
+                sc.run_clouds(0, n_views)
             counts = sc.cloud_counts(0, n_views)[2]
+        except Exception as e:
+            cl_err = repr(e)
+    if all_ok(cl_err is None):
+        barrier()
+        t0 = time.perf_counter()
+        try:
+            for _ in range(reps):
+                sc.run_clouds(0, n_views)
+                counts = sc.cloud_counts(0, n_views)[2]
+        except Exception as e:
+            cl_err = repr(e)
         barrier()
         te = dmod.max_over_ranks((time.perf_counter() - t0) / reps, red_dev)
-        sc.timer_start()
-        for _ in range(reps):
-            sc.run_clouds(0, n_views)
-        kms = dmod.max_over_ranks(sc.timer_stop() / reps, red_dev)
+        try:
+            sc.timer_start()
+            for _ in range(reps):
+                sc.run_clouds(0, n_views)
+            kms = sc.timer_stop() / reps
+        except Exception as e:
+            cl_err = cl_err or repr(e)
+        kms = dmod.max_over_ranks(kms, red_dev)
+        if not all_ok(cl_err is None):
+            cl_err = cl_err or "another rank failed"
+    else:
+        cl_err = cl_err or "another rank failed"
+    if cl_err is None:
         vf = sum(counts) / float(px_per_launch)
+        cl_bytes_px = 2 * 3 + 4 * N + 1 + 1 + 12 * vf   # frames + mask byte read, valid byte + 12 B per VALID pixel written
+        cl_achieved = cl_bytes_px * px_per_launch / (kms * 1e-3) / 1e9
+        cl_traffic, cl_traffic_src = measured_traffic(px_per_launch, "clouds") if alg_bytes_px == 60 else (None, None)
         out["to_compacted_clouds"] = {"value": round(px_per_step / te / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(te * 1e3, 4),
                                       "kernel_only": {"value": round(px_per_step / kms / 1e3, 1), "ms_per_launch": round(kms, 4)},
                                       "valid_points_per_step_rank0": int(sum(counts)), "valid_fraction_rank0": round(vf, 4),
-                                      "algorithmic_bytes_per_pixel": round(2 * 3 + 4 * N + 1 + 1 + 12 * vf, 2),
+                                      "algorithmic_bytes_per_pixel": round(cl_bytes_px, 2),
+                                      "roofline": {"bound": "hbm", "achieved": round(cl_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(cl_achieved / HBM_PEAK_GBS, 4), "traffic": cl_traffic,
+                                                   "traffic_source": cl_traffic_src and f"{cl_traffic_src} (committed PMC run of this command, scaled to this launch; not measured in this run)",
+                                                   "kernel": kernel_name.replace(", false>", ", true>"), "avg_launch_ms": round(kms, 4)},
                                       "how": "one launch: ordered compaction inside the fused kernel (decoupled look-back over 1024-pixel tiles)"}
-    except Exception as e:
-        out["to_compacted_clouds"] = {"error": repr(e)}
+    else:
+        out["to_compacted_clouds"] = {"error": cl_err}
 
     digests = {}
     if world > 1 and not args.no_assemble:
@@ -399,8 +446,9 @@ def main():
         def give_up():
             if rank == 0:
                 out["with_assembly"] = {"error": f"assembly legs did not finish within {args.assembly_timeout} s"}
+                out["ranks"] = rank_report
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)   # non-zero on every rank: the launcher (spawn_ranks / torchrun / CI) must see that the run did not complete
 
         watchdog = threading.Timer(args.assembly_timeout, give_up)
         watchdog.daemon = True
@@ -475,6 +523,8 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"error": repr(e)}
     sc.close()
+    if world > 1:
+        out["ranks"] = rank_report
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

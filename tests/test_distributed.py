@@ -143,6 +143,38 @@ def test_spawn_ranks_environment(tmp_path):
         d.spawn_ranks(str(script), ["x", "2"], 3)
 
 
+def test_spawn_ranks_supervises_its_children(tmp_path):
+    """A rank that dies (before a rendezvous, inside a collective ...) must not leave the others behind: the survivors --
+    here asleep for a minute, like a rank stuck in init_process_group -- are terminated and the failure is raised at once;
+    the same for an overall timeout."""
+    import os
+    import time
+    d = pkg("distributed")
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys, time\n"
+                      "open(os.path.join(sys.argv[1], 'pid' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                      "if os.environ['RANK'] == sys.argv[2]:\n    sys.exit(7)\n"
+                      "time.sleep(60)\n")
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+            return open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (OSError, IOError):
+            return False
+
+    for args, kw in ((["1"], {}), (["-1"], {"timeout": 1.5})):
+        for f in tmp_path.glob("pid*"):
+            f.unlink()
+        t0 = time.monotonic()
+        with pytest.raises(SystemExit) as e:
+            d.spawn_ranks(str(script), [str(tmp_path)] + args, 3, **kw)
+        assert time.monotonic() - t0 < 20
+        assert ("failed" in str(e.value)) if not kw else ("did not finish" in str(e.value))
+        pids = [int(f.read_text()) for f in tmp_path.glob("pid*")]
+        assert len(pids) == 3 and not any(alive(p) for p in pids), "orphaned ranks"
+
+
 def test_assembly_gloo_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
