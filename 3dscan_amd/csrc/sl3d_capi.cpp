@@ -104,6 +104,7 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     sl3d_ctx *x = new sl3d_ctx();
     x->cfg = c;
     x->keep = (c.flags & SL3D_FLAG_KEEP_STAGES) != 0;
+    x->clouds_lookback = (c.flags & SL3D_FLAG_CLOUDS_LOOKBACK) != 0;
 #define CREATE_CHK(call)                                                                 \
     do {                                                                                 \
         hipError_t e_ = (call);                                                          \
@@ -384,6 +385,7 @@ extern "C" int sl3d_get_projection_matrices(sl3d_ctx *x, double A_cam[12], doubl
 }
 
 static int launched(sl3d_ctx *x, int hip_err);
+static int need_keep(sl3d_ctx *x);
 
 static int check_view(sl3d_ctx *x, int view, int n = 1)
 {
@@ -423,6 +425,97 @@ extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t str
     rc = launched(x, launch_mask_prepare(P, view, x->d_mask_raw, x->stream));
     if (rc) return rc;
     if (!is_pinned_host(m)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
+    return SL3D_OK;
+}
+
+static int ensure_colrow(sl3d_ctx *x, size_t bytes)
+{
+    if (x->d_colrow && x->colrow_bytes >= bytes) return SL3D_OK;
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    if (x->d_colrow) {
+        (void)hipFree(x->d_colrow);
+        x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_colrow), x->allocs.end());
+        x->d_colrow = nullptr;
+        x->colrow_bytes = 0;
+    }
+    const int rc = dev_alloc(x, &x->d_colrow, bytes);
+    if (rc) return rc;
+    x->colrow_bytes = bytes;
+    return SL3D_OK;
+}
+
+// selected_region in the reference's own [col][row] int layout: the window's columns (+ 2-pixel halo, clipped to the frame) are
+// contiguous runs of rows -> one 2-D copy; k_mask_from_colrow transposes them into the byte staging plane, k_mask_prepare does
+// the rest (as for sl3d_set_mask).
+extern "C" int sl3d_set_mask_colrow(sl3d_ctx *x, int view, const int32_t *sel)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    if (!sel) return fail(x, SL3D_E_INVALID_ARG, "mask: null");
+    const KParams &P = x->P;
+    ON_DEVICE(x);
+    const int gy0 = std::max(P.row0 - SL3D_MASK_HALO, 0), gy1 = std::min(P.row0 + P.H + SL3D_MASK_HALO, P.fullH);
+    const int gx0 = std::max(P.col0 - SL3D_MASK_HALO, 0), gx1 = std::min(P.col0 + P.W + SL3D_MASK_HALO, P.fullW);
+    const int ncols = gx1 - gx0, nrows = gy1 - gy0;
+    rc = ensure_colrow(x, std::max((size_t)ncols * nrows * sizeof(int), (size_t)P.W * P.H * 24));
+    if (rc) return rc;
+    HIPCHK(x, hipMemcpy2DAsync(x->d_colrow, (size_t)nrows * sizeof(int), sel + (size_t)gx0 * P.fullH + gy0, (size_t)P.fullH * sizeof(int),
+                               (size_t)nrows * sizeof(int), (size_t)ncols, hipMemcpyHostToDevice, x->stream));
+    rc = launched(x, launch_mask_from_colrow(P, (const int *)x->d_colrow, gx0, gy0, ncols, nrows, x->d_mask_raw, x->stream));
+    if (rc) return rc;
+    rc = launched(x, launch_mask_prepare(P, view, x->d_mask_raw, x->stream));
+    if (rc) return rc;
+    if (!is_pinned_host(sel)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_get_global_colrow(sl3d_ctx *x, int view, int which, void *out, int out_height, int out_row0)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    const KParams &P = x->P;
+    if (!out || which < SL3D_G_VALID_V || which > SL3D_G_INTERSECTION_POINTS || out_row0 < 0 || out_row0 + P.H > out_height)
+        return fail(x, SL3D_E_INVALID_ARG, "get_global_colrow: null output, unknown global, or the window's rows do not fit out_height");
+    if (which != SL3D_G_VALID && (rc = need_keep(x))) return rc;
+    const size_t elem = which == SL3D_G_INTERSECTION_POINTS ? 24 : 4;
+    ON_DEVICE(x);
+    rc = ensure_colrow(x, (size_t)P.W * P.H * 24);
+    if (rc) return rc;
+    rc = launched(x, launch_to_colrow(P, view, which, x->d_colrow, x->stream));
+    if (rc) return rc;
+    uint8_t *dst = (uint8_t *)out + (size_t)out_row0 * elem;
+    if (out_height == P.H)
+        HIPCHK(x, hipMemcpyAsync(dst, x->d_colrow, (size_t)P.W * P.H * elem, hipMemcpyDeviceToHost, x->stream));
+    else
+        HIPCHK(x, hipMemcpy2DAsync(dst, (size_t)out_height * elem, x->d_colrow, (size_t)P.H * elem, (size_t)P.H * elem, (size_t)P.W, hipMemcpyDeviceToHost,
+                                   x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_set_frames_range(sl3d_ctx *x, int view, int axis, int first_plane, const uint8_t *const *planes, int n_planes, size_t stride)
+{
+    int rc = check_view(x, view);
+    if (rc) return rc;
+    const KParams &P = x->P;
+    const int N = axis == 0 ? P.Nv : P.Nh;
+    if ((axis != 0 && axis != 1) || !planes || first_plane < 0 || n_planes < 1 || first_plane + n_planes > P.F + 2 * N || stride < (size_t)P.W)
+        return fail(x, SL3D_E_INVALID_ARG, "set_frames_range: planes [first, first + n) must lie inside the axis' n_fringe + 2*n_gray planes, stride >= width");
+    ON_DEVICE(x);
+    const int base = (axis == 0 ? 0 : P.F + 2 * P.Nv) + first_plane;
+    bool back_to_back = true;
+    for (int i = 0; i < n_planes; i++) {
+        if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames_range: null plane");
+        if (i && planes[i] != planes[i - 1] + stride * (size_t)P.H) back_to_back = false;
+    }
+    uint8_t *dst0 = x->d_frames + (size_t)view * P.view_stride + (size_t)base * P.plane_stride;
+    if (back_to_back) {
+        HIPCHK(x, hipMemcpy2DAsync(dst0, P.pitch, planes[0], stride, P.W, (size_t)P.H * n_planes, hipMemcpyHostToDevice, x->stream));
+    } else {
+        for (int i = 0; i < n_planes; i++)
+            HIPCHK(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+    }
+    if (!is_pinned_host(planes[0])) HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 
@@ -735,7 +828,13 @@ extern "C" void sl3d_host_free(void *p)
 // is then the slowest stage (the upload: PCIe), not the sum of the three.  The mask of every slot must have been set.
 //   planes: n_views * planes_per_view pointers, view-major, plane order as in sl3d_device_buffers; `stride` bytes per row
 //   xyz:    n_views dense [height][width][3] float images (may be NULL);  valid: n_views [height][width] bytes (may be NULL)
-extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid)
+// The pipeline itself, ENQUEUED only (no host wait when the buffers are pinned): xyz / valid of view v go to
+// xyz + v*xyz_view_stride (floats) / valid + v*valid_view_stride (bytes) with `out_width` pixels per destination row -- a
+// whole-frame context passes its own width and W*H strides, a row stripe of a group passes the frame's.  sl3d_process_views_wait
+// drains the three streams.  (Shared with sl3d_group_process_views: every stripe's pipeline is enqueued before any is waited for,
+// so the GPUs -- and their PCIe links -- work concurrently behind one host thread.)
+int sl3d_process_views_enqueue(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, size_t xyz_view_stride, uint8_t *valid,
+                               size_t valid_view_stride, size_t out_width)
 {
     if (!x || n_views < 1 || !planes) return fail(x, SL3D_E_INVALID_ARG, "process_views: null argument");
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "process_views before set_calibration");
@@ -759,54 +858,68 @@ extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const
     // buffers the caller is about to free
     for (size_t i = 0; i < (size_t)n_views * (size_t)ppv; i++)
         if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "process_views: null plane");
-    auto pipeline = [&]() -> int {
-        for (int v = 0; v < n_views; v++) {
-            const int slot = v % S;
-            // the slot's previous occupant must have been computed (frames free) and downloaded (results free)
-            if (v >= S) {
-                HIPCHK(x, hipStreamWaitEvent(x->s_h2d, x->ev_done[(size_t)slot], 0));
-                HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_down[(size_t)slot], 0));
-            }
-            // a view whose planes are back to back in host memory, in the device's own pitch, goes up as ONE copy
-            bool contiguous = stride == (size_t)P.pitch && (size_t)P.W == (size_t)P.pitch;
-            for (int p = 1; p < ppv; p++)
-                if (planes[(size_t)v * ppv + p] != planes[(size_t)v * ppv + p - 1] + P.plane_stride) contiguous = false;
-            if (contiguous) {
-                HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)slot * P.view_stride, planes[(size_t)v * ppv], P.view_stride, hipMemcpyHostToDevice, x->s_h2d));
-            } else {
-                for (int p = 0; p < ppv; p++)
-                    HIPCHK(x, hipMemcpy2DAsync(x->d_frames + (size_t)slot * P.view_stride + (size_t)p * P.plane_stride, P.pitch,
-                                               planes[(size_t)v * ppv + p], stride, P.W, P.H, hipMemcpyHostToDevice, x->s_h2d));
-            }
-            HIPCHK(x, hipEventRecord(x->ev_up[(size_t)slot], x->s_h2d));
-            HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_up[(size_t)slot], 0));
-            const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, false, x->stream));
-            if (rc) return rc;
-            HIPCHK(x, hipEventRecord(x->ev_done[(size_t)slot], x->stream));
-            HIPCHK(x, hipStreamWaitEvent(x->s_d2h, x->ev_done[(size_t)slot], 0));
-            if (xyz)
-                HIPCHK(x, hipMemcpy2DAsync(xyz + (size_t)v * P.W * P.H * 3, (size_t)P.W * 12, P.points + (size_t)slot * P.px_view_stride * 3,
-                                           (size_t)P.pitch * 12, (size_t)P.W * 12, P.H, hipMemcpyDeviceToHost, x->s_d2h));
-            if (valid)
-                HIPCHK(x, hipMemcpy2DAsync(valid + (size_t)v * P.W * P.H, P.W, P.valid + (size_t)slot * P.px_view_stride, P.pitch, P.W, P.H,
-                                           hipMemcpyDeviceToHost, x->s_d2h));
-            HIPCHK(x, hipEventRecord(x->ev_down[(size_t)slot], x->s_d2h));
+    for (int v = 0; v < n_views; v++) {
+        const int slot = v % S;
+        // the slot's previous occupant must have been computed (frames free) and downloaded (results free)
+        if (v >= S) {
+            HIPCHK(x, hipStreamWaitEvent(x->s_h2d, x->ev_done[(size_t)slot], 0));
+            HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_down[(size_t)slot], 0));
         }
-        return SL3D_OK;
-    };
-    const int rc = pipeline();
-    // success or not, nothing may still be running against the caller's buffers when this returns, and the three streams are
-    // left drained for the next call
-    const std::string first_err = x->err;
-    const hipError_t e1 = hipStreamSynchronize(x->s_h2d), e2 = hipStreamSynchronize(x->stream), e3 = hipStreamSynchronize(x->s_d2h);
-    if (rc) {
-        x->err = first_err;
-        return rc;
+        // a view whose planes are back to back in host memory, in the device's own pitch, goes up as ONE copy
+        bool contiguous = stride == (size_t)P.pitch && (size_t)P.W == (size_t)P.pitch;
+        for (int p = 1; p < ppv; p++)
+            if (planes[(size_t)v * ppv + p] != planes[(size_t)v * ppv + p - 1] + P.plane_stride) contiguous = false;
+        if (contiguous) {
+            HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)slot * P.view_stride, planes[(size_t)v * ppv], P.view_stride, hipMemcpyHostToDevice, x->s_h2d));
+        } else {
+            for (int p = 0; p < ppv; p++)
+                HIPCHK(x, hipMemcpy2DAsync(x->d_frames + (size_t)slot * P.view_stride + (size_t)p * P.plane_stride, P.pitch,
+                                           planes[(size_t)v * ppv + p], stride, P.W, P.H, hipMemcpyHostToDevice, x->s_h2d));
+        }
+        HIPCHK(x, hipEventRecord(x->ev_up[(size_t)slot], x->s_h2d));
+        HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_up[(size_t)slot], 0));
+        const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, 0, x->stream));
+        if (rc) return rc;
+        HIPCHK(x, hipEventRecord(x->ev_done[(size_t)slot], x->stream));
+        HIPCHK(x, hipStreamWaitEvent(x->s_d2h, x->ev_done[(size_t)slot], 0));
+        if (xyz)
+            HIPCHK(x, hipMemcpy2DAsync(xyz + (size_t)v * xyz_view_stride, out_width * 12, P.points + (size_t)slot * P.px_view_stride * 3,
+                                       (size_t)P.pitch * 12, (size_t)P.W * 12, P.H, hipMemcpyDeviceToHost, x->s_d2h));
+        if (valid)
+            HIPCHK(x, hipMemcpy2DAsync(valid + (size_t)v * valid_view_stride, out_width, P.valid + (size_t)slot * P.px_view_stride, P.pitch, P.W, P.H,
+                                       hipMemcpyDeviceToHost, x->s_d2h));
+        HIPCHK(x, hipEventRecord(x->ev_down[(size_t)slot], x->s_d2h));
     }
+    return SL3D_OK;
+}
+
+// drains the three streams of the pipeline; returns the first HIP error met
+int sl3d_process_views_wait(sl3d_ctx *x)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    if (!x->s_h2d) return SL3D_OK;
+    ON_DEVICE(x);
+    const hipError_t e1 = hipStreamSynchronize(x->s_h2d), e2 = hipStreamSynchronize(x->stream), e3 = hipStreamSynchronize(x->s_d2h);
     HIPCHK(x, e1);
     HIPCHK(x, e2);
     HIPCHK(x, e3);
     return SL3D_OK;
+}
+
+extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    const size_t px = (size_t)x->P.W * x->P.H;
+    const int rc = sl3d_process_views_enqueue(x, n_views, planes, stride, xyz, px * 3, valid, px, (size_t)x->P.W);
+    // success or not, nothing may still be running against the caller's buffers when this returns, and the three streams are
+    // left drained for the next call
+    const std::string first_err = x->err;
+    const int rc2 = sl3d_process_views_wait(x);
+    if (rc) {
+        x->err = first_err;
+        return rc;
+    }
+    return rc2;
 }
 
 // ---- compacted clouds straight from the fused kernel ----------------------------------------------------------------
@@ -828,7 +941,15 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
     if (!x->d_tile_status) rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE);
     if (!rc && !x->d_ticket) rc = dev_alloc(x, &x->d_ticket, (size_t)1);
     if (!rc && !x->d_lookback_err) rc = dev_alloc(x, &x->d_lookback_err, (size_t)16);  // [0] = error flag; measurement builds keep counters behind it
+    P.n_segs = 4 * P.n_tiles;
+    if (!rc && !x->d_seg_counts) rc = dev_alloc(x, &x->d_seg_counts, mv * (size_t)P.n_segs);
+    if (!rc && !x->d_seg_offsets) rc = dev_alloc(x, &x->d_seg_offsets, mv * (size_t)P.n_segs);
     if (rc) return rc;
+    // a wave of the last tile that owns no row never stores its count: zero once, for good
+    HIPCHK(x, hipMemsetAsync(x->d_seg_counts, 0, mv * (size_t)P.n_segs * sizeof(unsigned), x->stream));
+    HIPCHK(x, hipMemsetAsync(x->d_seg_offsets, 0, mv * (size_t)P.n_segs * sizeof(unsigned long long), x->stream));
+    P.seg_counts = x->d_seg_counts;
+    P.seg_offsets = x->d_seg_offsets;
     HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE * sizeof(unsigned long long), x->stream));
     HIPCHK(x, hipMemsetAsync(x->d_lookback_err, 0, 16 * sizeof(int), x->stream));
     HIPCHK(x, hipMemsetAsync(x->d_ticket, 0, sizeof(unsigned), x->stream));
@@ -868,11 +989,22 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
     ON_DEVICE(x);
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
+    if (!x->clouds_lookback) {  // segmented clouds: the fused kernel, then the offsets / totals of its segment counts
+        rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 2, x->stream));
+        if (rc) return rc;
+        return launched(x, launch_seg_scan(x->P, first_view, n_views, x->stream));
+    }
     if (++x->P.epoch >= (1u << 30)) {  // the generation tag is 30 bits: start over with cleared words
         HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * SL3D_ST_STRIDE * sizeof(unsigned long long), x->stream));
         x->P.epoch = 1;
     }
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, true, x->stream, &x->tickets_drawn));
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 1, x->stream, &x->tickets_drawn));
+}
+
+static int ensure_packed(sl3d_ctx *x)
+{
+    if (x->d_packed) return SL3D_OK;
+    return dev_alloc(x, &x->d_packed, (size_t)x->cfg.max_views * x->P.px_view_stride * 3);
 }
 
 // counts (and the device address) of the clouds the last sl3d_run_clouds over these views produced; synchronises
@@ -892,8 +1024,86 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
         return fail(x, SL3D_E_HIP, "fused compaction: a tile look-back timed out");
     }
     for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[first_view + v];
-    if (device_xyz) *device_xyz = x->d_clouds + 3 * (size_t)first_view * x->P.px_view_stride;
+    if (device_xyz) {
+        if (x->clouds_lookback) {
+            *device_xyz = x->d_clouds + 3 * (size_t)first_view * x->P.px_view_stride;
+        } else {  // segmented clouds: the contiguous copy is made now, by one gap-closing launch over these views
+            rc = ensure_packed(x);
+            if (rc) return rc;
+            float *dst = x->d_packed + 3 * (size_t)first_view * x->P.px_view_stride;
+            rc = launched(x, launch_seg_close(x->P, first_view, n_views, dst, x->P.px_view_stride, x->stream));
+            if (rc) return rc;
+            *device_xyz = dst;
+        }
+    }
     if (view_stride_points) *view_stride_points = x->P.px_view_stride;
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_get_cloud_segments(sl3d_ctx *x, int first_view, int n_views, sl3d_cloud_segments *out, int64_t *counts)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!out) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
+    if (x->clouds_lookback) return fail(x, SL3D_E_STATE, "the context writes contiguous clouds (SL3D_FLAG_CLOUDS_LOOKBACK): use sl3d_get_cloud_counts");
+    if (counts) {
+        rc = sl3d_get_cloud_counts(x, first_view, n_views, nullptr, nullptr, counts);
+        if (rc) return rc;
+    }
+    const KParams &P = x->P;
+    out->xyz = x->d_clouds + 3 * (size_t)first_view * P.px_view_stride;
+    out->counts = x->d_seg_counts + (size_t)first_view * P.n_segs;
+    out->offsets = (const uint64_t *)(x->d_seg_offsets + (size_t)first_view * P.n_segs);
+    out->n_segments = P.n_segs;
+    out->segment_points = 256;
+    out->view_stride_points = P.px_view_stride;
+    out->view_stride_segments = (size_t)P.n_segs;
+    return SL3D_OK;
+}
+
+// The host copy of the clouds of the last sl3d_run_clouds, back to back (8/save_point_cloud.cpp:85-104 fills a host cloud).
+// Segmented clouds + pinned destination: the gap-closing kernel stores straight into the (mapped) host buffer -- the PCIe link is
+// the bound either way, so closing the gaps costs nothing; pageable destination or look-back clouds: a contiguous device copy
+// goes down by DMA.
+extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    rc = sl3d_get_cloud_counts(x, first_view, n_views, nullptr, nullptr, counts);
+    if (rc || !xyz) return rc;
+    ON_DEVICE(x);
+    const KParams &P = x->P;
+    int64_t total = 0;
+    for (int v = 0; v < n_views; v++) total += counts[v];
+    void *mapped = nullptr;
+    const char *zc = getenv("SL3D_ZEROCOPY");
+    const bool zero_copy = !x->clouds_lookback && total <= capacity && !(zc && atoi(zc) == 0) && is_pinned_host(xyz) &&
+                           hipHostGetDevicePointer(&mapped, xyz, 0) == hipSuccess && mapped;
+    if (!zero_copy) (void)hipGetLastError();
+    if (zero_copy) {
+        int64_t off = 0;
+        for (int v = 0; v < n_views; v++) {
+            if (counts[v] > 0) {
+                rc = launched(x, launch_seg_close(P, first_view + v, 1, (float *)mapped + 3 * off, 0, x->stream));
+                if (rc) return rc;
+            }
+            off += counts[v];
+        }
+    } else {
+        const float *dev = nullptr;
+        size_t stride = 0;
+        rc = sl3d_get_cloud_counts(x, first_view, n_views, &dev, &stride, counts);
+        if (rc) return rc;
+        int64_t off = 0;
+        for (int v = 0; v < n_views && off < capacity; v++) {
+            const int64_t n = std::min<int64_t>(counts[v], capacity - off);
+            if (n > 0) HIPCHK(x, hipMemcpyAsync(xyz + 3 * off, dev + 3 * (size_t)v * stride, (size_t)n * 12, hipMemcpyDeviceToHost, x->stream));
+            off += n;
+        }
+    }
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 
@@ -942,14 +1152,16 @@ extern "C" int sl3d_compact_views(sl3d_ctx *x, int first_view, int n_views, cons
     const KParams &P = x->P;
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
+    rc = ensure_packed(x);  // (the region sl3d_run_clouds writes is left alone)
+    if (rc) return rc;
     rc = launched(x, launch_compact_views(P, first_view, n_views, x->d_blk_cnt_all, x->d_blk_off_all, x->d_totals + first_view,
-                                          x->d_clouds + 3 * (size_t)first_view * P.px_view_stride, x->stream));
+                                          x->d_packed + 3 * (size_t)first_view * P.px_view_stride, x->stream));
     if (rc) return rc;
     std::vector<unsigned long long> t((size_t)n_views);
     HIPCHK(x, hipMemcpyAsync(t.data(), x->d_totals + first_view, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
     HIPCHK(x, hipStreamSynchronize(x->stream));
     for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[(size_t)v];
-    if (device_xyz) *device_xyz = x->d_clouds + 3 * (size_t)first_view * P.px_view_stride;
+    if (device_xyz) *device_xyz = x->d_packed + 3 * (size_t)first_view * P.px_view_stride;
     if (view_stride_points) *view_stride_points = P.px_view_stride;
     return SL3D_OK;
 }
@@ -1054,6 +1266,47 @@ extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, flo
         HIPCHK(x, hipMemcpyAsync(xyz, x->d_reg, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         HIPCHK(x, hipStreamSynchronize(x->stream));
     }
+    return SL3D_OK;
+}
+
+// register_point_clouds() on the clouds of the last sl3d_run_clouds: the segments of view k are rotated by theta_k while they are
+// concatenated (k_seg_close<REG>), so neither a dense plane nor a separate compaction nor a gap-closing pass is needed.
+extern "C" int sl3d_register_clouds(sl3d_ctx *x, int first_view, int n_views, float tx, float ty, float tz, float rot_step, float *xyz,
+                                    int64_t capacity, int64_t *total)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!total) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    std::vector<int64_t> counts((size_t)n_views);
+    const float *clouds = nullptr;
+    size_t stride = 0;
+    // (look-back clouds are contiguous already: they go through the plain transform kernel)
+    rc = sl3d_get_cloud_counts(x, first_view, n_views, x->clouds_lookback ? &clouds : nullptr, &stride, counts.data());
+    if (rc) return rc;
+    ON_DEVICE(x);
+    const KParams &P = x->P;
+    if (!x->d_reg) {
+        rc = dev_alloc(x, &x->d_reg, (size_t)x->cfg.max_views * P.px_view_stride * 3);
+        if (rc) return rc;
+    }
+    float theta = 0.0f;
+    int64_t off = 0;
+    for (int k = 0; k < n_views; k++) {
+        const int64_t n = counts[(size_t)k];
+        const float R4[4] = {(float)cos(theta * 22.0 / 7.0 / 180.0), (float)(-1.0f * sin(theta * 22.0 / 7.0 / 180.0)),
+                             (float)sin(theta * 22.0 / 7.0 / 180.0), (float)cos(theta * 22.0 / 7.0 / 180.0)};
+        if (n > 0) {
+            if (x->clouds_lookback) rc = launched(x, launch_register(clouds + 3 * (size_t)k * stride, x->d_reg + 3 * off, (long)n, R4, tx, ty, tz, x->stream));
+            else rc = launched(x, launch_seg_register(P, first_view + k, x->d_reg + 3 * off, R4, tx, ty, tz, x->stream));
+            if (rc) return rc;
+        }
+        off += n;
+        theta += rot_step;
+    }
+    *total = off;
+    const int64_t m = off < capacity ? off : capacity;
+    if (xyz && m > 0) HIPCHK(x, hipMemcpyAsync(xyz, x->d_reg, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 
@@ -1207,6 +1460,15 @@ extern "C" int sl3d_download(sl3d_ctx *x, void *host_dst, const void *device_src
     ON_DEVICE(x);
     if (bytes) HIPCHK(x, hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, x->stream));
     HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_download_2d(sl3d_ctx *x, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes, size_t height)
+{
+    if (!x || !host_dst || !device_src || dst_pitch < width_bytes || src_pitch < width_bytes) return fail(x, SL3D_E_INVALID_ARG, "download_2d: null argument or pitch < width");
+    ON_DEVICE(x);
+    if (width_bytes && height)
+        HIPCHK(x, hipMemcpy2DAsync(host_dst, dst_pitch, device_src, src_pitch, width_bytes, height, hipMemcpyDeviceToHost, x->stream));
     return SL3D_OK;
 }
 

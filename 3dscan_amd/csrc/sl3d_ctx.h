@@ -46,6 +46,10 @@ struct sl3d_ctx {
     unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
     unsigned long long *d_tile_status = nullptr;  // sl3d_run_clouds: look-back words [view][tile] of the fused compaction
     int *d_lookback_err = nullptr;
+    bool clouds_lookback = false;             // SL3D_FLAG_CLOUDS_LOOKBACK: contiguous clouds by a decoupled look-back; else segmented clouds
+    unsigned *d_seg_counts = nullptr;         // segmented clouds: [view][n_segs] counts, their exclusive scan,
+    unsigned long long *d_seg_offsets = nullptr;
+    float *d_packed = nullptr;                // and the contiguous copy made on demand (also the output of sl3d_compact_views)
     bool clouds_ready = false;                // ensure_cloud_buffers ran to its end: every pointer sl3d_run_clouds needs is set
     unsigned *d_ticket = nullptr;             // work-item counter of the persistent compacting kernel
     unsigned long long *h_counts = nullptr;   // pinned: the per-view counts (+ error flag) sl3d_get_cloud_counts reads back
@@ -58,6 +62,8 @@ struct sl3d_ctx {
     float2 *d_proj_disp = nullptr;            // RIG 2: projector undistortion table (allocated when a distorted projector is set)
     uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
     size_t pattern_pitch = 0;
+    uint8_t *d_colrow = nullptr;  // staging of one global in the reference's [col][row] layout (sl3d_get_global_colrow), and of a
+    size_t colrow_bytes = 0;      // [col][row] selection mask on its way in (sl3d_set_mask_colrow)
     DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
     size_t mask_rows = 0;
 };
@@ -65,6 +71,10 @@ struct sl3d_ctx {
 // records the message on the context (or, without one, as the thread's creation error) and returns `code`
 __attribute__((visibility("hidden"))) int sl3d_fail(sl3d_ctx *c, int code, const std::string &msg);
 #define fail sl3d_fail
+// sl3d_process_views in two halves (sl3d_capi.cpp), shared with sl3d_group_process_views
+__attribute__((visibility("hidden"))) int sl3d_process_views_enqueue(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz,
+                                                                     size_t xyz_view_stride, uint8_t *valid, size_t valid_view_stride, size_t out_width);
+__attribute__((visibility("hidden"))) int sl3d_process_views_wait(sl3d_ctx *x);
 
 #define HIPCHK(c, call)                                                                             \
     do {                                                                                            \

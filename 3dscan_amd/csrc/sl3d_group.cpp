@@ -451,6 +451,73 @@ extern "C" int sl3d_group_get_points(sl3d_group *g, int view, float *xyz, uint8_
     return SL3D_OK;
 }
 
+// The reference's consumer is the HOST (its results are host globals / a host PCL cloud: common_variables.h:12-21,56-62,
+// 8/save_point_cloud.cpp:85-104).  Every stripe copies its rows of every view straight into the caller's dense images, on its
+// own stream and over its own GPU's PCIe link -- no xGMI hop to a root, no single link that drains everything.  Pinned
+// destination memory (sl3d_host_alloc) makes the copies concurrent DMA; pageable memory works, serialised by the runtime.
+// Waits for the stripes' kernels of those views (stream order) and for the copies.
+extern "C" int sl3d_group_download_points(sl3d_group *g, int first, int n, float *xyz, uint8_t *valid)
+{
+    int rc = check_views(g, first, n);
+    if (rc) return rc;
+    const size_t W = (size_t)g->cfg.width, H = (size_t)g->cfg.height;
+    for (size_t s = 0; s < g->st.size(); s++) {
+        Stripe &S = g->st[s];
+        const KParams &P = S.ctx->P;
+        DeviceGuard dg(S.device);
+        for (int v = 0; v < n; v++) {
+            if (xyz)
+                GHIP(g, hipMemcpy2DAsync(xyz + ((size_t)v * H + (size_t)S.row0) * W * 3, W * 12, P.points + 3 * (size_t)(first + v) * P.px_view_stride,
+                                         (size_t)P.pitch * 12, W * 12, (size_t)S.rows, hipMemcpyDeviceToHost, S.ctx->stream));
+            if (valid)
+                GHIP(g, hipMemcpy2DAsync(valid + ((size_t)v * H + (size_t)S.row0) * W, W, P.valid + (size_t)(first + v) * P.px_view_stride, (size_t)P.pitch, W,
+                                         (size_t)S.rows, hipMemcpyDeviceToHost, S.ctx->stream));
+        }
+    }
+    for (size_t s = 0; s < g->st.size(); s++) GCTX(g, s, sl3d_synchronize(g->st[s].ctx));
+    return SL3D_OK;
+}
+
+// sl3d_process_views for a group: every stripe runs the three-stream pipeline (upload of its rows of view k+1, fused kernel of
+// view k, download of view k-1 into the caller's dense images) on its own GPU; all pipelines are enqueued before any is waited
+// for, so with pinned buffers the stripes -- and the PCIe links of their GPUs -- work concurrently behind the one calling thread.
+// planes: n_views * planes_per_view pointers to WINDOW-sized planes (`stride` bytes per row), view-major, plane order of
+// sl3d_device_buffers.  Masks and calibration must be set (every slot < max_views).
+extern "C" int sl3d_group_process_views(sl3d_group *g, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid)
+{
+    if (!g || n_views < 1 || !planes) return gfail(g, SL3D_E_INVALID_ARG, "group_process_views: null argument");
+    const size_t W = (size_t)g->cfg.width, H = (size_t)g->cfg.height;
+    const size_t ppv = (size_t)g->st[0].ctx->P.planes_per_view, np = (size_t)n_views * ppv;
+    for (size_t i = 0; i < np; i++)
+        if (!planes[i]) return gfail(g, SL3D_E_INVALID_ARG, "group_process_views: null plane");
+    int first_rc = SL3D_OK;
+    std::string first_err;
+    std::vector<const uint8_t *> sub(np);
+    size_t enq = 0;
+    for (; enq < g->st.size(); enq++) {
+        const Stripe &S = g->st[enq];
+        for (size_t i = 0; i < np; i++) sub[i] = planes[i] + (size_t)S.row0 * stride;
+        const int rc = sl3d_process_views_enqueue(S.ctx, n_views, sub.data(), stride, xyz ? xyz + (size_t)S.row0 * W * 3 : nullptr, W * H * 3,
+                                                  valid ? valid + (size_t)S.row0 * W : nullptr, W * H, W);
+        if (rc != SL3D_OK) {
+            first_rc = rc;
+            first_err = "stripe " + std::to_string(enq) + ": " + sl3d_last_error(S.ctx);
+            enq++;
+            break;
+        }
+    }
+    // nothing may still run against the caller's buffers when this returns, whatever happened above
+    for (size_t s = 0; s < enq; s++) {
+        const int rc = sl3d_process_views_wait(g->st[s].ctx);
+        if (rc != SL3D_OK && first_rc == SL3D_OK) {
+            first_rc = rc;
+            first_err = "stripe " + std::to_string(s) + ": " + sl3d_last_error(g->st[s].ctx);
+        }
+    }
+    if (first_rc != SL3D_OK) return gfail(g, first_rc, first_err);
+    return SL3D_OK;
+}
+
 extern "C" int sl3d_group_get_device_buffers(sl3d_group *g, sl3d_device_buffers *o)
 {
     if (!g || !o) return gfail(g, SL3D_E_INVALID_ARG, "null argument");

@@ -90,6 +90,11 @@ struct KParams {
     unsigned ticket_base;
     int n_cus;                 // compute units of the device (persistent grid of the COMPACT kernel)
     int n_tiles;               // 1024-pixel tiles per view = blocks of the fused kernel along x that own pixels
+    // segmented clouds (sl3d_run_clouds, default): `clouds` holds, per view, 4*n_tiles segments of 256 point slots; a segment's
+    // first seg_counts[view][seg] slots are its valid points in scan order
+    unsigned *seg_counts;              // [view][n_segs]
+    unsigned long long *seg_offsets;   // [view][n_segs] exclusive scan of the counts (k_compact_scan)
+    int n_segs;                        // 4 * n_tiles
     unsigned long long *dbg;   // measurement builds (-DSL3D_CX=128): [view][tile][4] clock stamps of the look-back; NULL otherwise
     // stage-boundary planes (NULL unless SL3D_FLAG_KEEP_STAGES)
     float *wrapped[2];
@@ -104,8 +109,14 @@ struct KParams {
 
 // launchers (sl3d_kernels.hip); `stream` is a hipStream_t
 // tickets_drawn (compact only): host mirror of *KParams::ticket, advanced by what this launch will draw
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream,
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int compact, void *stream,
                  unsigned *tickets_drawn = nullptr);
+// segmented clouds: offsets / totals of views [first_view, first_view + n_views) from the counts the fused kernel stored
+int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream);
+// segments -> contiguous: view first_view+k's points to dst + 3*k*dst_view_stride_points (dst: device memory or mapped host memory)
+int launch_seg_close(const KParams &P, int first_view, int n_views, float *dst, size_t dst_view_stride_points, void *stream);
+// register_point_clouds on segmented input: view first_view+k rotated by R4[4*k..], written at out + 3*(out_base[k] + offset)
+int launch_seg_register(const KParams &P, int view, float *out, const float R4[4], float tx, float ty, float tz, void *stream);
 // 8-byte words between the look-back status words of two neighbouring tiles.  8 = every word in a 64-byte line of its own:
 // neighbouring tiles publish from different XCDs at about the same time, and with the words packed those write-through
 // 8-byte stores (and the polls of them) contend for one line -- measured on the 16 x 1080p batch, three alternating runs:
@@ -115,6 +126,8 @@ int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view,
 #endif
 int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)
 int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream);  // raw: staged bytes in the layout of one mask plane
+int launch_to_colrow(const KParams &P, int view, int which, void *dst, void *stream);  // a global in the reference's [col][row] layout
+int launch_mask_from_colrow(const KParams &P, const int *sel, int gx0, int gy0, int ncols, int nrows, uint8_t *raw, void *stream);
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);
 int launch_cam_table(const KParams &P, const DevCal *d_cal, int kind, double *out, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);

@@ -891,10 +891,24 @@ __device__ __forceinline__ void triangulate_from(const KParams &P, CalP Cp, cons
 #ifndef SL3D_OCC_COMPACT
 #define SL3D_OCC_COMPACT 3
 #endif
-template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, bool COMPACT = false>
-__global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+// CMODE = 2 (sl3d_run_clouds, the default): the SEGMENTED ordered cloud -- no dependency between tiles at all.  A wave owns 256
+// consecutive pixels of the scan; it compacts ITS valid points (4 ballots + mbcnt, no block barrier, no LDS exchange) into its
+// own fixed slot of the cloud buffer -- points [256*seg, 256*seg + count) with seg = 4*tile + wave -- and stores the count.
+// Scan order is preserved inside a segment and across segments, so the cloud of a view is the concatenation of its segments;
+// k_compact_scan turns the counts into offsets, and the consumers that exist anyway close the gaps while they do their own
+// work (k_seg_close into a contiguous device / mapped host buffer, k_register_seg, the pack before an RCCL send).
+// Same traffic as the look-back kernel (47 + 1 + 12*valid_fraction B/px), none of its waiting.
+#ifndef SL3D_SEG_LDS
+#define SL3D_SEG_LDS 1 /* 1: a wave compacts its points inside its own 3 KB of the LDS staging area and stores whole 16-byte chunks (coalesced); 0: 12-byte stores per point */
+#endif
+#define SL3D_SEG_POINTS 256 /* pixels (point slots) per segment = one wave of the fused kernel */
+template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE = 0>
+__global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
-    static_assert(!(KEEP && COMPACT), "the parity mode writes dense planes");
+    constexpr bool COMPACT = CMODE == 1;  // the single-pass look-back compaction (everything named COMPACT below)
+    constexpr bool SEG = CMODE == 2;      // the segmented compaction
+    static_assert(!(KEEP && CMODE != 0), "the parity mode writes dense planes");
+    static_assert(!SEG || SL3D_BLOCK == 256, "a segment is one wave of a 256-thread block: 4 segments per 1024-pixel tile");
     static_assert(!COMPACT || SL3D_BLOCK != 256 || !SL3D_XCD_BANDS, "the look-back chains 1024-pixel tiles in ticket order");  // (other block sizes: A/B builds of the dense kernel only)
     __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];
     // COMPACT: valid pixels per wave of the current view, double-buffered by the parity of the block's view counter (a wave that
@@ -1239,6 +1253,57 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
 #pragma unroll
         for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
     };
+    // SEG: the wave's valid points of this view, compacted in scan order into the wave's own segment of the cloud buffer, and
+    // their count.  Needs nothing from any other wave: lanes that returned early (past the last row) just do not vote.
+    auto store_segment = [&](int view, size_t px, unsigned vout) {
+        *(unsigned *)(P.valid + px) = vout;
+        const unsigned long long b0 = __ballot((vout & 0x00000001u) != 0u), b1 = __ballot((vout & 0x00000100u) != 0u),
+                                 b2 = __ballot((vout & 0x00010000u) != 0u), b3 = __ballot((vout & 0x01000000u) != 0u);
+        auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+        unsigned rank = below(b0) + below(b1) + below(b2) + below(b3);  // valid pixels of the lanes below this one
+        const unsigned total = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+        const unsigned lane_ = threadIdx.x & 63u, wave_ = threadIdx.x >> 6;
+        const unsigned seg = tile * 4u + wave_;
+        if (lane_ == 0u) P.seg_counts[(size_t)view * (size_t)P.n_segs + seg] = total;
+        float *slot = P.clouds + 3 * ((size_t)view * P.px_view_stride + (size_t)seg * SL3D_SEG_POINTS);
+        if (SL3D_SEG_LDS) {
+            // in place, inside the wave's own 3 KB of the staging area: every lane first reads its 12 floats, then writes its
+            // valid points at their compacted position (<= its own: a wave's LDS instructions execute in order, so no lane's
+            // data is overwritten before it was read), then the wave stores ceil(3*total/4) whole 16-byte chunks, lane after
+            // lane: 1 KiB per store instruction.  (A chunk may run up to 3 floats past the last point: still inside the slot.)
+            const float4 *sx = (const float4 *)my_xyz;
+            const float4 a = sx[0], b = sx[1], c = sx[2];
+            const float q[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+            float *wbase = s_xyz + wave_ * (64u * 12u);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((vout >> (8 * k)) & 1u) {
+                    wbase[3 * rank + 0] = q[3 * k + 0];
+                    wbase[3 * rank + 1] = q[3 * k + 1];
+                    wbase[3 * rank + 2] = q[3 * k + 2];
+                    rank++;
+                }
+            const unsigned chunks = (3u * total + 3u) >> 2;
+            const float4 *wb4 = (const float4 *)wbase;
+            float4 *out4 = (float4 *)slot;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; c3++) {
+                const unsigned i = (unsigned)c3 * 64u + lane_;
+                if (i < chunks) out4[i] = wb4[i];
+            }
+        } else {
+            typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
+            float *dst = slot + 3 * (size_t)rank;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((vout >> (8 * k)) & 1u) {
+                    f32x3 pt;
+                    pt.x = my_xyz[3 * k + 0]; pt.y = my_xyz[3 * k + 1]; pt.z = my_xyz[3 * k + 2];
+                    *(f32x3 *)dst = pt;
+                    dst += 3;
+                }
+        }
+    };
 
     // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
     auto valid_bits = [&](const MaskQuad &m) -> unsigned {
@@ -1415,7 +1480,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
                 P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
             }
         }
-        if (!COMPACT && (KEEP || vbits == 0)) fill_nan();
+        if (!COMPACT && !SEG && (KEEP || vbits == 0)) fill_nan();
 
         if (!PIPE && vbits != 0) {
             // every load of the view is issued before the first one is consumed
@@ -1479,6 +1544,10 @@ __global__ __launch_bounds__(SL3D_BLOCK, COMPACT ? SL3D_OCC_COMPACT : SL3D_OCC) 
             gather_B(d);
             phase_B(vout, d);
         }
+        if (SEG) {
+            store_segment(view, px, vout);
+            continue;
+        }
         if (!COMPACT) {
             store_quad(px, vout);
             continue;
@@ -1534,7 +1603,7 @@ int fused_tiles(const KParams &P)
 
 // Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT: plane tests fold away)
 // and for the unroll bounds 8 / 12 / 16 otherwise; the parity mode and the 4-/5-step fringes use the bounds only.
-template <bool KEEP, bool FGEN, int RIG, bool COMPACT>
+template <bool KEEP, bool FGEN, int RIG, int COMPACT>
 static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     const int nmax = nv > nh ? nv : nh;
@@ -1555,7 +1624,7 @@ static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st
 #undef SL3D_LAUNCH
 }
 
-template <bool FGEN, bool COMPACT>
+template <bool FGEN, int COMPACT>
 static void launch_fused_rig(int rig, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     if (rig == 1) launch_fused_n<false, FGEN, 1, COMPACT>(P.Nv, P.Nh, grid, block, st, P, C, first_view, n_views, vpt);
@@ -1576,9 +1645,10 @@ static int views_per_lane(unsigned bx, int n_views)
 }
 
 // rig: 0 / 1 / 2, see pixel_chain (the host knows the calibration; folded at compile time in the timed kernels).
-// compact: the timed kernel writes compacted clouds (KParams::clouds / tile_status / cloud_totals must be set) instead of
-// the dense xyz plane.  Returns the hipError_t of THIS launch.
-int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, bool compact, void *stream,
+// compact: 1 = the timed kernel writes contiguous compacted clouds by a decoupled look-back (KParams::clouds / tile_status /
+// cloud_totals must be set), 2 = segmented clouds (KParams::clouds / seg_counts), instead of the dense xyz plane (0).
+// Returns the hipError_t of THIS launch.
+int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int compact, void *stream,
                  unsigned *tickets_drawn)
 {
     KParams P = P_;
@@ -1594,7 +1664,7 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 0) P.use_cam_table = 0;
 #endif
-    if (compact) {
+    if (compact == 1) {
         // persistent blocks that draw (tile, view group) items from the context's ticket counter: as many as the GPU holds at
         // once (more would only queue), each draws one ticket per item plus the one that tells it to stop
         const unsigned n_items = (unsigned)P.n_tiles * grid.y, slots = (unsigned)(P.n_cus > 0 ? P.n_cus : 256) * SL3D_OCC_COMPACT;
@@ -1606,14 +1676,16 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's
     if (keep) {
-        if (P.F == 3) launch_fused_n<true, false, 0, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_n<true, true, 0, false>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (P.F == 3) launch_fused_n<true, false, 0, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_n<true, true, 0, 0>(P.Nv, P.Nh, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else if (P.F != 3) {  // 4-step (and the all-invalid 5-step) fringes: the F test stays a run-time branch
-        if (compact) launch_fused_rig<true, true>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_rig<true, false>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (compact == 1) launch_fused_rig<true, 1>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else if (compact == 2) launch_fused_rig<true, 2>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_rig<true, 0>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        if (compact) launch_fused_rig<false, true>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
-        else launch_fused_rig<false, false>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        if (compact == 1) launch_fused_rig<false, 1>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else if (compact == 2) launch_fused_rig<false, 2>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
+        else launch_fused_rig<false, 0>(rig, grid, block, st, P, d_cal, first_view, n_views, vpt);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess && tickets_drawn) *tickets_drawn -= drawn;  // a launch that did not happen drew no tickets
@@ -2115,6 +2187,64 @@ int launch_compact_views(const KParams &P, int first_view, int n_views, unsigned
 }
 
 // ------------------------------------------------------------------------------------------------
+// Consumers of the SEGMENTED clouds the fused kernel writes (k_fused<..., CMODE = 2>): a view's cloud is the concatenation of
+// its segments' first `count` points.  One wave per segment, one point (12 bytes) per lane and step.
+// ------------------------------------------------------------------------------------------------
+int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream)
+{
+    (void)hipGetLastError();
+    // one 1024-thread block per view: offsets of the view's segments and the view's total (stored straight into the mapped host
+    // word sl3d_get_cloud_counts reads)
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_views), dim3(1024), 0, (hipStream_t)stream, P.seg_counts + (size_t)first_view * P.n_segs,
+                       P.seg_offsets + (size_t)first_view * P.n_segs, P.n_segs, P.cloud_totals + first_view);
+    return (int)hipGetLastError();
+}
+
+// REG = false: plain copy (closing the gaps); true: the rigid transform of k_register on the way (9/register_point_clouds.cpp:109-117)
+template <bool REG>
+__global__ __launch_bounds__(256) void k_seg_close(const float *__restrict__ seg_xyz, const unsigned *__restrict__ counts,
+                                                   const unsigned long long *__restrict__ offsets, int n_segs, size_t src_view_stride, float *dst,
+                                                   size_t dst_view_stride, float r00, float r02, float r20, float r22, float tx, float ty, float tz)
+{
+    typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
+    const int seg = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u), v = blockIdx.y;
+    if (seg >= n_segs) return;
+    const unsigned cnt = counts[(size_t)v * n_segs + seg];
+    const f32x3 *src = (const f32x3 *)(seg_xyz + 3 * ((size_t)v * src_view_stride + (size_t)seg * SL3D_SEG_POINTS));
+    f32x3 *out = (f32x3 *)(dst + 3 * ((size_t)v * dst_view_stride + (size_t)offsets[(size_t)v * n_segs + seg]));
+    for (unsigned i = (unsigned)lane; i < cnt; i += 64u) {
+        f32x3 p = src[i];
+        if (REG) {
+            const float x = p.x - tx, y = p.y - ty, z = p.z - tz;
+            const float X = (float)(((double)r00 * (double)x + 0.0 * (double)y) + (double)r02 * (double)z);
+            const float Y = (float)((0.0 * (double)x + 1.0 * (double)y) + 0.0 * (double)z);
+            const float Z = (float)(((double)r20 * (double)x + 0.0 * (double)y) + (double)r22 * (double)z);
+            p.x = X + tx; p.y = Y + ty; p.z = Z + tz;
+        }
+        out[i] = p;
+    }
+}
+
+int launch_seg_close(const KParams &P, int first_view, int n_views, float *dst, size_t dst_view_stride_points, void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_seg_close<false>, dim3((unsigned)((P.n_segs + 3) / 4), (unsigned)n_views), dim3(256), 0, (hipStream_t)stream,
+                       P.clouds + 3 * (size_t)first_view * P.px_view_stride, P.seg_counts + (size_t)first_view * P.n_segs,
+                       P.seg_offsets + (size_t)first_view * P.n_segs, P.n_segs, P.px_view_stride, dst, dst_view_stride_points, 0.f, 0.f, 0.f, 0.f, 0.f,
+                       0.f, 0.f);
+    return (int)hipGetLastError();
+}
+
+int launch_seg_register(const KParams &P, int view, float *out, const float R4[4], float tx, float ty, float tz, void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_seg_close<true>, dim3((unsigned)((P.n_segs + 3) / 4), 1u), dim3(256), 0, (hipStream_t)stream,
+                       P.clouds + 3 * (size_t)view * P.px_view_stride, P.seg_counts + (size_t)view * P.n_segs, P.seg_offsets + (size_t)view * P.n_segs,
+                       P.n_segs, P.px_view_stride, out, (size_t)0, R4[0], R4[1], R4[2], R4[3], tx, ty, tz);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // N3: turntable registration, 9/register_point_clouds.cpp:83-128.  Per point, in the reference's types:
 // p -= t (float), p = R*p with the float GEMM of cvMatMul (double accumulator, k ascending, rounded to float on
 // store), p += t (float).  R = rotation about Y by theta (row 1 and the last column are the identity's).
@@ -2250,6 +2380,84 @@ int launch_synth(const KParams &P, const DevCal &C, const SynthParams &S, int vi
 {
     const long quads = (long)(P.pitch >> 2) * P.H;
     hipLaunchKernelGGL(k_synth, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, C, S, view);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's global arrays in the reference's OWN layout: every image-shaped global is indexed [col][row]
+// (PROJECT_GLOBAL/common_variables.h:12-21,56-62), i.e. the transpose of the row-major planes the kernels write.  The transpose
+// is done HERE, through LDS tiles (32 x 32 elements: reads coalesced along the row of the source, writes coalesced along the
+// column-major destination), with the element conversion the reference's types ask for (valid bytes -> int), so that a global
+// reaches the caller as ONE contiguous device-to-host copy instead of a strided pass of the host over every plane
+// (3/wrapped_phase.cpp:165-175 is that access pattern, and SURVEY blames it for the reference's own slowness).
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO, int C>
+__global__ __launch_bounds__(256) void k_to_colrow(const TI *__restrict__ src, TO *__restrict__ dst, int W, int H, int pitch)
+{
+    __shared__ TO tile[32][32 * C + 1];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        if (r < H && c < W) {
+#pragma unroll
+            for (int k = 0; k < C; k++) tile[j][tx * C + k] = (TO)src[((size_t)r * pitch + c) * C + k];
+        }
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = bx + j, r = by + tx;
+        if (c < W && r < H) {
+#pragma unroll
+            for (int k = 0; k < C; k++) dst[((size_t)c * H + r) * C + k] = tile[tx][j * C + k];
+        }
+    }
+}
+
+// which: 0..2 valid maps (vertical, horizontal, merged) -> int; 3,4 wrapped; 5,6 unwrapped -> float; 7,8 code -> int;
+// 9 intersection_points -> double[3].  dst: [W][H] elements of the window.
+int launch_to_colrow(const KParams &P, int view, int which, void *dst, void *stream)
+{
+    const dim3 grid((unsigned)((P.W + 31) / 32), (unsigned)((P.H + 31) / 32)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t off = (size_t)view * P.px_view_stride;
+    (void)hipGetLastError();
+    switch (which) {
+    case 0: case 1: hipLaunchKernelGGL((k_to_colrow<uint8_t, int, 1>), grid, block, 0, st, P.valid_axis[which] + off, (int *)dst, P.W, P.H, P.pitch); break;
+    case 2: hipLaunchKernelGGL((k_to_colrow<uint8_t, int, 1>), grid, block, 0, st, P.valid + off, (int *)dst, P.W, P.H, P.pitch); break;
+    case 3: case 4: hipLaunchKernelGGL((k_to_colrow<float, float, 1>), grid, block, 0, st, P.wrapped[which - 3] + off, (float *)dst, P.W, P.H, P.pitch); break;
+    case 5: case 6: hipLaunchKernelGGL((k_to_colrow<float, float, 1>), grid, block, 0, st, P.unwrapped[which - 5] + off, (float *)dst, P.W, P.H, P.pitch); break;
+    case 7: case 8: hipLaunchKernelGGL((k_to_colrow<int32_t, int, 1>), grid, block, 0, st, P.code[which - 7] + off, (int *)dst, P.W, P.H, P.pitch); break;
+    case 9: hipLaunchKernelGGL((k_to_colrow<double, double, 3>), grid, block, 0, st, P.ipoints + 3 * off, (double *)dst, P.W, P.H, P.pitch); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+
+// selected_region as the reference holds it -- int [col][row] (m_tech_project_console.cpp:146-238) -- into the byte staging plane
+// k_mask_prepare reads: `sel` holds columns [gx0, gx0 + ncols) x rows [gy0, gy0 + nrows) of the frame, [col][row]; a pixel is
+// selected iff its int == 1.  Tiled the other way round: reads coalesced along the rows of a column, writes along the row.
+__global__ __launch_bounds__(256) void k_mask_from_colrow(const KParams P, const int *__restrict__ sel, int gx0, int gy0, int ncols, int nrows,
+                                                          uint8_t *__restrict__ raw)
+{
+    __shared__ uint8_t tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = bx + j, r = by + tx;
+        if (c < ncols && r < nrows) tile[j][tx] = sel[(size_t)c * nrows + r] == 1 ? 1 : 0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        if (c < ncols && r < nrows)
+            raw[(size_t)(gy0 + r - P.row0 + SL3D_MASK_HALO) * P.mpitch + SL3D_MASK_LPAD + (gx0 + c - P.col0)] = tile[tx][j];
+    }
+}
+
+int launch_mask_from_colrow(const KParams &P, const int *sel, int gx0, int gy0, int ncols, int nrows, uint8_t *raw, void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_mask_from_colrow, dim3((unsigned)((ncols + 31) / 32), (unsigned)((nrows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, P, sel, gx0,
+                       gy0, ncols, nrows, raw);
     return (int)hipGetLastError();
 }
 

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SL3D_LIB") or os.path.join(_HERE, "libsl3d.so")
 
 SL3D_FLAG_KEEP_STAGES = 1
 SL3D_FLAG_GROUP_FORCE_RCCL, SL3D_FLAG_GROUP_NO_RCCL = 2, 4
+SL3D_FLAG_CLOUDS_LOOKBACK = 8
 AXIS_VERTICAL, AXIS_HORIZONTAL = 0, 1
 PATTERN_FRINGE, PATTERN_GRAY, PATTERN_INVERSE_GRAY, PATTERN_BINARY = 0, 1, 2, 3
 VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
@@ -20,16 +21,16 @@ VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
 # every symbol include/sl3d.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
-    "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
+    "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_mask_colrow", "sl3d_set_frames_range", "sl3d_get_global_colrow", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
-    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
+    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
     "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
-    "sl3d_get_device_buffers", "sl3d_download",
+    "sl3d_get_device_buffers", "sl3d_download", "sl3d_download_2d",
     "sl3d_group_create", "sl3d_group_destroy", "sl3d_group_last_error", "sl3d_group_size", "sl3d_group_stripe", "sl3d_group_transport",
     "sl3d_group_set_calibration", "sl3d_group_set_mask", "sl3d_group_set_frames", "sl3d_group_run", "sl3d_group_gather",
-    "sl3d_group_get_points", "sl3d_group_get_device_buffers", "sl3d_group_run_clouds", "sl3d_group_gather_clouds",
+    "sl3d_group_get_points", "sl3d_group_download_points", "sl3d_group_process_views", "sl3d_group_get_device_buffers", "sl3d_group_run_clouds", "sl3d_group_gather_clouds",
     "sl3d_group_get_cloud", "sl3d_group_synchronize",
 )
 
@@ -53,6 +54,11 @@ class DeviceBuffers(C.Structure):
         ("points", C.c_void_p), ("points_pitch", C.c_size_t), ("points_view_stride", C.c_size_t),
         ("valid", C.c_void_p), ("valid_pitch", C.c_size_t), ("valid_view_stride", C.c_size_t),
     ]
+
+
+class CloudSegments(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("counts", C.c_void_p), ("offsets", C.c_void_p), ("n_segments", C.c_int32), ("segment_points", C.c_int32),
+                ("view_stride_points", C.c_size_t), ("view_stride_segments", C.c_size_t)]
 
 
 _lib = None
@@ -81,6 +87,9 @@ def load_library(path=None):
     L.sl3d_get_projection_matrices.argtypes = [vp, vp, vp]
     L.sl3d_set_mask.argtypes = [vp, i, vp, C.c_size_t]
     L.sl3d_set_frames.argtypes = [vp, i, i, vp, i, C.c_size_t]
+    L.sl3d_set_mask_colrow.argtypes = [vp, i, vp]
+    L.sl3d_set_frames_range.argtypes = [vp, i, i, i, vp, i, C.c_size_t]
+    L.sl3d_get_global_colrow.argtypes = [vp, i, i, vp, i, i]
     for n in ("sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_copy_view"):
         getattr(L, n).argtypes = [vp, i, i]
     for n in ("sl3d_compute_c_p_map", "sl3d_triangulate"):
@@ -90,6 +99,9 @@ def load_library(path=None):
     L.sl3d_run.argtypes = [vp, i, i]
     L.sl3d_run_clouds.argtypes = [vp, i, i]
     L.sl3d_get_cloud_counts.argtypes = [vp, i, i, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
+    L.sl3d_get_cloud_segments.argtypes = [vp, i, i, C.POINTER(CloudSegments), C.POINTER(C.c_int64)]
+    L.sl3d_download_clouds.argtypes = [vp, i, i, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sl3d_register_clouds.argtypes = [vp, i, i, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_run_timed.argtypes = [vp, i, i, C.POINTER(C.c_float)]
     L.sl3d_synchronize.argtypes = [vp]
     L.sl3d_timer_start.argtypes = [vp]
@@ -119,6 +131,7 @@ def load_library(path=None):
     L.sl3d_generate_pattern.argtypes = [vp, i, i, i, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sl3d_transform_cloud.argtypes = [vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.sl3d_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.sl3d_download_2d.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
     L.sl3d_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
     L.sl3d_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), i, C.POINTER(vp)]
     L.sl3d_group_destroy.argtypes = [vp]
@@ -136,6 +149,8 @@ def load_library(path=None):
         getattr(L, n).argtypes = [vp, i, i]
     L.sl3d_group_gather_clouds.argtypes = [vp, i, i, C.POINTER(C.c_int64)]
     L.sl3d_group_get_points.argtypes = [vp, i, vp, vp]
+    L.sl3d_group_download_points.argtypes = [vp, i, i, vp, vp]
+    L.sl3d_group_process_views.argtypes = [vp, i, vp, C.c_size_t, vp, vp]
     L.sl3d_group_get_device_buffers.argtypes = [vp, C.POINTER(DeviceBuffers)]
     L.sl3d_group_get_cloud.argtypes = [vp, i, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_group_synchronize.argtypes = [vp]
@@ -159,12 +174,12 @@ class Scanner:
 
     def __init__(self, width, height, proj_width, proj_height, n_gray_v, n_gray_h, fringe_width_v, fringe_width_h,
                  n_fringe=3, n_codes_v=0, n_codes_h=0, max_views=1, device=0, keep_stages=False,
-                 full_size=None, origin=(0, 0), stream=None):
+                 full_size=None, origin=(0, 0), stream=None, clouds_lookback=False):
         self.L = load_library()
         fw, fh = full_size if full_size else (width, height)
         self.cfg = Config(width, height, fw, fh, origin[0], origin[1], proj_width, proj_height, n_fringe,
                           n_gray_v, n_gray_h, fringe_width_v, fringe_width_h, n_codes_v, n_codes_h,
-                          max_views, device, SL3D_FLAG_KEEP_STAGES if keep_stages else 0, stream)
+                          max_views, device, (SL3D_FLAG_KEEP_STAGES if keep_stages else 0) | (SL3D_FLAG_CLOUDS_LOOKBACK if clouds_lookback else 0), stream)
         self.W, self.H = width, height
         self._h = C.c_void_p()
         rc = self.L.sl3d_create(C.byref(self.cfg), C.byref(self._h))
@@ -219,6 +234,29 @@ class Scanner:
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         self._chk(self.L.sl3d_set_frames(self._h, view, axis, ptrs, len(arrs), arrs[0].strides[0]), "sl3d_set_frames")
 
+    def set_mask_colrow(self, selected_region, view=0):
+        """selected_region as the reference holds it: int32 array [full_width][full_height] ([col][row]), selected iff == 1."""
+        m = np.ascontiguousarray(selected_region, dtype=np.int32)
+        assert m.shape == (self.cfg.full_width, self.cfg.full_height), m.shape
+        self._chk(self.L.sl3d_set_mask_colrow(self._h, view, m.ctypes.data), "sl3d_set_mask_colrow")
+
+    def set_frames_range(self, axis, first_plane, planes, view=0):
+        arrs = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+        for a in arrs:
+            assert a.shape == (self.H, self.W), a.shape
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._chk(self.L.sl3d_set_frames_range(self._h, view, axis, first_plane, ptrs, len(arrs), arrs[0].strides[0]), "sl3d_set_frames_range")
+
+    def global_colrow(self, which, view=0, out=None, row0=0):
+        """One of the reference's globals in its own [col][row] layout and type (sl3d_get_global_colrow); `out`: a [W][H_total(,3)]
+        array this window's rows are written into at row offset row0 (default: a fresh [W][H] array)."""
+        dt, comps = (np.float64, 3) if which == 9 else (np.float32, 1) if 3 <= which <= 6 else (np.int32, 1)
+        if out is None:
+            out = np.empty((self.W, self.H) + ((3,) if comps == 3 else ()), dtype=dt)
+        assert out.dtype == dt and out.flags["C_CONTIGUOUS"] and out.shape[0] == self.W
+        self._chk(self.L.sl3d_get_global_colrow(self._h, view, which, out.ctypes.data, out.shape[1], row0), "sl3d_get_global_colrow")
+        return out
+
     def set_frames_raw(self, axis, planes, view=0):
         """set_frames for raw captures: undistorted on the device with the camera calibration (whole frames only)."""
         arrs = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
@@ -271,12 +309,46 @@ class Scanner:
         """The fused pass with the ordered compaction inside the kernel (sl3d_run_clouds); asynchronous."""
         self._chk(self.L.sl3d_run_clouds(self._h, first_view, n_views), "sl3d_run_clouds")
 
-    def cloud_counts(self, first_view=0, n_views=1):
-        """(device address of the first cloud, points between clouds, [count per view]) after run_clouds; synchronises."""
+    def cloud_counts(self, first_view=0, n_views=1, want_device_copy=True):
+        """(device address of the first CONTIGUOUS cloud, points between clouds, [count per view]) after run_clouds; synchronises.
+        want_device_copy=False: counts only (address None) -- segmented clouds then need no gap-closing launch."""
         counts = (C.c_int64 * n_views)()
         ptr, stride = C.c_void_p(), C.c_size_t()
-        self._chk(self.L.sl3d_get_cloud_counts(self._h, first_view, n_views, C.byref(ptr), C.byref(stride), counts), "sl3d_get_cloud_counts")
+        self._chk(self.L.sl3d_get_cloud_counts(self._h, first_view, n_views, C.byref(ptr) if want_device_copy else None, C.byref(stride), counts),
+                  "sl3d_get_cloud_counts")
         return ptr.value, stride.value, [int(c) for c in counts]
+
+    def cloud_segments(self, first_view=0, n_views=1):
+        """(CloudSegments, [count per view]): the segmented clouds of the last run_clouds where they lie in HBM."""
+        seg = CloudSegments()
+        counts = (C.c_int64 * n_views)()
+        self._chk(self.L.sl3d_get_cloud_segments(self._h, first_view, n_views, C.byref(seg), counts), "sl3d_get_cloud_segments")
+        return seg, [int(c) for c in counts]
+
+    def download_clouds(self, first_view=0, n_views=1, out=None):
+        """Host copies of the clouds of the last run_clouds: list of (n_k, 3) float32 arrays (views of `out`, a flat float32 buffer --
+        pinned for the zero-copy route -- or of a fresh array)."""
+        counts = (C.c_int64 * n_views)()
+        self._chk(self.L.sl3d_download_clouds(self._h, first_view, n_views, None, 0, counts), "sl3d_download_clouds")
+        total = sum(counts)
+        if out is None:
+            out = np.empty(max(total, 1) * 3, dtype=np.float32)
+        assert out.dtype == np.float32 and out.size >= 3 * total
+        self._chk(self.L.sl3d_download_clouds(self._h, first_view, n_views, out.ctypes.data, out.size // 3, counts), "sl3d_download_clouds")
+        res, off = [], 0
+        for n in counts:
+            res.append(out[3 * off:3 * (off + n)].reshape(n, 3))
+            off += n
+        return res
+
+    def register_clouds(self, first_view, n_views, tx, ty, tz, rot_step):
+        """register_views on the clouds of the last run_clouds (rotation applied while the segments are concatenated)."""
+        n = C.c_int64(0)
+        self._chk(self.L.sl3d_register_clouds(self._h, first_view, n_views, tx, ty, tz, rot_step, None, 0, C.byref(n)), "sl3d_register_clouds")
+        out = np.empty((n.value, 3), dtype=np.float32)
+        self._chk(self.L.sl3d_register_clouds(self._h, first_view, n_views, tx, ty, tz, rot_step, out.ctypes.data, n.value, C.byref(n)),
+                  "sl3d_register_clouds")
+        return out
 
     def fused_clouds(self, first_view=0, n_views=1):
         """run_clouds + host copies: list of (n_k, 3) float32 arrays in the reference's scan order."""
@@ -347,6 +419,18 @@ class Scanner:
         valid = np.empty((self.H, self.W), dtype=np.uint8)
         self._chk(self.L.sl3d_get_points(self._h, view, xyz.ctypes.data, valid.ctypes.data), "sl3d_get_points")
         return xyz, valid
+
+    def download_views(self, first_view, n_views, xyz, valid):
+        """Dense results of views [first_view, first_view + n_views) into caller arrays (n, H, W, 3) f32 / (n, H, W) u8 (pinned
+        for full-rate DMA): one 2-D copy per view and plane, one wait."""
+        assert xyz.shape == (n_views, self.H, self.W, 3) and valid.shape == (n_views, self.H, self.W)
+        b = self.device_buffers()
+        for k in range(n_views):
+            self._chk(self.L.sl3d_download_2d(self._h, xyz[k].ctypes.data, self.W * 12, b.points + (first_view + k) * b.points_view_stride,
+                                              b.points_pitch, self.W * 12, self.H), "sl3d_download_2d")
+            self._chk(self.L.sl3d_download_2d(self._h, valid[k].ctypes.data, self.W, b.valid + (first_view + k) * b.valid_view_stride,
+                                              b.valid_pitch, self.W, self.H), "sl3d_download_2d")
+        self.synchronize()
 
     def cloud(self, view=0):
         n = C.c_int64(0)
@@ -526,6 +610,28 @@ class Group:
         xyz = np.empty((self.H, self.W, 3), dtype=np.float32)
         valid = np.empty((self.H, self.W), dtype=np.uint8)
         self._chk(self.L.sl3d_group_get_points(self._h, view, xyz.ctypes.data, valid.ctypes.data), "sl3d_group_get_points")
+        return xyz, valid
+
+    def download_points(self, first_view=0, n_views=1, xyz=None, valid=None):
+        """Every stripe's rows straight into the caller's dense host images (no gather to the root): (n, H, W, 3) f32, (n, H, W) u8."""
+        if xyz is None:
+            xyz = np.empty((n_views, self.H, self.W, 3), dtype=np.float32)
+        if valid is None:
+            valid = np.empty((n_views, self.H, self.W), dtype=np.uint8)
+        assert xyz.shape == (n_views, self.H, self.W, 3) and valid.shape == (n_views, self.H, self.W)
+        self._chk(self.L.sl3d_group_download_points(self._h, first_view, n_views, xyz.ctypes.data, valid.ctypes.data), "sl3d_group_download_points")
+        return xyz, valid
+
+    def process_views(self, frames, xyz=None, valid=None):
+        """frames: (n_views, planes_per_view, H, W) uint8 host array (pinned for concurrent DMA); returns (xyz, valid) dense images."""
+        n, ppv, H, W = frames.shape
+        assert (H, W) == (self.H, self.W) and frames.dtype == np.uint8 and frames.strides[3] == 1 and frames.strides[2] >= W
+        if xyz is None:
+            xyz = np.empty((n, H, W, 3), dtype=np.float32)
+        if valid is None:
+            valid = np.empty((n, H, W), dtype=np.uint8)
+        ptrs = (C.c_void_p * (n * ppv))(*[frames[v, p].ctypes.data for v in range(n) for p in range(ppv)])
+        self._chk(self.L.sl3d_group_process_views(self._h, n, ptrs, frames.strides[2], xyz.ctypes.data, valid.ctypes.data), "sl3d_group_process_views")
         return xyz, valid
 
     def run_clouds(self, first_view=0, n_views=1):

@@ -217,9 +217,9 @@ def side_figures(args, scm, syn, np, dev_index):
     out = {}
     full_mask = syn.default_mask(W, H)
 
-    def ctx(rig, n_gray, views, proj=None):
+    def ctx(rig, n_gray, views, proj=None, **kw):
         PW, PH = (proj, min(proj, H)) if proj else (W, H)
-        sc = scm.Scanner(W, H, PW, PH, n_gray, n_gray, fw, fw, max_views=views, device=dev_index)
+        sc = scm.Scanner(W, H, PW, PH, n_gray, n_gray, fw, fw, max_views=views, device=dev_index, **kw)
         sc.set_calibration(*rig_calibration(syn, np, rig, W, H, PW, PH))
         for v in range(views):
             sc.set_mask(full_mask, view=v)
@@ -232,6 +232,11 @@ def side_figures(args, scm, syn, np, dev_index):
             v, f, ms = steady_rate(sc, 1, W * H, 20 + 4 * N, 2000)
             out["one_view_latency"] = {"value": v, "unit": "Mpixels/s", "frac": f, "launch_us": round(ms * 1e3, 2),
                                        "note": "1 view per launch, back to back; the 124 MB working set sits in the Infinity Cache"}
+        # the other way to ordered clouds, same workload, same box: contiguous clouds in one pass by a decoupled look-back
+        # (SL3D_FLAG_CLOUDS_LOOKBACK); `to_compacted_clouds` above is the segmented default
+        with ctx("reference", N, args.views, clouds_lookback=True) as sc:
+            v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 300, clouds=True)
+            out["clouds_lookback_kernel_only"] = {"value": v, "unit": "Mpixels/s", "ms_per_launch": ms}
         for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig0_general")):
             with ctx(rig, N, args.views) as sc:
                 v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 400)
@@ -241,6 +246,14 @@ def side_figures(args, scm, syn, np, dev_index):
             out[f"n_gray_{N - 1}"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "algorithmic_bytes_per_pixel": 20 + 4 * (N - 1)}
     except Exception as e:
         out["error"] = repr(e)
+    # the Level-1 drop-in path: the reference's six stage calls + save_point_cloud() through the shim at the reference's own
+    # 1600x1200 (tools/shim_bench.cpp: host wall time per scan, BMP files / memory, device-side [col][row] globals vs host transposes)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import shim_timing
+        out["shim_scan_ms"] = shim_timing.run(scans=5)
+    except Exception as e:
+        out["shim_scan_ms"] = {"error": repr(e)}
     return out
 
 
@@ -355,7 +368,7 @@ def main():
     exact = 6 <= N <= 12                                   # the instantiation launch_fused picks (sl3d_kernels.hip)
     nmax = N if exact else next(m for m in (8, 12, 16) if m >= N)
     rig_id = {"reference": 1, "distorted": 2, "general": 0}[args.rig]
-    kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if exact else 'false'}, {rig_id}, false>"
+    kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if exact else 'false'}, {rig_id}, 0>"
     traffic, traffic_src = measured_traffic(px_per_launch) if alg_bytes_px == 60 else (None, None)
 
     out = {
@@ -393,7 +406,7 @@ def main():
         try:
             for _ in range(20):
                 sc.run_clouds(0, n_views)
-            counts = sc.cloud_counts(0, n_views)[2]
+            counts = sc.cloud_counts(0, n_views, want_device_copy=False)[2]
         except Exception as e:
             cl_err = repr(e)
     if all_ok(cl_err is None):
@@ -402,7 +415,7 @@ def main():
         try:
             for _ in range(reps):
                 sc.run_clouds(0, n_views)
-                counts = sc.cloud_counts(0, n_views)[2]
+                counts = sc.cloud_counts(0, n_views, want_device_copy=False)[2]
         except Exception as e:
             cl_err = repr(e)
         barrier()
@@ -431,8 +444,10 @@ def main():
                                       "roofline": {"bound": "hbm", "achieved": round(cl_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                    "frac": round(cl_achieved / HBM_PEAK_GBS, 4), "traffic": cl_traffic,
                                                    "traffic_source": cl_traffic_src and f"{cl_traffic_src} (committed PMC run of this command, scaled to this launch; not measured in this run)",
-                                                   "kernel": kernel_name.replace(", false>", ", true>"), "avg_launch_ms": round(kms, 4)},
-                                      "how": "one launch: ordered compaction inside the fused kernel (decoupled look-back over 1024-pixel tiles)"}
+                                                   "kernel": kernel_name.replace(", false>", ", 2>"), "avg_launch_ms": round(kms, 4)},
+                                      "how": "sl3d_run_clouds: the fused kernel writes SEGMENTED ordered clouds (every wave compacts its 256 scan pixels into its own "
+                                             "slot: no tile waits for another) + one scan launch for offsets and totals; value = launches + the wait for the "
+                                             "per-view counts; kernel_only = both launches between HIP events"}
     else:
         out["to_compacted_clouds"] = {"error": cl_err}
 
@@ -552,6 +567,7 @@ def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, 
     (every rank assembles its share of the views: all links busy), as one blocking collective after the compute."""
     res = {}
     nccl = args.backend == "nccl"
+    import numpy as np_mod
     try:
         b = sc.device_buffers()
         pitch = b.frame_pitch
@@ -606,6 +622,27 @@ def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, 
                 h.update(out_pts[v].view(H, pitch, 3)[:, :W].contiguous().cpu().numpy().tobytes())
                 h.update(out_val[v][:, :W].contiguous().cpu().numpy().tobytes())
             digests["dense_sha256"] = h.hexdigest()
+
+        # ---- host_parallel: the reference's consumer is the HOST -- every rank downloads its own rows of every view over its own
+        # GPU's PCIe link (what sl3d_group_download_points does for a single-process caller), no xGMI hop to a root ----
+        try:
+            hp = sc.pinned((n_views, rows, W, 3), np_mod.float32)
+            hv = sc.pinned((n_views, rows, W), np_mod.uint8)
+            herr = None
+        except Exception as e:
+            herr = repr(e)
+
+        def host_step(first):
+            for k, (f, n) in enumerate(chunks):
+                sc.run(f, n)
+            if herr is None:
+                sc.download_views(0, n_views, hp, hv)     # 2-D copies on the compute stream, then one wait
+
+        t = timed(host_step, max(2, reps // 4))
+        res["host_parallel"] = ({"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 3),
+                                 "bytes_to_host_per_rank_per_step": int(n_views * rows * W * 13),
+                                 "note": "every rank: fused kernel, then its own rows of every view D2H into pinned host memory over its own PCIe link"}
+                                if herr is None else {"error": herr})
 
         # ---- compact: the valid points only, compacted by the fused kernel ----
         sc.run_clouds(0, n_views)

@@ -60,7 +60,11 @@ enum sl3d_flags {
     /* sl3d_group_create only.  FORCE_RCCL: every stripe but the root's own travels by RCCL send/recv even when it shares the
      * root's GPU (exercises the RCCL path on a single-GPU box); NO_RCCL: (peer) device copies even across GPUs. */
     SL3D_FLAG_GROUP_FORCE_RCCL = 2u,
-    SL3D_FLAG_GROUP_NO_RCCL = 4u
+    SL3D_FLAG_GROUP_NO_RCCL = 4u,
+    /* sl3d_run_clouds writes every view's cloud CONTIGUOUSLY in one pass (tile prefixes by a decoupled look-back between the
+     * blocks of the launch: ordered, but every tile waits for its predecessors) instead of the default SEGMENTED clouds (no
+     * waiting; see sl3d_run_clouds).  Pays when the only consumer is a device kernel that needs one contiguous array. */
+    SL3D_FLAG_CLOUDS_LOOKBACK = 8u
 };
 
 /* Replaces the compile-time macros and initialised globals of the reference:
@@ -150,6 +154,16 @@ int sl3d_set_mask(sl3d_ctx *ctx, int view, const uint8_t *full_frame_mask, size_
  * at plane i + stride*height) go up as ONE 2-D copy per axis.  Pageable / pinned memory: as for sl3d_set_mask. */
 int sl3d_set_frames(sl3d_ctx *ctx, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride);
 
+/* selected_region exactly as the reference holds it: int [full_width][full_height], indexed [col][row]
+ * (m_tech_project_console.cpp:146-238, common_variables.h), selected iff == 1.  The window's columns (+ halo) go up as one 2-D
+ * copy and are transposed into the byte mask on the device; no pass of the host over the array. */
+int sl3d_set_mask_colrow(sl3d_ctx *ctx, int view, const int32_t *selected_region);
+
+/* n_planes planes of one axis starting at plane index first_plane of sl3d_set_frames' order (fringe[0..F), gray[0..N),
+ * inverse_gray[0..N)): stage 3 loads only the F fringe frames (read_image, 3/wrapped_phase.cpp:29-58), stage 4 only the Gray /
+ * inverse frames (read_captured_images, 4/phase_unwrap.cpp:51-131). */
+int sl3d_set_frames_range(sl3d_ctx *ctx, int view, int axis, int first_plane, const uint8_t *const *planes, int n_planes, size_t stride);
+
 /* Device-to-device duplicate of one resident view (frame stack + mask) into another slot of the batch. */
 int sl3d_copy_view(sl3d_ctx *ctx, int src_view, int dst_view);
 
@@ -177,15 +191,48 @@ int sl3d_triangulate(sl3d_ctx *ctx, int view);
  * float cast of 8/save_point_cloud.cpp:100-102, for views [first_view, first_view+n_views), as ONE
  * kernel launch that reads every frame byte once and writes xyz (f32) + valid (u8). Asynchronous. */
 int sl3d_run(sl3d_ctx *ctx, int first_view, int n_views);
-/* The same pass with the compaction of 8/save_point_cloud.cpp:33-37,85-104 INSIDE the kernel: instead of the dense xyz plane
- * every view's valid points are written once, already compacted in the reference's row-major scan order (tile prefixes by a
- * decoupled look-back between the blocks of the launch), plus the valid map.  ~47 + 12*valid_fraction + 1 bytes per pixel
- * instead of 60 for the dense pass + 25 for a separate compaction.  Timed mode only (no SL3D_FLAG_KEEP_STAGES).  Asynchronous;
+/* The same pass with the compaction of 8/save_point_cloud.cpp:33-37,85-104 INSIDE the kernel: instead of the dense xyz plane every
+ * view's valid points are written once, compacted in the reference's row-major scan order, plus the valid map:
+ * ~47 + 12*valid_fraction + 1 bytes per pixel instead of 60 for the dense pass + 25 for a separate compaction.  Timed mode only
+ * (no SL3D_FLAG_KEEP_STAGES).  Asynchronous.
+ *   Default: SEGMENTED clouds.  Every wave of the kernel compacts the 256 consecutive scan pixels it owns into its own fixed slot
+ *   (points [256*s, 256*s + count_s) of the view's region) and stores count_s; a small scan kernel turns the counts into offsets.
+ *   No tile ever waits for another one, scan order is preserved inside and across segments, so a view's cloud is the
+ *   concatenation of its segments -- and the consumers that exist anyway close the gaps for free: sl3d_download_clouds (host
+ *   copy), sl3d_register_clouds (turntable registration), the pack before a group's RCCL send, or any device consumer through
+ *   sl3d_get_cloud_segments.
+ *   With SL3D_FLAG_CLOUDS_LOOKBACK: contiguous clouds in the same single pass (decoupled look-back between tiles).
  * sl3d_get_cloud_counts synchronises and returns, for views [first_view, first_view+n_views), the number of points of each
- * cloud and where they are in HBM: view first_view+k's cloud is counts[k] points (3 floats each) at
- * *device_xyz + 3*k*(*view_stride_points), valid until the next sl3d_run_clouds / sl3d_compact_views on this context. */
+ * cloud; with device_xyz != NULL also a CONTIGUOUS device copy: view first_view+k's cloud is counts[k] points (3 floats each) at
+ * *device_xyz + 3*k*(*view_stride_points), valid until the next sl3d_run_clouds / sl3d_compact_views on this context (segmented
+ * mode: produced on demand by one gap-closing launch; pass NULL if only the counts are wanted). */
 int sl3d_run_clouds(sl3d_ctx *ctx, int first_view, int n_views);
 int sl3d_get_cloud_counts(sl3d_ctx *ctx, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts);
+
+/* The segmented clouds themselves, for consumers that stay on the device (not available with SL3D_FLAG_CLOUDS_LOOKBACK):
+ * segment s of view first_view+k holds counts[k*view_stride_segments + s] points at xyz + 3*(k*view_stride_points +
+ * s*segment_points); its first point is point number offsets[k*view_stride_segments + s] of the view's cloud. */
+typedef struct sl3d_cloud_segments {
+    const float *xyz;
+    const uint32_t *counts;
+    const uint64_t *offsets;
+    int32_t n_segments;            /* per view */
+    int32_t segment_points;        /* point slots per segment (256) */
+    size_t view_stride_points;
+    size_t view_stride_segments;   /* = n_segments */
+} sl3d_cloud_segments;
+int sl3d_get_cloud_segments(sl3d_ctx *ctx, int first_view, int n_views, sl3d_cloud_segments *out, int64_t *counts);
+
+/* The reference's consumer is the host (8/save_point_cloud.cpp:85-104 fills a host pcl::PointCloud): the clouds of views
+ * [first_view, first_view+n_views) of the last sl3d_run_clouds, back to back in host memory (at most `capacity` points in all;
+ * xyz may be NULL: counts only).  Segmented mode + pinned memory (sl3d_host_alloc): the gap-closing kernel writes the host
+ * buffer directly; otherwise a contiguous device copy is downloaded.  Synchronises. */
+int sl3d_download_clouds(sl3d_ctx *ctx, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts);
+
+/* sl3d_register_views on the clouds of the last sl3d_run_clouds (no dense planes, no separate compaction): the rotation of
+ * 9/register_point_clouds.cpp:83-128 is applied while the segments are concatenated. */
+int sl3d_register_clouds(sl3d_ctx *ctx, int first_view, int n_views, float tx, float ty, float tz, float rot_step, float *xyz, int64_t capacity,
+                         int64_t *total);
 /* sl3d_run bracketed by HIP events on the context's stream; returns the kernel time of this launch */
 int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);
 int sl3d_synchronize(sl3d_ctx *ctx);
@@ -213,6 +260,19 @@ int sl3d_get_c_p_map(sl3d_ctx *ctx, int view, int64_t *out);
 int sl3d_get_intersection_points(sl3d_ctx *ctx, int view, double *out);
 /* dense f32 points [H][W][3] (NaN where invalid) + merged valid map [H][W]; either may be NULL */
 int sl3d_get_points(sl3d_ctx *ctx, int view, float *xyz, uint8_t *valid);
+/* One of the reference's image-shaped globals in the reference's OWN layout and types (common_variables.h:12-21,56-62: every one
+ * is indexed [col][row]): transposed and converted on the device, then ONE contiguous copy into the caller's array.
+ *   which: SL3D_G_VALID_V / _H / SL3D_G_VALID -> int [W][H]; SL3D_G_WRAPPED_V / _H, SL3D_G_UNWRAPPED_V / _H -> float [W][H];
+ *          SL3D_G_CODE_V / _H -> int [W][H]; SL3D_G_INTERSECTION_POINTS -> double [W][H][3]
+ *   out: element (col, row) of this context's window is written at out[col * out_height + out_row0 + row]: a whole-frame
+ *        context passes (height, 0); a row stripe of a taller array passes the array's height and its own first row, and
+ *        writes only its rows of every column.  Needs SL3D_FLAG_KEEP_STAGES.  Synchronises. */
+enum sl3d_global {
+    SL3D_G_VALID_V = 0, SL3D_G_VALID_H = 1, SL3D_G_VALID = 2, SL3D_G_WRAPPED_V = 3, SL3D_G_WRAPPED_H = 4,
+    SL3D_G_UNWRAPPED_V = 5, SL3D_G_UNWRAPPED_H = 6, SL3D_G_CODE_V = 7, SL3D_G_CODE_H = 8, SL3D_G_INTERSECTION_POINTS = 9
+};
+int sl3d_get_global_colrow(sl3d_ctx *ctx, int view, int which, void *out, int out_height, int out_row0);
+
 /* the compacted cloud of 8/save_point_cloud.cpp:85-104: valid points in row-major scan order;
  * writes at most `capacity` points, always returns the total count in *count */
 int sl3d_get_cloud(sl3d_ctx *ctx, int view, float *xyz, int64_t capacity, int64_t *count);
@@ -299,6 +359,9 @@ int sl3d_get_device_buffers(sl3d_ctx *ctx, sl3d_device_buffers *out);
 /* Copy `bytes` from a device address this library handed out (sl3d_get_cloud_counts, sl3d_compact, sl3d_compact_views,
  * sl3d_get_device_buffers) to host memory, ordered after the context's work; synchronises. */
 int sl3d_download(sl3d_ctx *ctx, void *host_dst, const void *device_src, size_t bytes);
+/* the same for a pitched region (`height` rows of `width_bytes`), ENQUEUED on the context's stream: asynchronous for pinned host
+ * memory (the caller waits with sl3d_synchronize), so many regions can be queued behind one wait */
+int sl3d_download_2d(sl3d_ctx *ctx, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes, size_t height);
 
 /* ---- several GPUs behind one caller: row-stripe groups -------------------------------------------------------------
  * The reference is ONE process that scans one view after the other (m_tech_project_console.cpp:366-395); a group lets that
@@ -342,6 +405,16 @@ int sl3d_group_gather(sl3d_group *g, int first_view, int n_views);
 /* the assembled dense results of a view (window-sized [height][width][3] f32, NaN where invalid; [height][width] valid);
  * waits for the gather of that view; either pointer may be NULL */
 int sl3d_group_get_points(sl3d_group *g, int view, float *xyz, uint8_t *valid);
+/* The assembly for the reference's real consumer, the HOST (its results are host globals / a host cloud: common_variables.h:12-21,
+ * 56-62, 8/save_point_cloud.cpp:85-104): views [first_view, first_view+n_views) as n_views dense [height][width][3] float images
+ * (NaN where invalid) and [height][width] valid bytes; either pointer may be NULL.  Every stripe copies its rows straight into
+ * the caller's images on its own stream and over its own GPU's PCIe link -- no gather to a root, no xGMI hop.  Use pinned
+ * memory (sl3d_host_alloc) for concurrent DMA.  Waits for the stripes' kernels and for the copies. */
+int sl3d_group_download_points(sl3d_group *g, int first_view, int n_views, float *xyz, uint8_t *valid);
+/* sl3d_process_views for a group: host-resident views through every stripe's three-stream pipeline (upload of its rows,
+ * kernel, download into the caller's dense images); the stripes work concurrently.  planes: n_views * planes_per_view
+ * pointers to window-sized planes, view-major. */
+int sl3d_group_process_views(sl3d_group *g, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid);
 /* the assembled buffers in the root GPU's memory, for consumers that stay on the device (layout of sl3d_device_buffers'
  * points / valid with the window's height; frames / mask members are not filled) */
 int sl3d_group_get_device_buffers(sl3d_group *g, sl3d_device_buffers *out);

@@ -16,6 +16,8 @@
 #ifndef SL3D_SHIM_H
 #define SL3D_SHIM_H
 
+#include <stddef.h>
+
 #ifndef Camera_imagewidth
 #define Camera_imagewidth 1600
 #endif
@@ -57,10 +59,10 @@ void compute_c_p_map();                       /* 5/compute_correspondance.cpp:63
 void triangulate();                           /* 7/triangulation.cpp:1444 */
 void save_point_cloud(unsigned cloud_index);  /* 8/save_point_cloud.cpp:19: Point_cloud/texture.bmp -> point_cloud_<i>.pcd / .ply
                                                  (device compaction + colour gather of the last triangulate(); standard PCD / PLY
-                                                 ASCII text, not PCL 1.6's exact bytes) */
+                                                 ASCII text, not PCL 1.6's exact bytes; sl3d_shim_cloud_format(1): binary) */
 
 void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float tz, float rot_step); /* 9/register_point_clouds.cpp:23:
-                                                 Point_cloud/point_cloud_<i>.ply (the ASCII files save_point_cloud() writes) ->
+                                                 Point_cloud/point_cloud_<i>.ply (the files save_point_cloud() writes, ASCII or binary) ->
                                                  Point_cloud/registered_point_cloud.ply, rotation on the device */
 
 /* ---- shim configuration (not in the reference) ----
@@ -76,6 +78,20 @@ void sl3d_shim_write_debug_images(int enable);
 int sl3d_shim_last_status(void);
 const char *sl3d_shim_last_error(void);
 void sl3d_shim_reset(void); /* drop the context (e.g. before changing the scalar globals) */
+/* Inputs handed over in MEMORY instead of through files: whenever a stage would load <data root>/<relative_path> (the names the
+ * reference hard-codes, e.g. "Captured_patterns/Fringe_patterns/Vertical/Undistorted/Captured_image_0.bmp",
+ * "Point_cloud/texture.bmp" (channels = 3, B,G,R), "Camera_calibration/Matrices/cam_intrinsic_mat.xml"), it takes the provided
+ * buffer instead -- an IplImage's (imageData, widthStep) / a CvMat's doubles.  The image memory is not copied: it must stay
+ * valid until the stage that reads it has returned (pinned memory makes the upload an asynchronous DMA).  data / values == NULL
+ * withdraws an entry. */
+void sl3d_shim_provide_image(const char *relative_path, const unsigned char *data, int width, int height, int channels, size_t stride);
+void sl3d_shim_provide_matrix(const char *relative_path, const double *values, int count);
+/* save_point_cloud() / register_point_clouds(): 0 = ASCII PCD / PLY like the reference (8/save_point_cloud.cpp:211-217), 1 = the
+ * binary flavours of the same formats (PCD "DATA binary", PLY "binary_little_endian") */
+void sl3d_shim_cloud_format(int binary);
+/* measurement switch: 1 = fetch row-major planes and transpose them on the host (the shim's behaviour before the globals were
+ * transposed on the device); the results are identical */
+void sl3d_shim_host_transpose(int enable);
 }
 
 #endif /* SL3D_SHIM_H */

@@ -13,6 +13,8 @@
 
 int main(int argc, char **argv)
 {
+    if (getenv("SL3D_SHIM_HOST_TRANSPOSE")) sl3d_shim_host_transpose(atoi(getenv("SL3D_SHIM_HOST_TRANSPOSE")));
+    if (getenv("SL3D_SHIM_BINARY")) sl3d_shim_cloud_format(atoi(getenv("SL3D_SHIM_BINARY")));
     if (argc >= 8 && std::string(argv[1]) == "register") {
         sl3d_shim_set_data_root(argv[2]);
         register_point_clouds((unsigned)atoi(argv[3]), (float)atof(argv[4]), (float)atof(argv[5]), (float)atof(argv[6]), (float)atof(argv[7]));
@@ -32,6 +34,51 @@ int main(int argc, char **argv)
     if (argc < 9) return 2;
     sl3d_shim_set_data_root(argv[1]);
     sl3d_shim_write_debug_images(1);
+    // switches of the test: SL3D_SHIM_HOST_TRANSPOSE=1 (row-major download + host transposes), SL3D_SHIM_BINARY=1 (binary PCD / PLY),
+    // SL3D_SHIM_MEMORY=1: the frames, the texture and the calibration are handed over in memory (frames.raw: per axis F fringe,
+    // N gray, N inverse planes of W*H bytes; texture.raw: H*W*3 B,G,R; cal.raw: 40 doubles) -- no BMP / XML file exists then
+    static std::vector<unsigned char> mem_frames, mem_texture;
+    static double mem_cal[40];
+    if (getenv("SL3D_SHIM_MEMORY") && atoi(getenv("SL3D_SHIM_MEMORY"))) {
+        const size_t px = (size_t)Camera_imagewidth * Camera_imageheight;
+        const int Nv = atoi(argv[3]), Nh = atoi(argv[4]), F = 3;
+        auto slurp = [&](const char *name, std::vector<unsigned char> &v, size_t n) {
+            v.resize(n);
+            FILE *f = fopen((std::string(argv[1]) + "/" + name).c_str(), "rb");
+            const bool ok = f && fread(v.data(), 1, n, f) == n;
+            if (f) fclose(f);
+            return ok;
+        };
+        if (!slurp("frames.raw", mem_frames, px * (size_t)(2 * F + 2 * Nv + 2 * Nh)) || !slurp("texture.raw", mem_texture, px * 3)) return 4;
+        FILE *f = fopen((std::string(argv[1]) + "/cal.raw").c_str(), "rb");
+        if (!f || fread(mem_cal, sizeof(double), 40, f) != 40) return 5;
+        fclose(f);
+        const unsigned char *p = mem_frames.data();
+        char name[256];
+        for (int a = 0; a < 2; a++) {
+            const char *ax = a == 0 ? "Vertical" : "Horizontal";
+            const int N = a == 0 ? Nv : Nh;
+            for (int i = 0; i < F; i++, p += px) {
+                snprintf(name, sizeof name, "Captured_patterns/Fringe_patterns/%s/Undistorted/Captured_image_%d.bmp", ax, i);
+                sl3d_shim_provide_image(name, p, Camera_imagewidth, Camera_imageheight, 1, Camera_imagewidth);
+            }
+            for (int i = 0; i < N; i++, p += px) {
+                snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/Captured_image_%d.bmp", ax, i);
+                sl3d_shim_provide_image(name, p, Camera_imagewidth, Camera_imageheight, 1, Camera_imagewidth);
+            }
+            for (int i = 0; i < N; i++, p += px) {
+                snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Captured_image_%d.bmp", ax, i);
+                sl3d_shim_provide_image(name, p, Camera_imagewidth, Camera_imageheight, 1, Camera_imagewidth);
+            }
+        }
+        sl3d_shim_provide_image("Point_cloud/texture.bmp", mem_texture.data(), Camera_imagewidth, Camera_imageheight, 3, (size_t)Camera_imagewidth * 3);
+        const char *mats[8] = {"Camera_calibration/Matrices/cam_intrinsic_mat.xml", "Camera_calibration/Matrices/cam_distortion_vect.xml",
+                               "Triangulation/Camera_extrinsic_parametrs/world_to_cam_rot_vect.xml", "Triangulation/Camera_extrinsic_parametrs/world_to_cam_trans_vect.xml",
+                               "Projector_calibration/Matrices/proj_intrinsic_mat.xml", "Projector_calibration/Matrices/proj_distortion_vect.xml",
+                               "Triangulation/Projector_extrinsic_parametrs/world_to_proj_rot_vect.xml", "Triangulation/Projector_extrinsic_parametrs/world_to_proj_trans_vect.xml"};
+        const int cnt[8] = {9, 5, 3, 3, 9, 5, 3, 3};
+        for (int k = 0, o = 0; k < 8; o += cnt[k], k++) sl3d_shim_provide_matrix(mats[k], mem_cal + o, cnt[k]);
+    }
     number_of_patterns_binary_vertical = atoi(argv[3]);
     number_of_patterns_binary_horizontal = atoi(argv[4]);
     fringe_width_pixels_vertical = atoi(argv[5]);
@@ -60,8 +107,9 @@ int main(int argc, char **argv)
     if (sl3d_shim_last_status()) return 14;
     triangulate();
     if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 15; }
-    if (FILE *t = fopen((std::string(argv[1]) + "/Point_cloud/texture.bmp").c_str(), "rb")) {  // main() calls it after triangulate()
-        fclose(t);
+    FILE *t = fopen((std::string(argv[1]) + "/Point_cloud/texture.bmp").c_str(), "rb");
+    if (t || !mem_texture.empty()) {  // main() calls it after triangulate()
+        if (t) fclose(t);
         save_point_cloud(3);
         if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 16; }
     }

@@ -29,9 +29,11 @@ def _random_mask(rng, W, H, holes=6):
 # ---- ordered compaction inside the fused kernel ------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(640, 200, 8, 8, 4), (333, 77, 9, 9, 4), (200, 120, 6, 5, 16), (1021, 64, 7, 7, 4), (64, 3, 6, 6, 8)])
 @pytest.mark.parametrize("dist_proj", [False, True])
-def test_fused_compaction_equals_dense(shape, dist_proj):
-    """sl3d_run_clouds: the cloud of every view equals xyz[valid] of the dense pass (8/save_point_cloud.cpp:85-104 order),
-    the valid map is the same, and repeated launches reuse the look-back words correctly (launch generations)."""
+@pytest.mark.parametrize("lookback", [False, True])
+def test_fused_compaction_equals_dense(shape, dist_proj, lookback):
+    """sl3d_run_clouds -- segmented clouds (default) and the single-pass look-back (SL3D_FLAG_CLOUDS_LOOKBACK): the cloud of every
+    view equals xyz[valid] of the dense pass (8/save_point_cloud.cpp:85-104 order), the valid map is the same, and repeated
+    launches reuse the look-back words correctly (launch generations)."""
     S, syn = _S(), pkg("synth")
     W, H, Nv, Nh, fw = shape
     PW, PH, NV = 512, 384, 5
@@ -40,7 +42,7 @@ def test_fused_compaction_equals_dense(shape, dist_proj):
     cal = {k: np.array(v, dtype=np.float64).copy() for k, v in caps[0]["cal"].items()}
     if dist_proj:
         cal["dp"] = np.array([0.04, -0.01, 0.001, -0.0005, 0.0])
-    with S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=NV) as sc:
+    with S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=NV, clouds_lookback=lookback) as sc:
         sc.set_calibration(*syn.cal_tuple(cal))
         for v, c in enumerate(caps):
             sc.set_mask(_random_mask(rng, W, H) if v else c["mask"], view=v)
@@ -62,14 +64,15 @@ def test_fused_compaction_equals_dense(shape, dist_proj):
             assert np.array_equal(sc.cloud(v), dense[v][0][dense[v][1] == 1])
 
 
-def test_fused_compaction_full_hd_batch():
+@pytest.mark.parametrize("lookback", [False, True])
+def test_fused_compaction_full_hd_batch(lookback):
     """BASELINE configs[1] shape: 16 views of 1920x1080 in one launch (8100 tiles per view, 8 views per lane): every
     cloud equals xyz[valid]; a sparse mask and an empty mask included."""
     S, syn = _S(), pkg("synth")
     W, H, N, fw, NV = 1920, 1080, 10, 2, 16
     cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
     rng = np.random.default_rng(5)
-    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV) as sc:
+    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV, clouds_lookback=lookback) as sc:
         sc.set_calibration(*cal)
         for v in range(NV):
             m = syn.default_mask(W, H)

@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 W, H, PW, PH, NV, NH, FWV, FWH = 160, 120, 256, 192, 6, 5, 8, 8
 
 
+def exp_xyz_dev(got, exp):
+    """the binary files hold the device's float32 points: within the 1e-5 bar of the oracle's, returned for the bit comparison
+    of the second file against the first"""
+    assert_points_close(got[None].astype(np.float32), exp[None].astype(np.float64), np.ones((1, len(exp)), dtype=bool))
+    return got
+
+
 def _xml(path, name, rows, cols, vals):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
@@ -22,10 +29,14 @@ def _xml(path, name, rows, cols, vals):
                 % (name, rows, cols, " ".join("%.17e" % v for v in vals), name))
 
 
-@pytest.mark.parametrize("devices", [None, "0,0,0"])
-def test_shim_matches_oracle(tmp_path, devices):
+@pytest.mark.parametrize("devices,mode", [(None, "files"), ("0,0,0", "files"), (None, "memory"), ("0,0,0", "memory"), (None, "host_transpose"),
+                                          ("0,0,0", "host_transpose"), (None, "binary")])
+def test_shim_matches_oracle(tmp_path, devices, mode):
     """devices = "0,0,0": SL3D_DEVICES splits the scan into three row stripes (sl3d_group_*; here all on GPU 0): every
-    reference-layout global and both cloud files must come out exactly as on one context."""
+    reference-layout global and both cloud files must come out exactly as on one context.
+    mode: files = the reference's BMP / XML inputs; memory = the same inputs handed over in memory (sl3d_shim_provide_image /
+    _matrix; no input file exists); host_transpose = the pre-round-3 route (row-major planes transposed by the host) instead of
+    the [col][row] globals produced on the device; binary = binary PCD / PLY cloud files."""
     syn = pkg("synth")
     cap = syn.make_capture(W, H, PW, PH, NV, NH, FWV, FWH, noise=2)
     rng = np.random.default_rng(5)
@@ -40,6 +51,8 @@ def test_shim_matches_oracle(tmp_path, devices):
         d2 = f"{root}/Captured_patterns/Coded_patterns/Gray_coded/{ax[a]}/Undistorted"
         os.makedirs(d1); os.makedirs(d2)
         os.makedirs(f"{root}/Wrapped_phase_images/{ax[a]}"); os.makedirs(f"{root}/Unwrapped_phase_images/Gray_coded/{ax[a]}")
+        if mode == "memory":
+            continue
         for i in range(3):
             Image.fromarray(planes[i]).save(f"{d1}/Captured_image_{i}.bmp")
         for i in range(N):
@@ -54,16 +67,23 @@ def test_shim_matches_oracle(tmp_path, devices):
     # save_point_cloud()'s colour source, a 24-bit BMP of the camera size (8/save_point_cloud.cpp:46)
     os.makedirs(f"{root}/Point_cloud")
     texture = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)  # R,G,B
-    Image.fromarray(texture).save(f"{root}/Point_cloud/texture.bmp")
     Kc, dc, rc, tc, Kp, dp, rp, tp = cal
-    _xml(f"{root}/Camera_calibration/Matrices/cam_intrinsic_mat.xml", "cam_intrinsic_mat", 3, 3, Kc)
-    _xml(f"{root}/Camera_calibration/Matrices/cam_distortion_vect.xml", "cam_distortion_vect", 5, 1, dc)
-    _xml(f"{root}/Projector_calibration/Matrices/proj_intrinsic_mat.xml", "proj_intrinsic_mat", 3, 3, Kp)
-    _xml(f"{root}/Projector_calibration/Matrices/proj_distortion_vect.xml", "proj_distortion_vect", 5, 1, dp)
-    _xml(f"{root}/Triangulation/Camera_extrinsic_parametrs/world_to_cam_rot_vect.xml", "world_to_cam_rot_vect", 3, 1, rc)
-    _xml(f"{root}/Triangulation/Camera_extrinsic_parametrs/world_to_cam_trans_vect.xml", "world_to_cam_trans_vect", 3, 1, tc)
-    _xml(f"{root}/Triangulation/Projector_extrinsic_parametrs/world_to_proj_rot_vect.xml", "world_to_proj_rot_vect", 3, 1, rp)
-    _xml(f"{root}/Triangulation/Projector_extrinsic_parametrs/world_to_proj_trans_vect.xml", "world_to_proj_trans_vect", 3, 1, tp)
+    if mode == "memory":
+        np.concatenate([np.stack(cap["planes_v"]).ravel(), np.stack(cap["planes_h"]).ravel()]).tofile(f"{root}/frames.raw")
+        np.ascontiguousarray(texture[..., ::-1]).tofile(f"{root}/texture.raw")   # B,G,R as cvLoadImage returns it
+        np.concatenate(cal).astype(np.float64).tofile(f"{root}/cal.raw")
+        Kc = None
+    else:
+        Image.fromarray(texture).save(f"{root}/Point_cloud/texture.bmp")
+    if Kc is not None:
+        _xml(f"{root}/Camera_calibration/Matrices/cam_intrinsic_mat.xml", "cam_intrinsic_mat", 3, 3, Kc)
+        _xml(f"{root}/Camera_calibration/Matrices/cam_distortion_vect.xml", "cam_distortion_vect", 5, 1, dc)
+        _xml(f"{root}/Projector_calibration/Matrices/proj_intrinsic_mat.xml", "proj_intrinsic_mat", 3, 3, Kp)
+        _xml(f"{root}/Projector_calibration/Matrices/proj_distortion_vect.xml", "proj_distortion_vect", 5, 1, dp)
+        _xml(f"{root}/Triangulation/Camera_extrinsic_parametrs/world_to_cam_rot_vect.xml", "world_to_cam_rot_vect", 3, 1, rc)
+        _xml(f"{root}/Triangulation/Camera_extrinsic_parametrs/world_to_cam_trans_vect.xml", "world_to_cam_trans_vect", 3, 1, tc)
+        _xml(f"{root}/Triangulation/Projector_extrinsic_parametrs/world_to_proj_rot_vect.xml", "world_to_proj_rot_vect", 3, 1, rp)
+        _xml(f"{root}/Triangulation/Projector_extrinsic_parametrs/world_to_proj_trans_vect.xml", "world_to_proj_trans_vect", 3, 1, tp)
 
     # build the shim + driver for this test's compile-time dimensions (the reference fixes them with macros too)
     exe = f"{root}/shim_driver"
@@ -78,6 +98,7 @@ def test_shim_matches_oracle(tmp_path, devices):
     env = {k: v for k, v in os.environ.items() if k != "SL3D_DEVICES"}
     if devices:
         env["SL3D_DEVICES"] = devices
+    env.update({"memory": {"SL3D_SHIM_MEMORY": "1"}, "host_transpose": {"SL3D_SHIM_HOST_TRANSPOSE": "1"}, "binary": {"SL3D_SHIM_BINARY": "1"}}.get(mode, {}))
     r = subprocess.run([exe, root, out, str(NV), str(NH), str(FWV), str(FWH), str(ncv), str(nch)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
 
@@ -120,6 +141,20 @@ def test_shim_matches_oracle(tmp_path, devices):
     # save_point_cloud(3): valid pixels in row-major scan order, float xyz, r,g,b of the texture (8/save_point_cloud.cpp:85-104)
     exp_xyz = o.intersection_points()[v].astype(np.float32)
     exp_rgb = texture[v]
+    if mode == "binary":
+        raw = open(f"{root}/Point_cloud/point_cloud_3.pcd", "rb").read()
+        k = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
+        assert f"POINTS {len(exp_xyz)}".encode() in raw[:k] and b"FIELDS x y z rgb" in raw[:k]
+        rec = np.frombuffer(raw[k:], dtype=np.dtype([("xyz", "<f4", 3), ("rgb", "<u4")]))
+        assert len(rec) == len(exp_xyz) and np.array_equal(rec["xyz"].view(np.uint32), exp_xyz_dev(rec["xyz"], exp_xyz).view(np.uint32))
+        packed = rec["rgb"]
+        assert np.array_equal(np.stack([(packed >> 16) & 255, (packed >> 8) & 255, packed & 255], axis=1).astype(np.uint8), exp_rgb)
+        raw = open(f"{root}/Point_cloud/point_cloud_3.ply", "rb").read()
+        k = raw.index(b"end_header\n") + len(b"end_header\n")
+        assert b"format binary_little_endian 1.0" in raw[:k] and f"element vertex {len(exp_xyz)}".encode() in raw[:k]
+        rec2 = np.frombuffer(raw[k:], dtype=np.dtype([("xyz", "<f4", 3), ("rgb", "u1", 3)]))
+        assert np.array_equal(rec2["xyz"].view(np.uint32), rec["xyz"].view(np.uint32)) and np.array_equal(rec2["rgb"], exp_rgb)
+        return
     pcd = open(f"{root}/Point_cloud/point_cloud_3.pcd").read().split("\n")
     k = pcd.index("DATA ascii")
     assert f"POINTS {len(exp_xyz)}" in pcd[:k] and "FIELDS x y z rgb" in pcd[:k]
@@ -163,10 +198,12 @@ def test_shim_generate_pattern_reproduces_reference_files(tmp_path):
         assert hashlib.sha256(raw).hexdigest() == h, rel
 
 
-def test_shim_register_point_clouds_files(tmp_path):
-    """register_point_clouds() through the shim: reads Point_cloud/point_cloud_<i>.ply (ASCII, as save_point_cloud() writes
-    them), rotates cloud i by i*rot_step on the device, writes registered_point_cloud.ply; equal to the oracle's restatement
-    of 9/register_point_clouds.cpp:83-148 bit for bit, colours carried along."""
+@pytest.mark.parametrize("binary", [False, True])
+def test_shim_register_point_clouds_files(tmp_path, binary):
+    """register_point_clouds() through the shim: reads Point_cloud/point_cloud_<i>.ply (ASCII or binary_little_endian, as
+    save_point_cloud() writes them), rotates cloud i by i*rot_step on the device, writes registered_point_cloud.ply (in the
+    format sl3d_shim_cloud_format selects); equal to the oracle's restatement of 9/register_point_clouds.cpp:83-148 bit for
+    bit, colours carried along."""
     from oracle.oracle import register_point_clouds as orc_register
     rng = np.random.default_rng(17)
     root = str(tmp_path)
@@ -175,11 +212,16 @@ def test_shim_register_point_clouds_files(tmp_path):
     for i, n in enumerate((1500, 0, 733)):
         xyz = (rng.standard_normal((n, 3)) * 40 + [60, 35, -2]).astype(np.float32)
         rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
-        with open(f"{root}/Point_cloud/point_cloud_{i}.ply", "w") as f:
-            f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
-                    "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n)
-            for p, c in zip(xyz, rgb):
-                f.write("%.9g %.9g %.9g %d %d %d\n" % (*p, *c))
+        with open(f"{root}/Point_cloud/point_cloud_{i}.ply", "wb") as f:
+            f.write(("ply\nformat %s 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                     "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % ("binary_little_endian" if binary else "ascii", n)).encode())
+            if binary:
+                rec = np.zeros(n, dtype=np.dtype([("xyz", "<f4", 3), ("rgb", "u1", 3)]))
+                rec["xyz"], rec["rgb"] = xyz, rgb
+                f.write(rec.tobytes())
+            else:
+                for p, c in zip(xyz, rgb):
+                    f.write(("%.9g %.9g %.9g %d %d %d\n" % (*p, *c)).encode())
         clouds.append(xyz)
         cols.append(rgb)
     exe = f"{root}/shim_driver"
@@ -190,9 +232,17 @@ def test_shim_register_point_clouds_files(tmp_path):
                            os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"), "-lsl3d",
                            "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
     tx, ty, tz, step = 60.0, 35.0, -2.0, 12.5
-    r = subprocess.run([exe, "register", root, "3", str(tx), str(ty), str(tz), str(step)], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, SL3D_SHIM_BINARY="1" if binary else "0")
+    r = subprocess.run([exe, "register", root, "3", str(tx), str(ty), str(tz), str(step)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     exp = orc_register(clouds, tx, ty, tz, step)
+    if binary:
+        raw = open(f"{root}/Point_cloud/registered_point_cloud.ply", "rb").read()
+        k = raw.index(b"end_header\n") + len(b"end_header\n")
+        assert b"format binary_little_endian 1.0" in raw[:k] and f"element vertex {len(exp)}".encode() in raw[:k]
+        rec = np.frombuffer(raw[k:], dtype=np.dtype([("xyz", "<f4", 3), ("rgb", "u1", 3)]))
+        assert np.array_equal(rec["xyz"], exp) and np.array_equal(rec["rgb"], np.concatenate(cols))
+        return
     ply = open(f"{root}/Point_cloud/registered_point_cloud.ply").read().split("\n")
     k = ply.index("end_header")
     assert f"element vertex {len(exp)}" in ply[:k]

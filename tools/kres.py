@@ -8,7 +8,7 @@ txt = open(sys.argv[1]).read()
 want = set(sys.argv[2:]) or {"10"}
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
     name = b.split("\n")[0].strip()
-    m = re.search(r"k_fusedILb(\d)ELi(\d+)ELb(\d)ELb(\d)ELi(\d)ELb(\d)", name)
+    m = re.search(r"k_fusedILb(\d)ELi(\d+)ELb(\d)ELb(\d)ELi(\d)ELi(\d)", name)
     if not m:
         continue
     keep, nmax, fgen, exact, rig, comp = m.groups()
