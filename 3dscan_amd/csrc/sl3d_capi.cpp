@@ -224,6 +224,14 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
         CREATE_CHK(hipMemsetAsync(P.cpmap, 0, n * 16, x->stream));
         CREATE_CHK(hipMemsetAsync(P.ipoints, 0, n * 24, x->stream));
     }
+#if defined(SL3D_MEASURE) && defined(SL3D_TRACE)
+    {   // phase stamps [view group][block][wave][8] of the dense timed kernel (tools/phase_trace.py)
+        const size_t blocks = ((((size_t)(P.pitch >> 2) * P.H + 255) / 256) + 7) & ~(size_t)7;
+        x->dbg_words = V * blocks * 4 * 8;
+        ALLOC(P.dbg, x->dbg_words);
+        CREATE_CHK(hipMemsetAsync(P.dbg, 0, x->dbg_words * sizeof(unsigned long long), x->stream));
+    }
+#endif
     CREATE_CHK(hipStreamSynchronize(x->stream));
 #undef ALLOC
 #undef CREATE_CHK
@@ -1033,6 +1041,9 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
             float *dst = x->d_packed + 3 * (size_t)first_view * x->P.px_view_stride;
             rc = launched(x, launch_seg_close(x->P, first_view, n_views, dst, x->P.px_view_stride, x->stream));
             if (rc) return rc;
+            // the copy is handed to consumers on OTHER streams too (a group's communication stream, a caller's RCCL stream):
+            // like the counts, it is complete when this call returns
+            HIPCHK(x, hipStreamSynchronize(x->stream));
             *device_xyz = dst;
         }
     }
@@ -1448,7 +1459,7 @@ extern "C" int sl3d_debug_buffer(sl3d_ctx *x, const void **dev, size_t *bytes, i
 {
     if (!x || !x->P.dbg) return SL3D_E_STATE;
     *dev = x->P.dbg;
-    *bytes = (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * 4 * sizeof(unsigned long long);
+    *bytes = x->dbg_words ? x->dbg_words * sizeof(unsigned long long) : (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * 4 * sizeof(unsigned long long);
     *n_tiles = x->P.n_tiles;
     return SL3D_OK;
 }

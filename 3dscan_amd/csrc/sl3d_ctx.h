@@ -66,6 +66,7 @@ struct sl3d_ctx {
     size_t colrow_bytes = 0;      // [col][row] selection mask on its way in (sl3d_set_mask_colrow)
     DevCal *d_cal = nullptr;  // device copy of C for the fused kernel (read through scalar loads)
     size_t mask_rows = 0;
+    size_t dbg_words = 0;     // measurement builds (-DSL3D_TRACE): size of the phase-stamp buffer KParams::dbg
 };
 
 // records the message on the context (or, without one, as the thread's creation error) and returns `code`

@@ -89,6 +89,20 @@
 #undef SL3D_CX
 #define SL3D_CX 0
 #endif
+// measurement builds only (-DSL3D_MEASURE -DSL3D_TRACE): wall-clock stamps (100 MHz) of every wave of the dense timed kernel at
+// its phase boundaries, first view of the item: 0 entry, 1 mask / camera-table loads requested + reciprocal table filled, 2 first
+// view's plane loads issued (waited for the mask dword), 3 camera coordinates in LDS, 4 planes landed + decoded, 5 phase A done, 6 phase B done, 7 stores issued
+// -> KParams::dbg [block][wave][8] (tools/phase_trace.py)
+#if defined(SL3D_MEASURE) && defined(SL3D_TRACE)
+#define SL3D_STAMP(k)                                                                                                               \
+    do {                                                                                                                            \
+        /* every lane of the wave stores the same (scalar) clock to the same word: no divergent branch in the instrumented code */   \
+        if (CMODE == 0 && !KEEP && P.dbg)                                                                                           \
+            P.dbg[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64();              \
+    } while (0)
+#else
+#define SL3D_STAMP(k)
+#endif
 #ifdef SL3D_MEASURE
 #define SL3D_ABLATE_RT(P) ((P).ablate)
 #else
@@ -923,10 +937,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     // (the compacting kernel with three views of slack gives the table's 6 KB to its staging areas and computes 1/d: -1 %)
     constexpr bool RCP_TAB = SL3D_RCP_LDS != 0 && !(COMPACT && SL3D_SLACK >= 3);
     __shared__ __attribute__((aligned(16))) double s_rcp[RCP_TAB ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
-    if (RCP_TAB) {
-        fill_rcp_table(s_rcp);
-        __syncthreads();
-    }
+    SL3D_STAMP(0);
     const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
     // A work ITEM is one 1024-pixel tile (256 lanes x 4 pixels) of the window for one group of `vpt` views.
@@ -960,6 +971,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     }
     // everything of an item that depends on the pixel only; false if this lane has nothing to do in a dense kernel
     MaskQuad mq_first = {0u};
+    double camt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the lane's camera-table entries between begin_item (requested) and finish_item (consumed)
     auto begin_item = [&](unsigned tile_, int group) -> bool {
         tile = tile_;
         v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
@@ -969,36 +981,48 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
         cq = (int)(q - (long)row_q * qpr);
         // COMPACT: a block keeps all its lanes (block barriers in the view loop); lanes past the last row work on a clamped
         // address and have no valid pixel
-        if (!COMPACT && row_q >= P.H) return false;
+        // SEG: a wave stores its segment with all 64 lanes (whole 16-byte chunks, lane after lane), so the lanes past the last row
+        // stay too, without a valid pixel; only the blocks the grid was padded with leave (they own no segment)
+        if (SEG && tile_ >= (unsigned)P.n_tiles) return false;
+        if (!COMPACT && !SEG && row_q >= P.H) return false;
         alive = row_q < P.H;
-        row = COMPACT ? min(row_q, P.H - 1) : row_q;
+        row = (COMPACT || SEG) ? min(row_q, P.H - 1) : row_q;
         gx0 = P.col0 + cq * 4;
         gy = P.row0 + row;
         lane_off = (unsigned)row * (unsigned)P.pitch + (unsigned)cq * 4u;
         // the valid bits of the item's first view are requested now, so that they travel together with the camera table
         // entries below instead of after them (one round trip less before the first plane loads can leave)
         mq_first = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row);
-        // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
-        // index it (each lane reads back only what it wrote: no barrier)
+        // ... and so are the lane's entries of the camera table (k_cam_table: what the in-kernel iteration would produce); they are
+        // CONSUMED by finish_item, which runs after the first view's plane loads have been issued: nothing that is merely
+        // per-pixel set-up stands between kernel entry and the 11.5 KB of plane requests (round 3, tools/phase_trace.py: the
+        // dependent round trip of these loads used to precede them -- 2 us of a 30 us one-view launch, twice)
         if (P.use_cam_table) {
-            // the per-calibration table (k_cam_table) holds what the loop below iterates; the doubles that come out are the same
-            const auto &I = opaque_const(Cglobal)->cam;
             const size_t i0 = (size_t)row * P.pitch + (size_t)cq * 4;
-            const double y0 = ((double)gy - I.cy) * I.ify;
-            double t[8];
             if (P.use_cam_table == 1) {
                 const double2 *tp = (const double2 *)(P.cam_tab + i0);
                 const double2 a = tp[0], b = tp[1];
-                t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
+                camt[0] = a.x; camt[1] = a.y; camt[2] = b.x; camt[3] = b.y;
             } else {
                 const double2 *tp = (const double2 *)(P.cam_tab + 2 * i0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const double2 a = tp[k];
-                    t[2 * k] = a.x;
-                    t[2 * k + 1] = a.y;
+                    camt[2 * k] = a.x;
+                    camt[2 * k + 1] = a.y;
                 }
             }
+        }
+        return true;
+    };
+    // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
+    // index it (each lane reads back only what it wrote: no barrier)
+    auto finish_item = [&]() {
+        if (P.use_cam_table) {
+            // the per-calibration table (k_cam_table) holds what the loop below iterates; the doubles that come out are the same
+            const auto &I = opaque_const(Cglobal)->cam;
+            const double y0 = ((double)gy - I.cy) * I.ify;
+            const double *t = camt;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 double xn, yn;
@@ -1013,7 +1037,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
                 my_cam[2 * k] = xn;
                 my_cam[2 * k + 1] = yn;
             }
-            return true;
+            return;
         }
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
@@ -1025,8 +1049,18 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             my_cam[2 * k] = cu;
             my_cam[2 * k + 1] = cv;
         }
-        return true;
     };
+    // dense / segmented kernels have exactly one item per block: its mask and camera-table loads leave FIRST, and the LDS
+    // reciprocal table is filled (IEEE divisions + one block barrier, 0.5 us) while they travel.  Every thread takes part in the
+    // fill, also the lanes that own no pixel; they leave right behind the barrier.
+    bool have_item = true;
+    if (!COMPACT) have_item = begin_item(SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x, (int)blockIdx.y);
+    if (RCP_TAB) {
+        fill_rcp_table(s_rcp);
+        __syncthreads();
+    }
+    SL3D_STAMP(1);
+    if (!COMPACT && !have_item) return;
 
     PinnedRows PR;
 #pragma unroll
@@ -1254,9 +1288,9 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
         for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
     };
     // SEG: the wave's valid points of this view, compacted in scan order into the wave's own segment of the cloud buffer, and
-    // their count.  Needs nothing from any other wave: lanes that returned early (past the last row) just do not vote.
+    // their count.  Needs nothing from any other wave; lanes past the last row take part with no valid pixel.
     auto store_segment = [&](int view, size_t px, unsigned vout) {
-        *(unsigned *)(P.valid + px) = vout;
+        if (alive) *(unsigned *)(P.valid + px) = vout;
         const unsigned long long b0 = __ballot((vout & 0x00000001u) != 0u), b1 = __ballot((vout & 0x00000100u) != 0u),
                                  b2 = __ballot((vout & 0x00010000u) != 0u), b3 = __ballot((vout & 0x01000000u) != 0u);
         auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
@@ -1307,7 +1341,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
 
     // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
     auto valid_bits = [&](const MaskQuad &m) -> unsigned {
-        if (COMPACT && !alive) return 0u;
+        if ((COMPACT || SEG) && !alive) return 0u;
         return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(m);
     };
     // ---- COMPACT: up to three views of this lane's loop are in flight behind the one being computed ----------------------------
@@ -1435,8 +1469,6 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     if (COMPACT) {
         if (item >= n_items) break;  // block-uniform
         begin_item(item % (unsigned)P.n_tiles, (int)(item / (unsigned)P.n_tiles));
-    } else if (!begin_item(SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x, (int)blockIdx.y)) {
-        return;
     }
     unsigned next_ticket = 0;
     MaskQuad mq = mq_first;
@@ -1454,6 +1486,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             issue_gray(v_begin, g, iv);
         }
     }
+    SL3D_STAMP(2);
+    finish_item();  // behind the first view's plane loads (PIPE): the camera-table entries requested by begin_item become LDS coordinates
     for (int view = v_begin; view < v_end; view++) {
         unsigned vbits;
         if (PIPE) {
@@ -1493,7 +1527,9 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
         // COMPACT: the previous view's points leave now, behind this view's loads (its look-back overlaps their latency)
         if (COMPACT && !PIPE && have_held && !poll_pending) poll_held();  // behind this view's plane loads
         if (COMPACT && SL3D_PERSIST == 2 && view == v_begin && threadIdx.x == 0) s_ticket[(item_parity + 1u) & 1u] = next_ticket;
+        if (view == v_begin) SL3D_STAMP(3);
         if (vbits != 0) decode(g, iv, code);  // waits for the planes of this view
+        if (view == v_begin) SL3D_STAMP(4);
         if (COMPACT) {
             // the view computed two steps ago leaves (its look-back window arrived with the planes), then the previous view's
             // points move from the staging area -- about to be overwritten -- into registers
@@ -1530,6 +1566,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
                 vout = pixel_pairs(px, vbits, f, code);
             }
         }
+        if (view == v_begin) SL3D_STAMP(5);
         if (PIPE && view + 1 < v_end) {
             vb_next = valid_bits(mq);
             if (view + 2 < v_end) mq = load_mask_quad(P, view + 2, cq, row);
@@ -1549,7 +1586,9 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             continue;
         }
         if (!COMPACT) {
+            if (view == v_begin) SL3D_STAMP(6);
             store_quad(px, vout);
+            if (view == v_begin) SL3D_STAMP(7);
             continue;
         }
         if (alive) *(unsigned *)(P.valid + px) = vout;
@@ -2210,10 +2249,11 @@ __global__ __launch_bounds__(256) void k_seg_close(const float *__restrict__ seg
     const int seg = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u), v = blockIdx.y;
     if (seg >= n_segs) return;
     const unsigned cnt = counts[(size_t)v * n_segs + seg];
-    const f32x3 *src = (const f32x3 *)(seg_xyz + 3 * ((size_t)v * src_view_stride + (size_t)seg * SL3D_SEG_POINTS));
-    f32x3 *out = (f32x3 *)(dst + 3 * ((size_t)v * dst_view_stride + (size_t)offsets[(size_t)v * n_segs + seg]));
+    // (a 3-float vector type is PADDED to 16 bytes: points are addressed through float pointers, 12 bytes apart)
+    const float *src = seg_xyz + 3 * ((size_t)v * src_view_stride + (size_t)seg * SL3D_SEG_POINTS);
+    float *out = dst + 3 * ((size_t)v * dst_view_stride + (size_t)offsets[(size_t)v * n_segs + seg]);
     for (unsigned i = (unsigned)lane; i < cnt; i += 64u) {
-        f32x3 p = src[i];
+        f32x3 p = *(const f32x3 *)(src + 3 * (size_t)i);
         if (REG) {
             const float x = p.x - tx, y = p.y - ty, z = p.z - tz;
             const float X = (float)(((double)r00 * (double)x + 0.0 * (double)y) + (double)r02 * (double)z);
@@ -2221,7 +2261,7 @@ __global__ __launch_bounds__(256) void k_seg_close(const float *__restrict__ seg
             const float Z = (float)(((double)r20 * (double)x + 0.0 * (double)y) + (double)r22 * (double)z);
             p.x = X + tx; p.y = Y + ty; p.z = Z + tz;
         }
-        out[i] = p;
+        *(f32x3 *)(out + 3 * (size_t)i) = p;
     }
 }
 

@@ -98,19 +98,23 @@ bool read_bmp_gray(const std::string &path, std::vector<uint8_t> &out)
         }
     }
     const size_t rowbytes = (((size_t)w * bpp + 31) / 32) * 4;
-    std::vector<uint8_t> row(rowbytes);
-    out.assign((size_t)W * H, 0);
+    bool identity = bpp == 8;  // the grey ramp cvSaveImage writes for a 1-channel image: rows are copied, not looked up
+    for (int i = 0; i < 256 && identity; i++) identity = pal[i] == (uint8_t)i;
+    std::vector<uint8_t> file(rowbytes * (size_t)H);  // one read for the whole pixel array
+    out.resize((size_t)W * H);
     fseek(f, data_off, SEEK_SET);
+    if (fread(file.data(), 1, file.size(), f) != file.size()) { fclose(f); return false; }
+    fclose(f);
     for (int i = 0; i < H; i++) {
-        if (fread(row.data(), 1, rowbytes, f) != rowbytes) { fclose(f); return false; }
+        const uint8_t *row = file.data() + (size_t)i * rowbytes;
         const int y = hgt > 0 ? H - 1 - i : i;  // bottom-up unless the height is negative
         uint8_t *dst = out.data() + (size_t)y * W;
-        if (bpp == 8)
+        if (identity) memcpy(dst, row, (size_t)W);
+        else if (bpp == 8)
             for (int x = 0; x < W; x++) dst[x] = pal[row[x]];
         else
             for (int x = 0; x < W; x++) dst[x] = bgr2gray(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
     }
-    fclose(f);
     return true;
 }
 

@@ -37,18 +37,21 @@ def counters(prefix, kernel_substr):
 
 
 # the bench command launches two instantiations of k_fused: the dense kernel the bench line's `value` / `roofline` are about
-# (last template argument false) and the compacting one of its `to_compacted_clouds` leg (true): kept apart
+# (last template argument 0) and the compacting one of its `to_compacted_clouds` leg (2 = segmented clouds; 1 = the look-back
+# variant of the side figure): kept apart
 def dense_name():
     try:
         return json.loads(open(f"{src}/stats_bench.json").read())["roofline"]["kernel"].replace("sl3d::", "")
     except Exception:
-        return "k_fused<false, 10, false, true, 1, false>"
+        return "k_fused<false, 10, false, true, 1, 0>"
 
 
 dense = dense_name()
 bench = counters("bench", dense)
-compact = counters("bench", dense[:-len("false>")] + "true>")
-out = {"kernel": "sl3d::" + dense, "per_dispatch_mean": bench, "compacting_kernel_per_dispatch_mean": compact}
+compact = counters("bench", dense[:-len("0>")] + "2>")
+lookback = counters("bench", dense[:-len("0>")] + "1>")
+out = {"kernel": "sl3d::" + dense, "per_dispatch_mean": bench, "compacting_kernel_per_dispatch_mean": compact,
+       "lookback_kernel_per_dispatch_mean": lookback}
 # 2. calibration of FETCH_SIZE / WRITE_SIZE on tools/membench mode 0 (one dword per lane per plane, 47 planes;
 #    three 16-B stores + one dword per lane): the same access widths as the fused kernel, with KNOWN byte counts.
 mem = counters("membench", "k_dword")
@@ -78,5 +81,20 @@ if "FETCH_SIZE" in mem and "WRITE_SIZE" in mem:
                    "raw_FETCH_SIZE_KiB": bench["FETCH_SIZE"], "raw_WRITE_SIZE_KiB": bench["WRITE_SIZE"]}
         out["traffic"] = traffic
         json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+        # the compacting (segmented) kernel of the same command: its algorithmic bytes depend on the valid fraction of the run
+        if "FETCH_SIZE" in compact and "WRITE_SIZE" in compact:
+            rdc, wrc = compact["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KiB"], compact["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KiB"]
+            cbpp = None
+            try:
+                cbpp = bl["to_compacted_clouds"]["algorithmic_bytes_per_pixel"]
+            except Exception:
+                pass
+            tc = {"kernel": "sl3d::" + dense[:-len("0>")] + "2>", "pixels_per_launch": px_launch, "hbm_read_bytes_per_launch": rdc,
+                  "hbm_write_bytes_per_launch": wrc, "hbm_bytes_per_launch": rdc + wrc,
+                  "algorithmic_bytes_per_pixel": cbpp, "algorithmic_bytes_per_launch": cbpp * px_launch if cbpp else None,
+                  "ratio_to_algorithmic": (rdc + wrc) / (cbpp * px_launch) if cbpp else None, "method": traffic["method"],
+                  "raw_FETCH_SIZE_KiB": compact["FETCH_SIZE"], "raw_WRITE_SIZE_KiB": compact["WRITE_SIZE"]}
+            out["traffic_clouds"] = tc
+            json.dump(tc, open(f"profiles/{tag}_traffic_clouds.json", "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
