@@ -90,8 +90,8 @@
 #define SL3D_CX 0
 #endif
 // measurement builds only (-DSL3D_MEASURE -DSL3D_TRACE): wall-clock stamps (100 MHz) of every wave of the dense timed kernel at
-// its phase boundaries, first view of the item: 0 entry, 1 mask / camera-table loads requested + reciprocal table filled, 2 first
-// view's plane loads issued (waited for the mask dword), 3 camera coordinates in LDS, 4 planes landed + decoded, 5 phase A done, 6 phase B done, 7 stores issued
+// its phase boundaries, first view of the item: 0 entry, 1 reciprocal table filled, 2 item set up (camera table entries, first
+// mask dword requested), 3 plane loads issued, 4 planes landed + decoded, 5 phase A done, 6 phase B done, 7 stores issued
 // -> KParams::dbg [block][wave][8] (tools/phase_trace.py)
 #if defined(SL3D_MEASURE) && defined(SL3D_TRACE)
 #define SL3D_STAMP(k)                                                                                                               \
@@ -938,6 +938,11 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     constexpr bool RCP_TAB = SL3D_RCP_LDS != 0 && !(COMPACT && SL3D_SLACK >= 3);
     __shared__ __attribute__((aligned(16))) double s_rcp[RCP_TAB ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
     SL3D_STAMP(0);
+    if (RCP_TAB) {
+        fill_rcp_table(s_rcp);
+        __syncthreads();
+    }
+    SL3D_STAMP(1);
     const int F = FGEN ? P.F : 3;
     const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
     // A work ITEM is one 1024-pixel tile (256 lanes x 4 pixels) of the window for one group of `vpt` views.
@@ -971,7 +976,6 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     }
     // everything of an item that depends on the pixel only; false if this lane has nothing to do in a dense kernel
     MaskQuad mq_first = {0u};
-    double camt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the lane's camera-table entries between begin_item (requested) and finish_item (consumed)
     auto begin_item = [&](unsigned tile_, int group) -> bool {
         tile = tile_;
         v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
@@ -993,36 +997,32 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
         // the valid bits of the item's first view are requested now, so that they travel together with the camera table
         // entries below instead of after them (one round trip less before the first plane loads can leave)
         mq_first = load_mask_quad(P, min(v_begin, first_view + n_views - 1), cq, row);
-        // ... and so are the lane's entries of the camera table (k_cam_table: what the in-kernel iteration would produce); they are
-        // CONSUMED by finish_item, which runs after the first view's plane loads have been issued: nothing that is merely
-        // per-pixel set-up stands between kernel entry and the 11.5 KB of plane requests (round 3, tools/phase_trace.py: the
-        // dependent round trip of these loads used to precede them -- 2 us of a 30 us one-view launch, twice)
+        // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
+        // index it (each lane reads back only what it wrote: no barrier).
+        // (Round 3 measured the other order -- these loads requested before the reciprocal-table fill, their entries consumed
+        // behind the first view's plane loads, so that no set-up round trip precedes the 11.5 KB of plane requests: one-view
+        // launch 31.8-32.2 us against 31.1-31.6, 16 views +-0 (profiles/r03_prologue_ab.txt).  The phase trace says why: what a
+        // cold launch waits for in its first 5 us is the memory system's ramp under 4096 waves asking at once, not this
+        // dependency.)
         if (P.use_cam_table) {
+            // the per-calibration table (k_cam_table) holds what the loop below iterates; the doubles that come out are the same
+            const auto &I = opaque_const(Cglobal)->cam;
             const size_t i0 = (size_t)row * P.pitch + (size_t)cq * 4;
+            const double y0 = ((double)gy - I.cy) * I.ify;
+            double t[8];
             if (P.use_cam_table == 1) {
                 const double2 *tp = (const double2 *)(P.cam_tab + i0);
                 const double2 a = tp[0], b = tp[1];
-                camt[0] = a.x; camt[1] = a.y; camt[2] = b.x; camt[3] = b.y;
+                t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
             } else {
                 const double2 *tp = (const double2 *)(P.cam_tab + 2 * i0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const double2 a = tp[k];
-                    camt[2 * k] = a.x;
-                    camt[2 * k + 1] = a.y;
+                    t[2 * k] = a.x;
+                    t[2 * k + 1] = a.y;
                 }
             }
-        }
-        return true;
-    };
-    // T1 for the camera depends on the pixel only: once per lane and item, kept in LDS so the rolled pixel loop can
-    // index it (each lane reads back only what it wrote: no barrier)
-    auto finish_item = [&]() {
-        if (P.use_cam_table) {
-            // the per-calibration table (k_cam_table) holds what the loop below iterates; the doubles that come out are the same
-            const auto &I = opaque_const(Cglobal)->cam;
-            const double y0 = ((double)gy - I.cy) * I.ify;
-            const double *t = camt;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 double xn, yn;
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
                 my_cam[2 * k] = xn;
                 my_cam[2 * k + 1] = yn;
             }
-            return;
+            return true;
         }
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
@@ -1049,18 +1049,8 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             my_cam[2 * k] = cu;
             my_cam[2 * k + 1] = cv;
         }
+        return true;
     };
-    // dense / segmented kernels have exactly one item per block: its mask and camera-table loads leave FIRST, and the LDS
-    // reciprocal table is filled (IEEE divisions + one block barrier, 0.5 us) while they travel.  Every thread takes part in the
-    // fill, also the lanes that own no pixel; they leave right behind the barrier.
-    bool have_item = true;
-    if (!COMPACT) have_item = begin_item(SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x, (int)blockIdx.y);
-    if (RCP_TAB) {
-        fill_rcp_table(s_rcp);
-        __syncthreads();
-    }
-    SL3D_STAMP(1);
-    if (!COMPACT && !have_item) return;
 
     PinnedRows PR;
 #pragma unroll
@@ -1469,7 +1459,10 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     if (COMPACT) {
         if (item >= n_items) break;  // block-uniform
         begin_item(item % (unsigned)P.n_tiles, (int)(item / (unsigned)P.n_tiles));
+    } else if (!begin_item(SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x, (int)blockIdx.y)) {
+        return;
     }
+    SL3D_STAMP(2);
     unsigned next_ticket = 0;
     MaskQuad mq = mq_first;
     // PIPE (timed kernels): the planes of view v+1 are requested in the middle of view v -- after phase A, when the plane
@@ -1486,8 +1479,6 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             issue_gray(v_begin, g, iv);
         }
     }
-    SL3D_STAMP(2);
-    finish_item();  // behind the first view's plane loads (PIPE): the camera-table entries requested by begin_item become LDS coordinates
     for (int view = v_begin; view < v_end; view++) {
         unsigned vbits;
         if (PIPE) {

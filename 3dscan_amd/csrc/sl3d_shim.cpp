@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <charconv>
 #include <cstring>
 #include <map>
 #include <string>
@@ -177,6 +178,34 @@ bool write_bmp_gray(const std::string &path, const uint8_t *img, int w = W, int 
     for (int y = h - 1; y >= 0; y--) { memcpy(row.data(), img + (size_t)y * w, w); fwrite(row.data(), 1, rowbytes, f); }
     fclose(f);
     return true;
+}
+
+// The ASCII cloud rows the reference's PCL writers produce are built in memory and written with one fwrite: std::to_chars with
+// chars_format::general and precision 9 yields the digits of printf("%.9g") (the C++17 contract), several times faster than a
+// fprintf per point.  `cols`: 1 = one packed 0x00RRGGBB integer (PCD), 3 = red green blue (PLY).
+void append_cloud_ascii(std::string &out, const float *xyz, const uint8_t *rgb, int64_t n, int cols)
+{
+    out.reserve(out.size() + (size_t)n * 48);
+    char buf[64];
+    for (int64_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) {
+            const auto r = std::to_chars(buf, buf + sizeof buf, xyz[3 * i + k], std::chars_format::general, 9);
+            out.append(buf, r.ptr);
+            out.push_back(' ');
+        }
+        if (cols == 1) {
+            const unsigned packed = ((unsigned)rgb[3 * i] << 16) | ((unsigned)rgb[3 * i + 1] << 8) | (unsigned)rgb[3 * i + 2];
+            const auto r = std::to_chars(buf, buf + sizeof buf, packed);
+            out.append(buf, r.ptr);
+        } else {
+            for (int k = 0; k < 3; k++) {
+                const auto r = std::to_chars(buf, buf + sizeof buf, (unsigned)rgb[3 * i + k]);
+                out.append(buf, r.ptr);
+                if (k < 2) out.push_back(' ');
+            }
+        }
+        out.push_back('\n');
+    }
 }
 
 // One input frame: the caller's memory (sl3d_shim_provide_image under one of the names; no copy) or the first readable file of
@@ -627,9 +656,9 @@ void save_point_cloud(unsigned cloud_index)
         }
         fwrite(rec.data(), 1, rec.size(), f);
     } else {
-        for (int64_t i = 0; i < n; i++)
-            fprintf(f, "%.9g %.9g %.9g %u\n", xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2],
-                    ((unsigned)rgb[3 * i] << 16) | ((unsigned)rgb[3 * i + 1] << 8) | (unsigned)rgb[3 * i + 2]);
+        std::string rows;
+        append_cloud_ascii(rows, xyz.data(), rgb.data(), n, 1);
+        fwrite(rows.data(), 1, rows.size(), f);
     }
     fclose(f);
     f = fopen((base + ".ply").c_str(), "wb");
@@ -645,8 +674,9 @@ void save_point_cloud(unsigned cloud_index)
         }
         fwrite(rec.data(), 1, rec.size(), f);
     } else {
-        for (int64_t i = 0; i < n; i++)
-            fprintf(f, "%.9g %.9g %.9g %u %u %u\n", xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+        std::string rows;
+        append_cloud_ascii(rows, xyz.data(), rgb.data(), n, 3);
+        fwrite(rows.data(), 1, rows.size(), f);
     }
     fclose(f);
     fprintf(stderr, "Saved %lld data points to %s.pcd / .ply\n", (long long)n, base.c_str());
@@ -762,8 +792,9 @@ void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float 
         }
         fwrite(rec.data(), 1, rec.size(), f);
     } else {
-        for (long long i = 0; i < n; i++)
-            fprintf(f, "%.9g %.9g %.9g %u %u %u\n", all_xyz[3 * i], all_xyz[3 * i + 1], all_xyz[3 * i + 2], all_rgb[3 * i], all_rgb[3 * i + 1], all_rgb[3 * i + 2]);
+        std::string rows;
+        append_cloud_ascii(rows, all_xyz.data(), all_rgb.data(), (int64_t)n, 3);
+        fwrite(rows.data(), 1, rows.size(), f);
     }
     fclose(f);
 }

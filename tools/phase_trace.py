@@ -44,7 +44,7 @@ a = a[(a > 0).all(axis=1)]                      # waves that ran (padded blocks 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"phase_trace_{V}.npz"), stamps=a, ms_per_launch=ms)
 t = (a - a[:, 0].min()) / 100.0                  # microseconds since the first wave entered the kernel
-names = ["request mask+cam, rcp table", "wait mask, issue plane loads", "camera coords -> LDS", "wait planes + decode", "phase A (stages 3-5)", "phase B (stage 7)", "issue stores"]
+names = ["reciprocal table", "item set-up", "issue plane loads", "wait planes + decode", "phase A (stages 3-5)", "phase B (stage 7)", "issue stores"]
 print(f"{V} view(s) per launch, back to back: {ms * 1e3:.2f} us per launch (HIP events, 200 launches); traced launch: "
       f"{len(t)} waves, first entry -> last store issued {t[:, 7].max():.2f} us")
 print("per-wave phase durations (us): median / p90")
@@ -57,7 +57,7 @@ start = np.sort(t[:, 0])
 print("waves entering the kernel per microsecond: " + " ".join(str(int(((start >= u) & (start < u + 1)).sum())) for u in range(int(start.max()) + 1)))
 print("  t(us)  loading  decode+A  B  (waves in each state at t; 'loading' = plane loads issued, not landed)")
 for u in np.arange(0.5, t[:, 7].max(), 1.0):
-    loading = ((t[:, 1] <= u) & (t[:, 4] > u)).sum()
+    loading = ((t[:, 2] <= u) & (t[:, 4] > u)).sum()
     a_ = ((t[:, 4] <= u) & (t[:, 5] > u)).sum()
     b_ = ((t[:, 5] <= u) & (t[:, 7] > u)).sum()
     print(f"  {u:5.1f}  {loading:6d}  {a_:6d}  {b_:6d}")
