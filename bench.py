@@ -444,7 +444,8 @@ def main():
                                       "roofline": {"bound": "hbm", "achieved": round(cl_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                    "frac": round(cl_achieved / HBM_PEAK_GBS, 4), "traffic": cl_traffic,
                                                    "traffic_source": cl_traffic_src and f"{cl_traffic_src} (committed PMC run of this command, scaled to this launch; not measured in this run)",
-                                                   "kernel": kernel_name.replace(", false>", ", 2>"), "avg_launch_ms": round(kms, 4)},
+                                                   "kernel": kernel_name[:-len("0>")] + "2>", "launches": "the fused kernel + k_seg_scan (both between the HIP events)",
+                                                   "avg_launch_ms": round(kms, 4)},
                                       "how": "sl3d_run_clouds: the fused kernel writes SEGMENTED ordered clouds (every wave compacts its 256 scan pixels into its own "
                                              "slot: no tile waits for another) + one scan launch for offsets and totals; value = launches + the wait for the "
                                              "per-view counts; kernel_only = both launches between HIP events"}
