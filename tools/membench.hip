@@ -143,6 +143,164 @@ __global__ __launch_bounds__(256, OCC) void k_steps(const uint8_t *in, size_t pl
     }
 }
 
+// Round 3: what a PERSISTENT, VIEW-MAJOR walk of the same bytes would give the data path: as many blocks as the machine holds
+// (slots), every block walks the views in the same order (outer loop) and, inside a view, its share of the tiles (inner loop:
+// tile b, b + slots, ...), so that at any moment the whole machine streams the 47 planes of about ONE view instead of 8 views at
+// once; per step the lane also reads 32 B of a per-pixel table (the camera table, which nothing amortises in this order; it is
+// re-read per view, from L2 / the Infinity Cache).  Compare with flags 0 (one view per block) and 65 (8 views per lane).
+template <int P, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_viewmajor(const uint8_t *in, size_t plane, size_t view_stride, int nviews, const double *camtab, float4 *out,
+                                                        unsigned *outv, size_t nquads, int use_tab)
+{
+    const size_t ntiles = (nquads + 255) / 256;
+    for (int view = 0; view < nviews; view++)
+        for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const size_t q = tile * 256 + threadIdx.x;
+            if (q >= nquads) continue;
+            const uint8_t *base = in + (size_t)view * view_stride + q * 4;
+            unsigned v[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(base + p * plane);
+            double t = 0;
+            if (use_tab) {
+                const double2 *tp = (const double2 *)(camtab + q * 4);
+                const double2 a = tp[0], b = tp[1];
+                t = a.x + a.y + b.x + b.y;
+            }
+            unsigned a = 0, b = 0, c = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+            float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u) + (float)t, fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+                  fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+            float4 *op = out + ((size_t)view * nquads + q) * 3;
+            op[0] = make_float4(fa, fb, fc, fa); op[1] = make_float4(fb, fc, fa, fb); op[2] = make_float4(fc, fa, fb, fc);
+            outv[(size_t)view * nquads + q] = a;
+        }
+}
+
+// Round 3: persistent WAVES that draw their work from a ticket counter, items in address order (view-major, then tile, 256
+// pixels = one wave's quads per item): the set of tiles in flight stays the narrow moving window the dispatcher gives short
+// blocks (flags 0) although the waves loop -- which is what would let a looping kernel keep its in-wave pipeline AND the DRAM
+// locality of one-view-per-block.  The next ticket is drawn while the current item is processed; `prefetch` also requests the
+// next item's planes before the current item's stores (two register sets).
+template <int P, int OCC, bool PREFETCH>
+__global__ __launch_bounds__(256, OCC) void k_ticket(const uint8_t *in, size_t plane, size_t view_stride, int nviews, const double *camtab, float4 *out,
+                                                     unsigned *outv, size_t nquads, int use_tab, unsigned *counter)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t nw = (nquads + 63) / 64, total = nw * (size_t)nviews;  // wave items per view, items in all
+    auto draw = [&]() -> unsigned {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(counter, 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    auto issue = [&](unsigned item, unsigned (&v)[P], double2 (&ct)[2]) {
+        const size_t view = item / nw, q = (item % nw) * 64 + lane;
+        const size_t qq = q < nquads ? q : nquads - 1;
+        const uint8_t *base = in + view * view_stride + qq * 4;
+#pragma unroll
+        for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(base + p * plane);
+        if (use_tab) {
+            const double2 *tp = (const double2 *)(camtab + qq * 4);
+            ct[0] = tp[0];
+            ct[1] = tp[1];
+        }
+    };
+    auto finish = [&](unsigned item, const unsigned (&v)[P], const double2 (&ct)[2]) {
+        const size_t view = item / nw, q = (item % nw) * 64 + lane;
+        if (q >= nquads) return;
+        const double t = use_tab ? ct[0].x + ct[0].y + ct[1].x + ct[1].y : 0.0;
+        unsigned a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+        float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u) + (float)t, fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+              fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+        float4 *op = out + (view * nquads + q) * 3;
+        op[0] = make_float4(fa, fb, fc, fa); op[1] = make_float4(fb, fc, fa, fb); op[2] = make_float4(fc, fa, fb, fc);
+        outv[view * nquads + q] = a;
+    };
+    unsigned item = draw();
+    if (item >= total) return;
+    if constexpr (!PREFETCH) {
+        for (;;) {
+            unsigned va[P];
+            double2 ca[2] = {};
+            const unsigned next = draw();
+            issue(item, va, ca);
+            finish(item, va, ca);
+            if (next >= total) return;
+            item = next;
+        }
+    }
+    unsigned va[P], vb[P];
+    double2 ca[2] = {}, cb[2] = {};
+    issue(item, va, ca);
+    for (;;) {
+        const unsigned next = draw();
+        if (PREFETCH) {
+            if (next < total) issue(next, vb, cb);
+            finish(item, va, ca);
+            if (next >= total) break;
+            item = next;
+            const unsigned next2 = draw();
+            if (next2 < total) issue(next2, va, ca);
+            finish(item, vb, cb);
+            if (next2 >= total) break;
+            item = next2;
+            // (the ticket drawn at the top of the loop for this item is next2's successor: handled by the next iteration)
+        } else {
+            finish(item, va, ca);
+            if (next >= total) break;
+            item = next;
+            issue(item, va, ca);
+        }
+    }
+}
+
+// Round 3: the same static view-major walk with the NEXT item's loads issued before the current item's stores (two register
+// sets): a looping wave then never has to wait for the acknowledgement of its own stores before it can consume loads (vmcnt
+// counts loads and stores in one in-order counter on this ISA), which is what separates a looping kernel from short blocks.
+template <int P, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_viewmajor_pipe(const uint8_t *in, size_t plane, size_t view_stride, int nviews, float4 *out, unsigned *outv,
+                                                             size_t nquads)
+{
+    const size_t ntiles = (nquads + 255) / 256, total = ntiles * (size_t)nviews;
+    auto issue = [&](size_t item, unsigned (&v)[P]) {
+        const size_t view = item / ntiles, q = (item % ntiles) * 256 + threadIdx.x, qq = q < nquads ? q : nquads - 1;
+        const uint8_t *base = in + view * view_stride + qq * 4;
+#pragma unroll
+        for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(base + p * plane);
+    };
+    auto finish = [&](size_t item, const unsigned (&v)[P]) {
+        const size_t view = item / ntiles, q = (item % ntiles) * 256 + threadIdx.x;
+        if (q >= nquads) return;
+        unsigned a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+        float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+              fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+        float4 *op = out + (view * nquads + q) * 3;
+        op[0] = make_float4(fa, fb, fc, fa); op[1] = make_float4(fb, fc, fa, fb); op[2] = make_float4(fc, fa, fb, fc);
+        outv[view * nquads + q] = a;
+    };
+    size_t item = blockIdx.x;
+    if (item >= total) return;
+    unsigned va[P], vb[P];
+    issue(item, va);
+    for (;;) {
+        size_t next = item + gridDim.x;
+        if (next < total) issue(next, vb);
+        finish(item, va);
+        if (next >= total) break;
+        item = next;
+        next = item + gridDim.x;
+        if (next < total) issue(next, va);
+        finish(item, vb);
+        if (next >= total) break;
+        item = next;
+    }
+}
+
 int main(int argc, char **argv)
 {
     constexpr int P = 47;
@@ -195,6 +353,55 @@ int main(int argc, char **argv)
                 CHK(hipGetLastError());
                 printf("steps occ>=%d flags=%2d  %8.3f ms  %7.1f GB/s  %6.1f Gpx/s\n", occ == 0 ? 8 : 4, flags, best, by / best / 1e6, vpx * nviews / best / 1e6);
             }
+        // persistent, view-major walk (round 3), 4 waves/SIMD like the fused kernel: with and without the per-step table read
+        double *ct;
+        CHK(hipMalloc(&ct, vpx * 8));
+        CHK(hipMemset(ct, 0, vpx * 8));
+        for (int slots : {1024, 2048, 512})
+            for (int use_tab = 0; use_tab < 2; use_tab++) {
+                float best = 1e9;
+                for (int it = 0; it < 8; it++) {
+                    CHK(hipEventRecord(e0));
+                    hipLaunchKernelGGL((k_viewmajor<P, 4>), dim3(slots), dim3(256), 0, 0, fr, vpx, vpx * P, nviews, ct, o, ov, nq, use_tab);
+                    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                    if (it >= 2 && ms < best) best = ms;
+                }
+                CHK(hipGetLastError());
+                printf("view-major persistent, %4d blocks, table %d  %8.3f ms  %7.1f GB/s  %6.1f Gpx/s\n", slots, use_tab, best, by / best / 1e6, vpx * nviews / best / 1e6);
+            }
+        for (int slots : {768, 1024, 512}) {
+            float best = 1e9;
+            for (int it = 0; it < 8; it++) {
+                CHK(hipEventRecord(e0));
+                hipLaunchKernelGGL((k_viewmajor_pipe<P, 3>), dim3(slots), dim3(256), 0, 0, fr, vpx, vpx * P, nviews, o, ov, nq);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (it >= 2 && ms < best) best = ms;
+            }
+            CHK(hipGetLastError());
+            printf("view-major persistent, next loads before the stores, %4d blocks  %8.3f ms  %7.1f GB/s  %6.1f Gpx/s\n", slots, best, by / best / 1e6, vpx * nviews / best / 1e6);
+        }
+        // ticketed persistent waves (round 3)
+        unsigned *cnt;
+        CHK(hipMalloc(&cnt, 4));
+        for (int pre = 0; pre < 2; pre++)
+            for (int slots : {1024})
+                for (int use_tab = 0; use_tab < 1; use_tab++) {
+                    float best = 1e9;
+                    for (int it = 0; it < 4; it++) {
+                        CHK(hipMemsetAsync(cnt, 0, 4, 0));
+                        CHK(hipEventRecord(e0));
+                        if (pre) hipLaunchKernelGGL((k_ticket<P, 3, true>), dim3(slots), dim3(256), 0, 0, fr, vpx, vpx * P, nviews, ct, o, ov, nq, use_tab, cnt);
+                        else hipLaunchKernelGGL((k_ticket<P, 4, false>), dim3(slots), dim3(256), 0, 0, fr, vpx, vpx * P, nviews, ct, o, ov, nq, use_tab, cnt);
+                        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                        if (it >= 2 && ms < best) best = ms;
+                    }
+                    CHK(hipGetLastError());
+                    printf("ticketed persistent waves, prefetch %d, %4d blocks, table %d  %8.3f ms  %7.1f GB/s  %6.1f Gpx/s\n", pre, slots, use_tab, best, by / best / 1e6,
+                           vpx * nviews / best / 1e6);
+                }
     }
     return 0;
 }
