@@ -87,6 +87,12 @@ def main():
                         if not np.array_equal(sc.code(a)[va], o.code(a)[va]): msg.append(f"code axis {a}")
                         if not np.array_equal(sc.unwrapped_phase(a)[va], o.unwrapped_phi(a)[va]): msg.append(f"unwrapped axis {a}")
                     if not np.array_equal(sc.c_p_map()[v], o.c_p_map()[v]): msg.append("c_p_map")
+                    # the reference's [col][row] globals, transposed on the device, == the transposed row-major planes
+                    rm = {0: sc.valid_map(0), 2: sc.valid_map(2), 4: sc.wrapped_phase(1), 5: sc.unwrapped_phase(0), 8: sc.code(1), 9: sc.intersection_points()}
+                    for which, plane in rm.items():
+                        want = plane.transpose(1, 0, 2) if which == 9 else plane.T
+                        if not np.array_equal(sc.global_colrow(which), want.astype(np.float64 if which == 9 else np.float32 if 3 <= which <= 6 else np.int32), equal_nan=True):
+                            msg.append(f"colrow global {which}")
         # the same window as row stripes behind sl3d_group_* (random stripe count, both transports) == the single context
         if H >= 2 and not msg:
             ns = int(rng.integers(1, min(H, 6) + 1))
@@ -108,6 +114,14 @@ def main():
                 g.gather_clouds(0, 1)
                 if not np.array_equal(g.cloud(0), a_[0][a_[1] == 1]):
                     msg.append(f"group cloud of {ns} stripes != xyz[valid]")
+                g.run(0, 1)
+                hx, hv = g.download_points(0, 1)   # every stripe straight into the host images
+                if not (np.array_equal(hv[0], a_[1]) and np.array_equal(hx[0], a_[0], equal_nan=True)):
+                    msg.append(f"group download_points of {ns} stripes != single context")
+                fr = np.stack(cap["planes_v"] + cap["planes_h"])[None]
+                hx, hv = g.process_views(fr)
+                if not (np.array_equal(hv[0], a_[1]) and np.array_equal(hx[0], a_[0], equal_nan=True)):
+                    msg.append(f"group process_views of {ns} stripes != single context")
         # a batch launch over several views with different masks (empty and full ones included) == the views one by one,
         # dense and compacted: exercises the view loop (views per lane, the pipelined plane loads, skipped views)
         if not msg:
@@ -129,6 +143,16 @@ def main():
                 sc.run(0, V)
                 batch = [sc.points(v) for v in range(V)]
                 bclouds = sc.fused_clouds(0, V)
+                # the consumers of the segmented clouds: host copies (pageable, and pinned = written by the gap-closing kernel),
+                # registration straight from the segments == registration of the dense results; the look-back context agrees
+                got = sc.download_clouds(0, V)
+                pin = sc.pinned((max(1, sum(len(c) for c in bclouds)) * 3,), np.float32)
+                got_pin = sc.download_clouds(0, V, out=pin)
+                for v in range(V):
+                    if not (np.array_equal(got[v], bclouds[v]) and np.array_equal(got_pin[v], bclouds[v])):
+                        msg.append(f"batch of {V}: download_clouds of view {v}")
+                if not np.array_equal(sc.register_clouds(0, V, 3.5, -2.0, 250.0, 11.25), sc.register_views(0, V, 3.5, -2.0, 250.0, 11.25)):
+                    msg.append(f"batch of {V}: register_clouds != register_views")
                 for v in range(V):
                     sc.run(v, 1)
                     one = sc.points(v)
