@@ -916,7 +916,12 @@ __device__ __forceinline__ void triangulate_from(const KParams &P, CalP Cp, cons
 #define SL3D_SEG_LDS 1 /* 1: a wave compacts its points inside its own 3 KB of the LDS staging area and stores whole 16-byte chunks (coalesced); 0: 12-byte stores per point */
 #endif
 #define SL3D_SEG_POINTS 256 /* pixels (point slots) per segment = one wave of the fused kernel */
-template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE = 0>
+// RCPT = false: the instantiation for SMALL launches (a handful of views: the reference's one scan per call): 1/d of the atan2
+// quotient by v_rcp_f64 + one Newton step instead of the LDS table, whose fill (768 IEEE divisions and a block barrier per block)
+// nothing amortises when a block lives for one or two views.  Both ways are proven equal to the host's libm on the whole lattice
+// by the device self-check.  Round 3, alternating on one box: 1 view 30.3 against 31.6 us (rocprofv3 kernel durations), 2 views
+// -2.7 %, 4 views -1 %; at 16 views per launch the table is as fast (dense) or 1.4 % faster (clouds) -- profiles/r03_rcp_table_ab*.txt.
+template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE = 0, bool RCPT = true>
 __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     constexpr bool COMPACT = CMODE == 1;  // the single-pass look-back compaction (everything named COMPACT below)
@@ -935,7 +940,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     __shared__ __attribute__((aligned(16))) float s_mid[NMID > 0 ? NMID * SL3D_BLOCK * 12 : 4];
     __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
     // (the compacting kernel with three views of slack gives the table's 6 KB to its staging areas and computes 1/d: -1 %)
-    constexpr bool RCP_TAB = SL3D_RCP_LDS != 0 && !(COMPACT && SL3D_SLACK >= 3);
+    constexpr bool RCP_TAB = RCPT && SL3D_RCP_LDS != 0 && !(COMPACT && SL3D_SLACK >= 3);
     __shared__ __attribute__((aligned(16))) double s_rcp[RCP_TAB ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
     SL3D_STAMP(0);
     if (RCP_TAB) {
@@ -1639,11 +1644,19 @@ int fused_tiles(const KParams &P)
 
 // Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT: plane tests fold away)
 // and for the unroll bounds 8 / 12 / 16 otherwise; the parity mode and the 4-/5-step fringes use the bounds only.
+// launches of at most this many views take the instantiation without the LDS reciprocal table (dense 3-step timed kernels)
+#define SL3D_SMALL_LAUNCH_VIEWS 4
 template <bool KEEP, bool FGEN, int RIG, int COMPACT>
 static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     const int nmax = nv > nh ? nv : nh;
-#define SL3D_LAUNCH(NM, EX) hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, COMPACT>), grid, block, 0, st, P, C, first_view, n_views, vpt)
+    constexpr bool HAS_SMALL = !KEEP && !FGEN && COMPACT == 0 && SL3D_RCP_LDS != 0;  // (the only family that has the second instantiation)
+    const bool small = HAS_SMALL && n_views <= SL3D_SMALL_LAUNCH_VIEWS;
+#define SL3D_LAUNCH(NM, EX)                                                                                                              \
+    do {                                                                                                                                 \
+        if (small) hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, COMPACT, !HAS_SMALL>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
+        else hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, COMPACT>), grid, block, 0, st, P, C, first_view, n_views, vpt);         \
+    } while (0)
     if (!KEEP && !FGEN && nv == nh && nv >= 6 && nv <= 12) {
         switch (nv) {
         case 6: SL3D_LAUNCH(6, true); break;

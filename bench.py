@@ -368,7 +368,8 @@ def main():
     exact = 6 <= N <= 12                                   # the instantiation launch_fused picks (sl3d_kernels.hip)
     nmax = N if exact else next(m for m in (8, 12, 16) if m >= N)
     rig_id = {"reference": 1, "distorted": 2, "general": 0}[args.rig]
-    kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if exact else 'false'}, {rig_id}, 0>"
+    small = n_views <= 4                                    # SL3D_SMALL_LAUNCH_VIEWS: the instantiation without the LDS reciprocal table
+    kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if exact else 'false'}, {rig_id}, 0, {'false' if small else 'true'}>"
     traffic, traffic_src = measured_traffic(px_per_launch) if alg_bytes_px == 60 else (None, None)
 
     out = {
@@ -444,7 +445,7 @@ def main():
                                       "roofline": {"bound": "hbm", "achieved": round(cl_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                    "frac": round(cl_achieved / HBM_PEAK_GBS, 4), "traffic": cl_traffic,
                                                    "traffic_source": cl_traffic_src and f"{cl_traffic_src} (committed PMC run of this command, scaled to this launch; not measured in this run)",
-                                                   "kernel": kernel_name[:-len("0>")] + "2>", "launches": "the fused kernel + k_seg_scan (both between the HIP events)",
+                                                   "kernel": kernel_name.rsplit(", 0, ", 1)[0] + ", 2, true>", "launches": "the fused kernel + k_seg_scan (both between the HIP events)",
                                                    "avg_launch_ms": round(kms, 4)},
                                       "how": "sl3d_run_clouds: the fused kernel writes SEGMENTED ordered clouds (every wave compacts its 256 scan pixels into its own "
                                              "slot: no tile waits for another) + one scan launch for offsets and totals; value = launches + the wait for the "
