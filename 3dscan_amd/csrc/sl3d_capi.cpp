@@ -343,7 +343,8 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
             C.tcn[i] = -(R[0 * 3 + i] * tc[0] + R[1 * 3 + i] * tc[1] + R[2 * 3 + i] * tc[2]);
         }
         C.fx2 = Kc[0] * Kc[0];
-        C.fy2 = Kc[4] * Kc[4];
+        C.fy2 = Kc[1] * Kc[1] + Kc[4] * Kc[4];
+        C.fxs = Kc[0] * Kc[1];
     }
     memcpy(x->S.tc, tc, sizeof x->S.tc);
     memcpy(x->S.tp, tp, sizeof x->S.tp);
@@ -353,7 +354,10 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
     // rig class of the timed fused kernel (pixel_chain): 1 = the reference's kind of calibration, 2 = distorted projector
     // behind a per-calibration undistortion table, 0 = everything else, evaluated in the kernel
-    x->rig = !x->C.cam.plain ? 0 : x->C.proj.identity ? 1 : 2;
+    // (camera-frame solve: any upper-triangular affine camera matrix -- a skew term included; only a K with a perspective row
+    // or a non-zero K[1][0] is left to the general kernel)
+    const bool cam_frame_ok = x->C.cam.affine && Kc[3] == 0.0;
+    x->rig = !cam_frame_ok ? 0 : x->C.proj.identity ? 1 : 2;
     x->P.proj_disp = nullptr;
     x->P.cam_tab = nullptr;
     x->P.cam_tab_kind = 0;

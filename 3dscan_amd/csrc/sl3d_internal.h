@@ -31,12 +31,14 @@ struct DevCal {
     double Ac[12], Ap[12];
     Intr cam, proj;
     // Camera-frame form of the same least-squares problem (fast path of the fused kernel; valid when the camera matrix
-    // is plain, K = [fx 0 cx; 0 fy cy; 0 0 1]).  With Y = Rc*X + tc the two camera rows of P become fx*(1,0,-xn) and
-    // fy*(0,1,-yn) with a zero right-hand side ((xn,yn) = undistorted normalised coordinates), so their part of
-    // P^T P is 4 flops instead of 26; the rigid change of variables leaves the minimiser unchanged.
+    // is upper triangular and affine, K = [fx s cx; 0 fy cy; 0 0 1]).  With Y = Rc*X + tc the two camera rows of P become
+    // fx*(1,0,-xn) + s*(0,1,-yn) and fy*(0,1,-yn) with a zero right-hand side ((xn,yn) = undistorted normalised coordinates --
+    // cvUndistortPoints normalises with fx, fy, cx, cy only, the skew enters when K re-projects), so their part of
+    // P^T P is a handful of flops instead of 26; the rigid change of variables leaves the minimiser unchanged.
     double Apc[12];       // Ap * [Rc tc; 0 1]^-1 : projector projection matrix acting on camera-frame points
     double Rct[9], tcn[3];  // X = Rct*Y + tcn  (Rct = Rc^T, tcn = -Rc^T tc)
-    double fx2, fy2;      // Kc[0]^2, Kc[4]^2
+    double fx2, fy2;      // Kc[0]^2, Kc[1]^2 + Kc[4]^2
+    double fxs;           // Kc[0]*Kc[1]: the skew term (0 for the usual K); the camera-frame form holds for any upper-triangular affine K
 };
 
 // Scene + camera model of the synthetic-capture generator (k_synth).

@@ -73,6 +73,7 @@
 #ifndef SL3D_MASK_PREFETCH
 #define SL3D_MASK_PREFETCH 1
 #endif
+
 // measurement only (tools/ab.sh builds with -DSL3D_MEASURE -DSL3D_ABLATE=n): 1 = no per-pixel arithmetic (xyz made of the raw
 // decode results), 2 = no mask reads, 4 = no xyz stores.  Results are wrong by construction; the shipped build has neither
 // the compile-time switch nor the run-time hooks (SL3D_VPT / SL3D_ABLATE environment variables, KParams::ablate).
@@ -513,8 +514,10 @@ template <typename CalT>
 __device__ __forceinline__ void triangulate_camframe(const CalT &C, const PinnedRows &R, double xn, double yn, double up, double vp, double X[3],
                                                      bool &singular)
 {
-    const double a = C.fx2 * xn, b = C.fy2 * yn;
-    double m00 = C.fx2, m01 = 0, m02 = -a, m11 = C.fy2, m12 = -b, m22 = fma(a, xn, b * yn), g0 = 0, g1 = 0, g2 = 0;
+    // camera rows fx*(1,0,-xn) + s*(0,1,-yn) and fy*(0,1,-yn): their outer products, with q = fx*s and r = s^2 + fy^2
+    // (q = 0 for the usual K: a and b are then fx^2*xn and fy^2*yn, bit for bit what round 2 computed)
+    const double a = fma(C.fxs, yn, C.fx2 * xn), b = fma(C.fxs, xn, C.fy2 * yn);
+    double m00 = C.fx2, m01 = C.fxs, m02 = -a, m11 = C.fy2, m12 = -b, m22 = fma(a, xn, b * yn), g0 = 0, g1 = 0, g2 = 0;
     tri_row(C.Apc, R.p2, up, m00, m01, m02, m11, m12, m22, g0, g1, g2, 0);
     tri_row(C.Apc, R.p2, vp, m00, m01, m02, m11, m12, m22, g0, g1, g2, 1);
     const double c00 = fma(m11, m22, -m12 * m12);
@@ -747,9 +750,9 @@ struct PixelResult {
 // RIG (stage 7 of the timed fused kernel, chosen by launch_fused from the calibration):
 //   0  general: any K, any distortion, everything evaluated in the kernel with the reference's operation order
 //      (also what the parity mode and the per-stage kernels run)
-//   1  camera K plain, projector without distortion and with a plain K (the reference's own calibration): camera-frame
-//      least squares, the projector point is the correspondence itself
-//   2  camera K plain, projector distorted: camera-frame least squares; the undistorted projector point comes from the
+//   1  camera K upper triangular + affine (fx, skew, fy, cx, cy), projector without distortion and with a plain K (the reference's
+//      own calibration): camera-frame least squares, the projector point is the correspondence itself
+//   2  the same camera, any other projector: camera-frame least squares; the undistorted projector point comes from the
 //      per-calibration table KParams::proj_disp (one float2 displacement per projector pixel, built by k_proj_table with
 //      the same 5-iteration undistortion) -- the reference also tabulates it (7/triangulation.cpp:363-378), per scan
 template <bool KEEP, int RIG, typename CalP>
@@ -939,6 +942,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     constexpr int NMID = COMPACT ? SL3D_SLACK - 1 : 0;
     __shared__ __attribute__((aligned(16))) float s_mid[NMID > 0 ? NMID * SL3D_BLOCK * 12 : 4];
     __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
+
     // (the compacting kernel with three views of slack gives the table's 6 KB to its staging areas and computes 1/d: -1 %)
     constexpr bool RCP_TAB = RCPT && SL3D_RCP_LDS != 0 && !(COMPACT && SL3D_SLACK >= 3);
     __shared__ __attribute__((aligned(16))) double s_rcp[RCP_TAB ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
@@ -1569,6 +1573,11 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             }
         }
         if (view == v_begin) SL3D_STAMP(5);
+        // (Round 3 read the ISA of the table rigs: their 4 projector-table entries are requested BEHIND the next view's 46 plane
+        // loads, so -- vmcnt counts in issue order -- phase B starts only once those planes have landed.  Requesting them first,
+        // waiting, and parking them in the pixel's spare staging slots was built and measured: distorted rig 77.8-78.2 Gpx/s
+        // against 79.0-79.5 for this order (profiles/r03_gather_first_ab.txt).  The wave waits for those planes at the next decode
+        // anyway; an L2 round trip of its own in front of the plane issue is what costs.)
         if (PIPE && view + 1 < v_end) {
             vb_next = valid_bits(mq);
             if (view + 2 < v_end) mq = load_mask_quad(P, view + 2, cq, row);
