@@ -237,7 +237,9 @@ def side_figures(args, scm, syn, np, dev_index):
         with ctx("reference", N, args.views, clouds_lookback=True) as sc:
             v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 300, clouds=True)
             out["clouds_lookback_kernel_only"] = {"value": v, "unit": "Mpixels/s", "ms_per_launch": ms}
-        for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig0_general")):
+        # (distorted: projector k1,k2,p1,p2 + camera tangential terms; general: a skewed camera matrix as well -- since round 3 both
+        # take the pipelined table kernel, RIG 2; the un-pipelined general kernel is left with perspective rows in K)
+        for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig2_general_skewed_camera")):
             with ctx(rig, N, args.views) as sc:
                 v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 400)
                 out[key] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms}
