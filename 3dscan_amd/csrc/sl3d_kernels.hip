@@ -50,6 +50,12 @@
 #ifndef SL3D_NT_STORES
 #define SL3D_NT_STORES 0
 #endif
+// dense xyz stores: 0 = three 16-byte stores per lane at a 48-byte lane stride (the L2 merges the partial lines), 1 = read back
+// across the wave's lanes from LDS so that every store instruction writes 1 KiB of whole lines for EVERY launch (round 1: -1.2 %,
+// round 3: -2.4 % at 16 views; the one-view launch takes the coalesced form whatever this switch says, see store_quad)
+#ifndef SL3D_COALESCED_STORES
+#define SL3D_COALESCED_STORES 0
+#endif
 // 1: XCD-banded tile order.  Workgroups go round-robin to the 8 XCDs (each with its own L2); with the natural order the
 // three tiles that share a mask row (vertical neighbours are 1.9 tiles apart) land on three different L2s, and the mask
 // is what the measured 1.046x traffic over the algorithmic bytes consists of.  With 1, XCD x walks the x-th eighth of
@@ -1273,6 +1279,17 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
                 __builtin_nontemporal_store(sv[0], ov);
                 __builtin_nontemporal_store(sv[1], ov + 1);
                 __builtin_nontemporal_store(sv[2], ov + 2);
+            } else if ((SL3D_COALESCED_STORES || (!RCPT && n_views == 1)) && !KEEP && __ballot(true) == ~0ull) {
+                // a full wave's 64 x 48 B of results are 3 KB contiguous in LDS AND in the dense plane (quads are consecutive in the
+                // pitch-padded layout): every store instruction writes 1 KiB of whole lines, lane after lane, as the segmented kernel
+                // does.  Round 3, alternating: 16 views per launch -2.4 % (five of five), 4 views -1.5 %, ONE view 29.0 against
+                // 29.6 us (profiles/r03_coalesced_stores_ab.txt) -- so only the one-view launch of the small-launch instantiation takes it.
+                const unsigned lane_ = threadIdx.x & 63u;
+                const float4 *wb4 = (const float4 *)(s_xyz + (threadIdx.x >> 6) * (64u * 12u));
+                float4 *o4 = (float4 *)(P.points + 3 * (px - 4u * lane_));
+                o4[lane_] = wb4[lane_];
+                o4[64u + lane_] = wb4[64u + lane_];
+                o4[128u + lane_] = wb4[128u + lane_];
             } else {
                 out_xyz[0] = sx[0];
                 out_xyz[1] = sx[1];
