@@ -56,6 +56,9 @@
 #ifndef SL3D_COALESCED_STORES
 #define SL3D_COALESCED_STORES 0
 #endif
+#ifndef SL3D_EARLY_PLANES
+#define SL3D_EARLY_PLANES 1 /* small-launch instantiation: the first view's planes requested before the mask is known (see EARLY in k_fused) */
+#endif
 // 1: XCD-banded tile order.  Workgroups go round-robin to the 8 XCDs (each with its own L2); with the natural order the
 // three tiles that share a mask row (vertical neighbours are 1.9 tiles apart) land on three different L2s, and the mask
 // is what the measured 1.046x traffic over the algorithmic bytes consists of.  With 1, XCD x walks the x-th eighth of
@@ -991,6 +994,12 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     }
     // everything of an item that depends on the pixel only; false if this lane has nothing to do in a dense kernel
     MaskQuad mq_first = {0u};
+    // EARLY (the small-launch instantiation of the pipelined dense kernels): the first view's planes are requested UNCONDITIONALLY,
+    // right behind the item's mask / camera-table requests and before any of those is waited for -- one round trip instead of two
+    // (mask -> valid bits -> plane loads) in front of the first decode, at the price of plane loads for quads that turn out to be
+    // masked off.  It pays where a block lives for one or two views (SL3D_EARLY_PLANES, profiles/README.md).
+    constexpr bool EARLY = SL3D_EARLY_PLANES && !RCPT && CMODE == 0 && SL3D_PIPE && SL3D_SPLIT && !KEEP && RIG != 0;
+    double camt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // EARLY: the lane's camera-table entries between their request and finish_cam
     auto begin_item = [&](unsigned tile_, int group) -> bool {
         tile = tile_;
         v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
@@ -1019,6 +1028,23 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
         // launch 31.8-32.2 us against 31.1-31.6, 16 views +-0 (profiles/r03_prologue_ab.txt).  The phase trace says why: what a
         // cold launch waits for in its first 5 us is the memory system's ramp under 4096 waves asking at once, not this
         // dependency.)
+        if (EARLY && P.use_cam_table) {  // requested only; finish_cam turns them into coordinates behind the plane requests
+            const size_t i0 = (size_t)row * P.pitch + (size_t)cq * 4;
+            if (P.use_cam_table == 1) {
+                const double2 *tp = (const double2 *)(P.cam_tab + i0);
+                const double2 a = tp[0], b = tp[1];
+                camt[0] = a.x; camt[1] = a.y; camt[2] = b.x; camt[3] = b.y;
+            } else {
+                const double2 *tp = (const double2 *)(P.cam_tab + 2 * i0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double2 a = tp[k];
+                    camt[2 * k] = a.x;
+                    camt[2 * k + 1] = a.y;
+                }
+            }
+            return true;
+        }
         if (P.use_cam_table) {
             // the per-calibration table (k_cam_table) holds what the loop below iterates; the doubles that come out are the same
             const auto &I = opaque_const(Cglobal)->cam;
@@ -1065,6 +1091,25 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             my_cam[2 * k + 1] = cv;
         }
         return true;
+    };
+    auto finish_cam = [&]() {  // EARLY: the table entries requested by begin_item -> camera coordinates in LDS (same arithmetic)
+        if (!P.use_cam_table) return;
+        const auto &I = opaque_const(Cglobal)->cam;
+        const double y0 = ((double)gy - I.cy) * I.ify;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double xn, yn;
+            if (P.use_cam_table == 1) {
+                xn = (((double)(gx0 + k)) - I.cx) * I.ifx * camt[k];
+                yn = y0 * camt[k];
+            } else {
+                xn = camt[2 * k];
+                yn = camt[2 * k + 1];
+            }
+            if (RIG == 0) reproject(xn, yn, I, xn, yn);
+            my_cam[2 * k] = xn;
+            my_cam[2 * k + 1] = yn;
+        }
     };
 
     PinnedRows PR;
@@ -1482,11 +1527,17 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     // during the pixel loop, landing in the registers the decode has freed -- was measured: 142 VGPRs, 3 waves/SIMD,
     // -6 %; squeezed into 128 with spills, -14 %.  Occupancy hides the latency better than in-wave pipelining.)
     for (;;) {  // items of this block (dense kernels: exactly one)
+    unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     if (COMPACT) {
         if (item >= n_items) break;  // block-uniform
         begin_item(item % (unsigned)P.n_tiles, (int)(item / (unsigned)P.n_tiles));
     } else if (!begin_item(SL3D_XCD_BANDS ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x, (int)blockIdx.y)) {
         return;
+    }
+    if (EARLY) {  // planes of the first view right behind the set-up requests; then the set-up results are consumed
+        issue_fringe(v_begin, f);
+        issue_gray(v_begin, g, iv);
+        finish_cam();
     }
     SL3D_STAMP(2);
     unsigned next_ticket = 0;
@@ -1495,7 +1546,6 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     // registers of view v are dead, before stage 7 -- so a wave's own arithmetic runs under its own memory requests
     // (the general rig's stage 7 is too register-hungry for it: 44 bytes of scratch per lane, -9 %)
     constexpr bool PIPE = SL3D_PIPE && SL3D_SPLIT && !KEEP && (RIG != 0 || SL3D_PIPE_RIG0);
-    unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     unsigned vb_next = 0;
     // (Round 3 read the ISA of this loop: the wait-count pass puts an s_waitcnt vmcnt(0) at the pipeline point and at the loop
     // latch -- vmcnt is ONE in-order counter for loads and stores, so the first makes a wave wait for the acknowledgement of the
@@ -1506,7 +1556,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     if (PIPE) {
         vb_next = valid_bits(mq);
         if (v_begin + 1 < v_end) mq = load_mask_quad(P, v_begin + 1, cq, row);
-        if (vb_next != 0) {
+        if (!EARLY && vb_next != 0) {  // (EARLY: they are in flight already)
             issue_fringe(v_begin, f);
             issue_gray(v_begin, g, iv);
         }
