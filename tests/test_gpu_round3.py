@@ -305,3 +305,51 @@ def test_group_host_assembly_equals_single_context(n_stripes):
             xyz, valid = g.process_views(f, xyz=ox, valid=ov)
             for v in range(NV):
                 assert np.array_equal(valid[v], want[v][1]) and np.array_equal(xyz[v], want[v][0], equal_nan=True), v
+
+
+# ---- the small-launch instantiation ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(640, 64, 8, 4), (333, 65, 9, 4), (1021, 127, 7, 4), (64, 201, 6, 8), (1920, 1080, 10, 2), (1920, 271, 10, 2)])
+@pytest.mark.parametrize("rig", ["reference", "distorted"])
+def test_one_view_launch_equals_the_batch(shape, rig):
+    """A view's result does not depend on the batch it was launched in: points and valid map of every view launched alone (the
+    small-launch instantiation: planes requested before the mask is known, no reciprocal table, coalesced stores) == the same
+    view inside a batch of 6 (the other instantiation) bit for bit -- even and odd heights, masks with holes, empty masks, masks
+    that select two middle rows or the last row only.  (The batch launch is what tests/test_gpu_parity.py and
+    tests/fuzz_parity.py hold against the oracle; the fuzz run launches its views one by one as well.)
+    Written for the banded one-view launch that round 3 built, measured and dropped (profiles/r03_bands_ab.txt)."""
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, N, fw = shape
+    PW, PH = (512, 384) if W < 1900 else (1920, 1080)
+    rng = np.random.default_rng(W + 31 * H)
+    masks = _masks(rng, W, H)
+    half = np.ones((H, W), np.uint8)
+    half[(H + 1) // 2 - 1:(H + 1) // 2 + 1] = 0          # two middle rows
+    bottom = np.zeros((H, W), np.uint8)
+    bottom[H - 1] = 1                                    # only the last row
+    masks += [half, bottom]
+    NV = len(masks)
+    r = syn.synth_rig(W, H, PW, PH)
+    if rig == "distorted":
+        r["dp"] = np.array([0.05, -0.02, 0.001, -0.0005, 0.01])
+    cal = syn.cal_tuple(r)
+    def load(sc):
+        sc.set_calibration(*cal)
+        for v, m in enumerate(masks):
+            sc.set_mask(m, view=v)
+            sc.synth_view(v, plane=(1.5 * v, 0.05, 0.04 + 0.01 * v), view_id=v, noise=2)
+    # two contexts, so that no launch finds the other's results in its output planes
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=NV) as sb, S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=NV) as ss:
+        load(sb)
+        load(ss)
+        sb.run(0, NV)
+        for v in reversed(range(NV)):
+            ss.run(v, 1)
+        n_valid = 0
+        for v in range(NV):
+            bx, bv = sb.points(v)
+            xyz, val = ss.points(v)
+            assert np.array_equal(val, bv), v
+            assert np.array_equal(xyz, bx, equal_nan=True), v
+            n_valid += int(bv.sum())
+        assert n_valid > 0
+        assert int(ss.points(NV - 1)[1][:H - 1].sum()) == 0 and int(ss.points(NV - 1)[1][H - 1].sum()) > 0
