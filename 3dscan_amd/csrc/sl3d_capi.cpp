@@ -515,19 +515,20 @@ extern "C" int sl3d_set_frames_range(sl3d_ctx *x, int view, int axis, int first_
         return fail(x, SL3D_E_INVALID_ARG, "set_frames_range: planes [first, first + n) must lie inside the axis' n_fringe + 2*n_gray planes, stride >= width");
     ON_DEVICE(x);
     const int base = (axis == 0 ? 0 : P.F + 2 * P.Nv) + first_plane;
-    bool back_to_back = true;
+    bool back_to_back = true;  // the planes follow each other in host memory with the same row stride
     for (int i = 0; i < n_planes; i++) {
-        if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames_range: null plane");
+        if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames: null plane");
         if (i && planes[i] != planes[i - 1] + stride * (size_t)P.H) back_to_back = false;
     }
     uint8_t *dst0 = x->d_frames + (size_t)view * P.view_stride + (size_t)base * P.plane_stride;
     if (back_to_back) {
+        // the device planes of an axis are back to back too (plane_stride = pitch * H): the whole range is ONE 2-D copy
         HIPCHK(x, hipMemcpy2DAsync(dst0, P.pitch, planes[0], stride, P.W, (size_t)P.H * n_planes, hipMemcpyHostToDevice, x->stream));
     } else {
         for (int i = 0; i < n_planes; i++)
             HIPCHK(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
     }
-    if (!is_pinned_host(planes[0])) HIPCHK(x, hipStreamSynchronize(x->stream));
+    if (!is_pinned_host(planes[0])) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
 }
 
@@ -539,23 +540,7 @@ extern "C" int sl3d_set_frames(sl3d_ctx *x, int view, int axis, const uint8_t *c
     const int N = axis == 0 ? P.Nv : P.Nh;
     if ((axis != 0 && axis != 1) || !planes || n_planes != P.F + 2 * N || stride < (size_t)P.W)
         return fail(x, SL3D_E_INVALID_ARG, "set_frames: expected n_fringe + 2*n_gray planes (fringe, gray, inverse) and stride >= width");
-    ON_DEVICE(x);
-    const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
-    bool back_to_back = true;  // the planes follow each other in host memory with the same row stride
-    for (int i = 0; i < n_planes; i++) {
-        if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames: null plane");
-        if (i && planes[i] != planes[i - 1] + stride * (size_t)P.H) back_to_back = false;
-    }
-    uint8_t *dst0 = x->d_frames + (size_t)view * P.view_stride + (size_t)base * P.plane_stride;
-    if (back_to_back) {
-        // the device planes of an axis are back to back too (plane_stride = pitch * H): the whole axis is ONE 2-D copy
-        HIPCHK(x, hipMemcpy2DAsync(dst0, P.pitch, planes[0], stride, P.W, (size_t)P.H * n_planes, hipMemcpyHostToDevice, x->stream));
-    } else {
-        for (int i = 0; i < n_planes; i++)
-            HIPCHK(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
-    }
-    if (!is_pinned_host(planes[0])) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
-    return SL3D_OK;
+    return sl3d_set_frames_range(x, view, axis, 0, planes, n_planes, stride);  // the whole axis
 }
 
 // sl3d_set_frames for RAW captures: what the acquisition stage does between the camera and the files stage 3/4 read
