@@ -526,7 +526,7 @@ extern "C" int sl3d_set_frames_range(sl3d_ctx *x, int view, int axis, int first_
         HIPCHK(x, hipMemcpy2DAsync(dst0, P.pitch, planes[0], stride, P.W, (size_t)P.H * n_planes, hipMemcpyHostToDevice, x->stream));
     } else {
         for (int i = 0; i < n_planes; i++)
-            HIPCHK(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+            HIPCHK_DRAIN(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
     }
     if (!is_pinned_host(planes[0])) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
@@ -566,9 +566,10 @@ extern "C" int sl3d_set_frames_raw(sl3d_ctx *x, int view, int axis, const uint8_
     short *m1 = (short *)x->d_raw;
     unsigned short *m2 = (unsigned short *)(x->d_raw + (size_t)P.W * P.H * 4);
     uint8_t *raw = x->d_raw + maps;
-    for (int i = 0; i < n_planes; i++) {
+    for (int i = 0; i < n_planes; i++)  // every pointer is checked before anything is enqueued
         if (!planes[i]) return fail(x, SL3D_E_INVALID_ARG, "set_frames_raw: null plane");
-        HIPCHK(x, hipMemcpy2DAsync(raw + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+    for (int i = 0; i < n_planes; i++) {
+        HIPCHK_DRAIN(x, hipMemcpy2DAsync(raw + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
     }
     const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
     uint8_t *dst = x->d_frames + (size_t)view * P.view_stride + (size_t)base * P.plane_stride;
@@ -627,7 +628,7 @@ extern "C" int sl3d_get_frames(sl3d_ctx *x, int view, int axis, uint8_t *const *
     const int base = axis == 0 ? 0 : P.F + 2 * P.Nv;
     for (int i = 0; i < n_planes; i++) {
         const uint8_t *src = x->d_frames + (size_t)view * P.view_stride + (size_t)(base + i) * P.plane_stride;
-        HIPCHK(x, hipMemcpy2DAsync(planes[i], stride, src, P.pitch, P.W, P.H, hipMemcpyDeviceToHost, x->stream));
+        HIPCHK_DRAIN(x, hipMemcpy2DAsync(planes[i], stride, src, P.pitch, P.W, P.H, hipMemcpyDeviceToHost, x->stream));
     }
     HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
@@ -1099,7 +1100,7 @@ extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, fl
         int64_t off = 0;
         for (int v = 0; v < n_views && off < capacity; v++) {
             const int64_t n = std::min<int64_t>(counts[v], capacity - off);
-            if (n > 0) HIPCHK(x, hipMemcpyAsync(xyz + 3 * off, dev + 3 * (size_t)v * stride, (size_t)n * 12, hipMemcpyDeviceToHost, x->stream));
+            if (n > 0) HIPCHK_DRAIN(x, hipMemcpyAsync(xyz + 3 * off, dev + 3 * (size_t)v * stride, (size_t)n * 12, hipMemcpyDeviceToHost, x->stream));
             off += n;
         }
     }
@@ -1178,7 +1179,7 @@ extern "C" int sl3d_get_clouds(sl3d_ctx *x, int first_view, int n_views, float *
     int64_t off = 0;
     for (int v = 0; v < n_views && xyz; v++) {
         const int64_t n = counts[v] < capacity - off ? counts[v] : capacity - off;
-        if (n > 0) HIPCHK(x, hipMemcpyAsync(xyz + 3 * off, dev + 3 * (size_t)v * stride, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        if (n > 0) HIPCHK_DRAIN(x, hipMemcpyAsync(xyz + 3 * off, dev + 3 * (size_t)v * stride, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         off += n > 0 ? n : 0;
     }
     HIPCHK(x, hipStreamSynchronize(x->stream));
@@ -1220,7 +1221,7 @@ extern "C" int sl3d_get_cloud_rgb(sl3d_ctx *x, int view, float *xyz, uint8_t *rg
     const int64_t n = *count < capacity ? *count : capacity;
     if (n > 0) {
         if (xyz) HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
-        if (rgb) HIPCHK(x, hipMemcpyAsync(rgb, x->d_cloud_rgb, (size_t)n * 3, hipMemcpyDeviceToHost, x->stream));
+        if (rgb) HIPCHK_DRAIN(x, hipMemcpyAsync(rgb, x->d_cloud_rgb, (size_t)n * 3, hipMemcpyDeviceToHost, x->stream));
         HIPCHK(x, hipStreamSynchronize(x->stream));
     }
     return SL3D_OK;

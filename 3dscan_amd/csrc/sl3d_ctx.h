@@ -84,6 +84,17 @@ __attribute__((visibility("hidden"))) int sl3d_process_views_wait(sl3d_ctx *x);
             return fail((c), SL3D_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
+// the same for asynchronous copies that touch CALLER memory in a loop: an error return first drains the stream, so that no copy
+// enqueued earlier in the call is still running against buffers the caller is about to free
+#define HIPCHK_DRAIN(c, call)                                                                       \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (void)hipStreamSynchronize((c)->stream);                                                \
+            return fail((c), SL3D_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+        }                                                                                           \
+    } while (0)
+
 // Every entry point runs on the context's device and hands the caller's current device back on return: the caller may be a
 // process that holds contexts on several GPUs, or a torch process whose current device differs.
 struct DeviceGuard {

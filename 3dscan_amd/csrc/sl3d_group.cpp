@@ -461,20 +461,32 @@ extern "C" int sl3d_group_download_points(sl3d_group *g, int first, int n, float
     int rc = check_views(g, first, n);
     if (rc) return rc;
     const size_t W = (size_t)g->cfg.width, H = (size_t)g->cfg.height;
-    for (size_t s = 0; s < g->st.size(); s++) {
+    hipError_t e = hipSuccess;
+    for (size_t s = 0; s < g->st.size() && e == hipSuccess; s++) {
         Stripe &S = g->st[s];
         const KParams &P = S.ctx->P;
         DeviceGuard dg(S.device);
-        for (int v = 0; v < n; v++) {
+        for (int v = 0; v < n && e == hipSuccess; v++) {
             if (xyz)
-                GHIP(g, hipMemcpy2DAsync(xyz + ((size_t)v * H + (size_t)S.row0) * W * 3, W * 12, P.points + 3 * (size_t)(first + v) * P.px_view_stride,
-                                         (size_t)P.pitch * 12, W * 12, (size_t)S.rows, hipMemcpyDeviceToHost, S.ctx->stream));
-            if (valid)
-                GHIP(g, hipMemcpy2DAsync(valid + ((size_t)v * H + (size_t)S.row0) * W, W, P.valid + (size_t)(first + v) * P.px_view_stride, (size_t)P.pitch, W,
-                                         (size_t)S.rows, hipMemcpyDeviceToHost, S.ctx->stream));
+                e = hipMemcpy2DAsync(xyz + ((size_t)v * H + (size_t)S.row0) * W * 3, W * 12, P.points + 3 * (size_t)(first + v) * P.px_view_stride,
+                                     (size_t)P.pitch * 12, W * 12, (size_t)S.rows, hipMemcpyDeviceToHost, S.ctx->stream);
+            if (valid && e == hipSuccess)
+                e = hipMemcpy2DAsync(valid + ((size_t)v * H + (size_t)S.row0) * W, W, P.valid + (size_t)(first + v) * P.px_view_stride, (size_t)P.pitch, W,
+                                     (size_t)S.rows, hipMemcpyDeviceToHost, S.ctx->stream);
         }
     }
-    for (size_t s = 0; s < g->st.size(); s++) GCTX(g, s, sl3d_synchronize(g->st[s].ctx));
+    // success or not, no copy may still be running against the caller's images when this returns
+    int sync_rc = SL3D_OK;
+    size_t sync_s = 0;
+    for (size_t s = 0; s < g->st.size(); s++) {
+        const int r = sl3d_synchronize(g->st[s].ctx);
+        if (r != SL3D_OK && sync_rc == SL3D_OK) {
+            sync_rc = r;
+            sync_s = s;
+        }
+    }
+    if (e != hipSuccess) return gfail(g, SL3D_E_HIP, std::string("group_download_points: hipMemcpy2DAsync: ") + hipGetErrorString(e));
+    if (sync_rc != SL3D_OK) return gfail(g, sync_rc, "stripe " + std::to_string(sync_s) + ": " + sl3d_last_error(g->st[sync_s].ctx));
     return SL3D_OK;
 }
 
