@@ -61,6 +61,7 @@ struct KParams {
     int F, Nv, Nh;
     int fwv, fwh;
     int ncodes_v, ncodes_h;
+    int stagger;               // measurement builds only (env SL3D_STAGGER): artificial start delay of the first round of blocks, see k_fused
     int ablate;                // measurement builds only (-DSL3D_MEASURE, env SL3D_ABLATE): bit2 skips the camera undistortion; 0 otherwise
     int pitch;                 // bytes per row of every u8 plane (multiple of 16)
     int planes_per_view;

@@ -956,6 +956,17 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     constexpr bool RCP_TAB = RCPT && SL3D_RCP_LDS != 0 && !(COMPACT && SL3D_SLACK >= 3);
     __shared__ __attribute__((aligned(16))) double s_rcp[RCP_TAB ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
     SL3D_STAMP(0);
+#ifdef SL3D_MEASURE
+    // experiment (tools/ab.sh, env SL3D_STAGGER = mode * 256 + units): the blocks of the FIRST round (the ones that find the machine
+    // empty) start `slot * units` sleeps of ~0.45 us late, slot = the block's generation on its CU taken from the dispatch order
+    // (mode 0: blockIdx.x / n_cus) or the wave's slot on its SIMD (mode 1: HW_ID.wave_id) -- so that the first slots' planes land
+    // early and their arithmetic runs under the later slots' loads instead of every wave of the round loading at once
+    if (P.stagger != 0 && CMODE == 0 && blockIdx.y == 0 && blockIdx.x < (unsigned)(P.n_cus > 0 ? P.n_cus : 256) * 4u) {
+        const unsigned units = (unsigned)P.stagger & 255u, mode = (unsigned)P.stagger >> 8;
+        const unsigned slot = mode == 0 ? blockIdx.x / (unsigned)(P.n_cus > 0 ? P.n_cus : 256) : (__builtin_amdgcn_s_getreg(6148) & 3u);  // HW_REG_HW_ID[3:0]
+        for (unsigned i = 0; i < slot * units; i++) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     if (RCP_TAB) {
         fill_rcp_table(s_rcp);
         __syncthreads();
@@ -1788,6 +1799,7 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     P.use_cam_table = P.cam_tab != nullptr ? P.cam_tab_kind : 0;
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 0) P.use_cam_table = 0;
+    P.stagger = getenv("SL3D_STAGGER") ? atoi(getenv("SL3D_STAGGER")) : 0;
 #endif
     if (compact == 1) {
         // persistent blocks that draw (tile, view group) items from the context's ticket counter: as many as the GPU holds at

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -301,9 +302,74 @@ __global__ __launch_bounds__(256, OCC) void k_viewmajor_pipe(const uint8_t *in, 
     }
 }
 
+// one-view launches (round 3): the data path of ONE 1080p view per launch, back to back (the working set stays in the Infinity
+// Cache), at 8 waves/SIMD (every wave of the launch resident at once: one round) against 4 (LDS-limited: two rounds, like the
+// fused kernel at 128 VGPRs), and with the planes requested in two dependent halves (what a 64-VGPR kernel would have to do)
+template <int P, bool SPLIT>
+__global__ __launch_bounds__(256, 8) void k_one(const uint8_t *in, size_t plane, float4 *out, unsigned *outv, size_t nquads, int lds_words)
+{
+    extern __shared__ unsigned pad[];
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    unsigned a = 0, b = 0, c = 0;
+    if (lds_words) pad[threadIdx.x] = (unsigned)q;  // keeps the allocation alive
+    if (SPLIT) {
+        constexpr int H1 = P / 2;
+        unsigned v[H1];
+#pragma unroll
+        for (int p = 0; p < H1; p++) v[p] = *(const unsigned *)(in + p * plane + q * 4);
+#pragma unroll
+        for (int p = 0; p < H1; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+        unsigned w[P - H1];
+        const uint8_t *in2 = in + (a == 0x12345u ? 4 : 0);  // the second half's addresses depend on the first half's data
+#pragma unroll
+        for (int p = H1; p < P; p++) w[p - H1] = *(const unsigned *)(in2 + p * plane + q * 4);
+#pragma unroll
+        for (int p = H1; p < P; p++) { a ^= w[p - H1]; b += w[p - H1]; c |= w[p - H1] >> (p & 7); }
+    } else {
+        unsigned v[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) v[p] = *(const unsigned *)(in + p * plane + q * 4);
+#pragma unroll
+        for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+    }
+    if (lds_words) a ^= pad[threadIdx.x ^ 1] & 1u;
+    float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+          fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+    out[q * 3 + 0] = make_float4(fa, fb, fc, fa);
+    out[q * 3 + 1] = make_float4(fb, fc, fa, fb);
+    out[q * 3 + 2] = make_float4(fc, fa, fb, fc);
+    outv[q] = a;
+}
+
 int main(int argc, char **argv)
 {
     constexpr int P = 47;
+    if (argc > 1 && !strcmp(argv[1], "oneview")) {
+        const size_t vpx = 1920 * 1080, nq = vpx / 4;
+        uint8_t *fr; float4 *o; unsigned *ov;
+        CHK(hipMalloc(&fr, vpx * P + 64)); CHK(hipMalloc(&o, vpx * 12)); CHK(hipMalloc(&ov, vpx));
+        CHK(hipMemset(fr, 0x5a, vpx * P + 64));
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; rep++)
+            for (int split = 0; split < 2; split++)
+                for (int lds_kb : {0, 20, 40, 52}) {  // 160 KB per CU: 0 -> 8 blocks (VGPR-limited), 20 -> 8, 40 -> 4, 52 -> 3 blocks of 4 waves
+                    const int launches = 300;
+                    for (int pass = 0; pass < 2; pass++) {
+                        CHK(hipEventRecord(e0));
+                        for (int i = 0; i < launches; i++) {
+                            if (split) hipLaunchKernelGGL((k_one<P, true>), dim3((nq + 255) / 256), dim3(256), lds_kb * 1024, 0, fr, vpx, o, ov, nq, lds_kb);
+                            else hipLaunchKernelGGL((k_one<P, false>), dim3((nq + 255) / 256), dim3(256), lds_kb * 1024, 0, fr, vpx, o, ov, nq, lds_kb);
+                        }
+                        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                        if (pass) printf("one view per launch, %s, %2d KB LDS per block: %6.2f us per launch\n", split ? "planes in two dependent halves" : "all planes at once", lds_kb, ms * 1e3 / launches);
+                    }
+                    CHK(hipGetLastError());
+                }
+        return 0;
+    }
     size_t npx = (size_t)(argc > 1 ? atof(argv[1]) : 33.1776) * 1000000;
     npx = (npx + 4095) / 4096 * 4096;
     uint8_t *in; float4 *out; unsigned *outv;
