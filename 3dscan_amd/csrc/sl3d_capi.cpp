@@ -364,12 +364,18 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     if (!x->keep && x->C.cam.has_dist) {  // timed mode: T1 of the camera per window pixel (k_cam_table)
         const int kind = x->C.cam.has_tan ? 2 : 1;
         if (!x->d_cam_tab || x->cam_tab_doubles < (size_t)kind * x->P.px_view_stride) {
-            int rc = dev_alloc(x, &x->d_cam_tab, (size_t)kind * x->P.px_view_stride);
-            if (rc) return rc;
+            if (x->d_cam_tab) {  // a radial-only table that has to grow into a two-double one (no launch reads it: synchronised above)
+                (void)hipFree(x->d_cam_tab);
+                x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_cam_tab), x->allocs.end());
+                x->d_cam_tab = nullptr;
+                x->cam_tab_doubles = 0;
+            }
+            const int st = dev_alloc(x, &x->d_cam_tab, (size_t)kind * x->P.px_view_stride);
+            if (st) return st;
             x->cam_tab_doubles = (size_t)kind * x->P.px_view_stride;
         }
-        const int rc = launch_cam_table(x->P, x->d_cal, kind, x->d_cam_tab, x->stream);
-        if (rc) return fail(x, SL3D_E_HIP, std::string("k_cam_table: ") + hipGetErrorString((hipError_t)rc));
+        const int st = launch_cam_table(x->P, x->d_cal, kind, x->d_cam_tab, x->stream);
+        if (st) return fail(x, SL3D_E_HIP, std::string("k_cam_table: ") + hipGetErrorString((hipError_t)st));
         x->P.cam_tab = x->d_cam_tab;
         x->P.cam_tab_kind = kind;
     }
@@ -378,8 +384,8 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
             HIPCHK(x, hipMalloc((void **)&x->d_proj_disp, (size_t)x->cfg.proj_width * x->cfg.proj_height * sizeof(float2)));
             x->allocs.push_back(x->d_proj_disp);
         }
-        const int rc = launch_proj_table(x->d_cal, x->cfg.proj_width, x->cfg.proj_height, x->d_proj_disp, x->stream);
-        if (rc) return fail(x, SL3D_E_HIP, std::string("k_proj_table: ") + hipGetErrorString((hipError_t)rc));
+        const int st = launch_proj_table(x->d_cal, x->cfg.proj_width, x->cfg.proj_height, x->d_proj_disp, x->stream);
+        if (st) return fail(x, SL3D_E_HIP, std::string("k_proj_table: ") + hipGetErrorString((hipError_t)st));
         HIPCHK(x, hipStreamSynchronize(x->stream));
         x->P.proj_disp = x->d_proj_disp;
     }

@@ -230,7 +230,8 @@ def test_distorted_projector_table_path_and_recalibration():
         sc.set_mask(cap["mask"])
         sc.set_frames(0, cap["planes_v"])
         sc.set_frames(1, cap["planes_h"])
-        for cal in (cal_a, cal_b, cal_c, cal_a):
+        # (cal_b first: its radial-only camera table, one double per pixel, has to grow into cal_a's two-double one)
+        for cal in (cal_b, cal_a, cal_b, cal_c, cal_a):
             o = _oracle_for(dict(cap, cal=cal), W, H, PW, PH, N, N, fw, fw, cap["mask"])
             sc.set_calibration(*syn.cal_tuple(cal))
             sc.run()
