@@ -259,8 +259,27 @@ def side_figures(args, scm, syn, np, dev_index):
     return out
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """fd 1 carries the JSON line and nothing else: from here on whatever a library writes to stdout (Gloo's connection notes, an
+    RCCL banner, a stray print) lands on stderr; emit() writes the line to the descriptor stdout was."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
+
+
 def main():
     args = parse()
+    claim_stdout()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
         os.environ["NCCL_DEBUG"] = "WARN"   # no RCCL version banner on stdout next to the JSON line
@@ -271,7 +290,7 @@ def main():
         lines = [l for l in out.splitlines() if l.startswith("{")]
         if not lines:
             raise SystemExit("rank 0 printed no JSON line:\n" + out)
-        print(lines[-1], flush=True)
+        emit(lines[-1])
         return
     rank, local_rank, world = dmod.env_ranks()
     if world != args.gpus:
@@ -466,7 +485,7 @@ def main():
             if rank == 0:
                 out["with_assembly"] = {"error": f"assembly legs did not finish within {args.assembly_timeout} s"}
                 out["ranks"] = rank_report
-                print(json.dumps(out), flush=True)
+                emit(json.dumps(out))
             os._exit(3)   # non-zero on every rank: the launcher (spawn_ranks / torchrun / CI) must see that the run did not complete
 
         watchdog = threading.Timer(args.assembly_timeout, give_up)
@@ -545,7 +564,7 @@ def main():
     if world > 1:
         out["ranks"] = rank_report
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
