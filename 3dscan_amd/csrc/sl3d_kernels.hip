@@ -53,8 +53,14 @@
 // dense xyz stores: 0 = three 16-byte stores per lane at a 48-byte lane stride (the L2 merges the partial lines), 1 = read back
 // across the wave's lanes from LDS so that every store instruction writes 1 KiB of whole lines for EVERY launch (round 1: -1.2 %,
 // round 3: -2.4 % at 16 views; the one-view launch takes the coalesced form whatever this switch says, see store_quad)
+#ifndef SL3D_NT_COALESCED
+#define SL3D_NT_COALESCED 1 /* the coalesced store path (whole 1-KiB runs per instruction) carries the non-temporal hint, see store_quad */
+#endif
+#ifndef SL3D_NT_SEG
+#define SL3D_NT_SEG 1 /* the same hint on the segment stores (and the valid dword) of the segmented clouds */
+#endif
 #ifndef SL3D_COALESCED_STORES
-#define SL3D_COALESCED_STORES 0
+#define SL3D_COALESCED_STORES 1
 #endif
 #ifndef SL3D_EARLY_PLANES
 #define SL3D_EARLY_PLANES 1 /* small-launch instantiation: the first view's planes requested before the mask is known (see EARLY in k_fused) */
@@ -1320,10 +1326,10 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             vb >>= 16;
         }
     };
-    // the 48 B of xyz a lane produces are staged in LDS (the rolled pixel loop indexes them) and leave as three 16-B
-    // stores per lane; each lane reads back only what it wrote itself: no barrier needed
-    // (Measured and rejected: reading the staging area back across lanes so that every store instruction of a wave
-    // writes 1 KiB of whole lines instead of 64 x 16 B at a 48-B stride: -1.2 %; the L2 merges the three partial stores.)
+    // the 48 B of xyz a lane produces are staged in LDS (the rolled pixel loop indexes them).  A full wave reads its 3 KB of the
+    // staging area back ACROSS lanes (a wave's LDS instructions execute in order: no barrier) and stores whole 1-KiB runs with the
+    // non-temporal hint; a wave that is not whole (the last rows of a window), and the parity mode, store three 16-B pieces per lane,
+    // each lane what it wrote itself.
     auto store_quad = [&](size_t px, unsigned vout) {
         float4 *out_xyz = (float4 *)(P.points + 3 * px);
         const float4 *sx = (const float4 *)my_xyz;
@@ -1338,11 +1344,25 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
             } else if ((SL3D_COALESCED_STORES || (!RCPT && n_views == 1)) && !KEEP && __ballot(true) == ~0ull) {
                 // a full wave's 64 x 48 B of results are 3 KB contiguous in LDS AND in the dense plane (quads are consecutive in the
                 // pitch-padded layout): every store instruction writes 1 KiB of whole lines, lane after lane, as the segmented kernel
-                // does.  Round 3, alternating: 16 views per launch -2.4 % (five of five), 4 views -1.5 %, ONE view 29.0 against
-                // 29.6 us (profiles/r03_coalesced_stores_ab.txt) -- so only the one-view launch of the small-launch instantiation takes it.
+                // does -- and because they are whole lines they can carry the non-temporal hint: nothing is left for the L2 to merge,
+                // the lines stream out instead of sitting dirty in the L2 until they are evicted or the kernel ends.
+                // Round 3, alternating (profiles/r03_nt_coalesced_ab.txt): 16 views per launch +6...8 % (0.634 -> 0.683 on a slow box,
+                // 0.66-0.67 -> 0.70-0.72 on a fast one), one view 29.2 -> 27.3 us, other rigs +7 %; each half alone LOSES
+                // (coalesced without the hint -2.4 %, profiles/r03_coalesced_stores_ab.txt; the hint on the 16-byte pieces below
+                // -11 %, round 1: every piece becomes a memory write of its own).
                 const unsigned lane_ = threadIdx.x & 63u;
                 const float4 *wb4 = (const float4 *)(s_xyz + (threadIdx.x >> 6) * (64u * 12u));
                 float4 *o4 = (float4 *)(P.points + 3 * (px - 4u * lane_));
+                if (SL3D_NT_COALESCED) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 *w4 = (const f32x4 *)wb4;
+                    f32x4 *q4 = (f32x4 *)o4;
+                    __builtin_nontemporal_store(w4[lane_], q4 + lane_);
+                    __builtin_nontemporal_store(w4[64u + lane_], q4 + 64u + lane_);
+                    __builtin_nontemporal_store(w4[128u + lane_], q4 + 128u + lane_);
+                    __builtin_nontemporal_store(vout, (unsigned *)(P.valid + px));
+                    return;
+                }
                 o4[lane_] = wb4[lane_];
                 o4[64u + lane_] = wb4[64u + lane_];
                 o4[128u + lane_] = wb4[128u + lane_];
@@ -1362,7 +1382,10 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
     // SEG: the wave's valid points of this view, compacted in scan order into the wave's own segment of the cloud buffer, and
     // their count.  Needs nothing from any other wave; lanes past the last row take part with no valid pixel.
     auto store_segment = [&](int view, size_t px, unsigned vout) {
-        if (alive) *(unsigned *)(P.valid + px) = vout;
+        if (alive) {
+            if (SL3D_NT_SEG) __builtin_nontemporal_store(vout, (unsigned *)(P.valid + px));
+            else *(unsigned *)(P.valid + px) = vout;
+        }
         const unsigned long long b0 = __ballot((vout & 0x00000001u) != 0u), b1 = __ballot((vout & 0x00000100u) != 0u),
                                  b2 = __ballot((vout & 0x00010000u) != 0u), b3 = __ballot((vout & 0x01000000u) != 0u);
         auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
@@ -1395,7 +1418,14 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
 #pragma unroll
             for (int c3 = 0; c3 < 3; c3++) {
                 const unsigned i = (unsigned)c3 * 64u + lane_;
-                if (i < chunks) out4[i] = wb4[i];
+                if (i < chunks) {
+                    if (SL3D_NT_SEG) {
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(((const f32x4 *)wb4)[i], (f32x4 *)out4 + i);
+                    } else {
+                        out4[i] = wb4[i];
+                    }
+                }
             }
         } else {
             typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
