@@ -1798,12 +1798,19 @@ static void launch_fused_rig(int rig, dim3 grid, dim3 block, hipStream_t st, con
     else launch_fused_n<false, FGEN, 0, COMPACT>(P.Nv, P.Nh, grid, block, st, P, C, first_view, n_views, vpt);
 }
 
-// views per lane: as many as possible (amortises the camera undistortion) while the grid still has >= ~8 blocks per CU
-// to balance the tail
-static int views_per_lane(unsigned bx, int n_views)
+// views per lane: as many as possible up to SL3D_VPT_MAX (amortises the set-up of a block and the camera table entries) while
+// the grid still has >= ~8 blocks per CU to balance the tail.  (Rounds 1-2: 8.  With the stores streaming past the L2 the
+// optimum moved: 16 views per launch 354.5 us at 4 against 359.6 at 8 and 359.3 at 2, 372.7 at 16; 32 views 700 against 708,
+// profiles/r03_vpt_sweep4.txt; on another box, production builds alternating: 360.7-361.7 against 362.6-363.1.)
+#ifndef SL3D_VPT_MAX
+#define SL3D_VPT_MAX 4
+#endif
+static int views_per_lane(unsigned bx, int n_views, int cam_table_kind)
 {
     int vpt = 1;
-    while (vpt < 8 && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
+    // (a two-double camera table -- tangential terms -- costs a block 16 B/px: those rigs keep 8 views per lane, measured -0.6 % at 4)
+    const int cap = cam_table_kind == 2 ? 8 : SL3D_VPT_MAX;
+    while (vpt < cap && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_VPT") && atoi(getenv("SL3D_VPT")) >= 1) vpt = atoi(getenv("SL3D_VPT"));
 #endif
@@ -1821,7 +1828,7 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     unsigned drawn = 0;
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: see the tile order in k_fused
-    const int vpt = views_per_lane(bx, n_views);
+    const int vpt = views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0);
     dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1), block(SL3D_BLOCK, 1, 1);
     // the timed kernels read the camera-side T1 from the per-calibration table whatever the batch is: with 8 views per lane it
     // costs nothing (1 B/px/view), with 1..4 it saves the iteration (+2..13 %), and a view's result does not depend on the
@@ -2357,27 +2364,51 @@ int launch_compact_views(const KParams &P, int first_view, int n_views, unsigned
 // Consumers of the SEGMENTED clouds the fused kernel writes (k_fused<..., CMODE = 2>): a view's cloud is the concatenation of
 // its segments' first `count` points.  One wave per segment, one point (12 bytes) per lane and step.
 // ------------------------------------------------------------------------------------------------
-// Exclusive scan of one view's segment counts (a 1024-thread block per view), behind every segmented launch: it is on the critical
-// path of sl3d_run_clouds, so it is written for latency.  The counts are taken through LDS in chunks of 32 x 1024: coalesced loads
-// into a padded LDS array (33-word rows: the per-thread runs below are conflict-free), every thread scans its 32 consecutive
-// entries, the 1024 run totals are scanned by wave shuffles + 16 wave totals, and the offsets leave coalesced again; a running
-// carry links the chunks (any frame size).  The view's total goes straight into the mapped host word sl3d_get_cloud_counts reads.
-// (k_compact_scan -- 32 strided dwords per thread straight from global memory -- took 14.3 us for 16 x 32,400 counts.)
-#define SL3D_SCAN_RUN 32
+// Exclusive scan of one view's segment counts (1024-thread blocks), behind every segmented launch: it is on the critical path of
+// sl3d_run_clouds, so it is written for latency.  The counts are taken through LDS in chunks of SL3D_SCAN_RUN x 1024: coalesced
+// loads into a padded LDS array (rows of RUN + 1 words: the per-thread runs below are conflict-free), every thread scans its RUN
+// consecutive entries, the 1024 run totals are scanned by wave shuffles + 16 wave totals, and the offsets leave coalesced again;
+// a running carry links the chunks (any frame size).  The view's total goes straight into the mapped host word
+// sl3d_get_cloud_counts reads.  (k_compact_scan -- 32 strided dwords per thread straight from global memory -- took 14.3 us for
+// 16 x 32,400 counts; this scan with ONE block per view and runs of 32: 10.2 us.)
+// Since the end of round 3 a view's segments are scanned by SL3D_SCAN_PARTS blocks instead of one (16 blocks on a 256-CU machine were
+// a latency chain of ~10 us behind every sl3d_run_clouds): block (view, part) first SUMS the counts of the parts in front of it --
+// the same coalesced reads every one of them does anyway, at most n dwords from the L2 -- and then scans its own part from that
+// carry; no block waits for another.  The last part's block leaves the view's total.
+#define SL3D_SCAN_RUN 4
+#define SL3D_SCAN_PARTS 8
 __global__ __launch_bounds__(1024) void k_seg_scan(const unsigned *__restrict__ counts, unsigned long long *__restrict__ offsets, int n,
                                                    unsigned long long *total)
 {
-    counts += (size_t)blockIdx.x * n;
-    offsets += (size_t)blockIdx.x * n;
+    const int view = (int)blockIdx.y, part = (int)blockIdx.x;
+    counts += (size_t)view * n;
+    offsets += (size_t)view * n;
+    constexpr int CHUNK = 1024 * SL3D_SCAN_RUN;
+    // parts are whole chunks, so that every chunk of a part is scanned by the same code path
+    const int part_len = (((n + SL3D_SCAN_PARTS - 1) / SL3D_SCAN_PARTS + CHUNK - 1) / CHUNK) * CHUNK;
+    const int begin = min(part * part_len, n), end = min(begin + part_len, n);
     __shared__ unsigned s_val[1024 * (SL3D_SCAN_RUN + 1)];
     __shared__ unsigned s_wave[16];
     __shared__ unsigned long long s_carry;
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_carry = 0ull;
-    for (int base = 0; base < n; base += 1024 * SL3D_SCAN_RUN) {
-        const int m = min(n - base, 1024 * SL3D_SCAN_RUN);
+    {   // the carry into this part: the sum of everything in front of it
+        unsigned long long acc = 0ull;
+        for (int i = t; i < begin; i += 1024) acc += counts[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        __shared__ unsigned long long s_part[16];
+        if (lane == 0) s_part[wave] = acc;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long c = 0ull;
+            for (int w = 0; w < 16; w++) c += s_part[w];
+            s_carry = c;
+        }
+    }
+    for (int base = begin; base < end; base += CHUNK) {
+        const int m = min(end - base, CHUNK);
         __syncthreads();  // the previous chunk's LDS values have been written out; s_carry is up to date
-        for (int i = t; i < 1024 * SL3D_SCAN_RUN; i += 1024) s_val[i + i / SL3D_SCAN_RUN] = i < m ? counts[base + i] : 0u;
+        for (int i = t; i < CHUNK; i += 1024) s_val[i + i / SL3D_SCAN_RUN] = i < m ? counts[base + i] : 0u;
         __syncthreads();
         unsigned *mine = s_val + t * (SL3D_SCAN_RUN + 1);
         unsigned run = 0;
@@ -2407,14 +2438,15 @@ __global__ __launch_bounds__(1024) void k_seg_scan(const unsigned *__restrict__ 
         if (t == 1023) s_carry = carry + (unsigned long long)(wbase + incl);
     }
     __syncthreads();
-    if (t == 0) total[blockIdx.x] = s_carry;
+    if (t == 0 && part == SL3D_SCAN_PARTS - 1) total[view] = s_carry;
 }
 
 int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream)
 {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_seg_scan, dim3(n_views), dim3(1024), 0, (hipStream_t)stream, P.seg_counts + (size_t)first_view * P.n_segs,
-                       P.seg_offsets + (size_t)first_view * P.n_segs, P.n_segs, P.cloud_totals + first_view);
+    hipLaunchKernelGGL(k_seg_scan, dim3(SL3D_SCAN_PARTS, (unsigned)n_views), dim3(1024), 0, (hipStream_t)stream,
+                       P.seg_counts + (size_t)first_view * P.n_segs, P.seg_offsets + (size_t)first_view * P.n_segs, P.n_segs,
+                       P.cloud_totals + first_view);
     return (int)hipGetLastError();
 }
 
