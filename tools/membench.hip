@@ -305,7 +305,9 @@ __global__ __launch_bounds__(256, OCC) void k_viewmajor_pipe(const uint8_t *in, 
 // one-view launches (round 3): the data path of ONE 1080p view per launch, back to back (the working set stays in the Infinity
 // Cache), at 8 waves/SIMD (every wave of the launch resident at once: one round) against 4 (LDS-limited: two rounds, like the
 // fused kernel at 128 VGPRs), and with the planes requested in two dependent halves (what a 64-VGPR kernel would have to do)
-template <int P, bool SPLIT>
+// store form of k_one: 0 = three 16-B pieces per lane (48-B stride), 1 = the same with the non-temporal hint, 2 = 1-KiB runs of
+// whole lines per instruction (lane after lane), 3 = the same with the hint (what the fused kernel ships since the end of round 3)
+template <int P, bool SPLIT, int ST = 0>
 __global__ __launch_bounds__(256, 8) void k_one(const uint8_t *in, size_t plane, float4 *out, unsigned *outv, size_t nquads, int lds_words)
 {
     extern __shared__ unsigned pad[];
@@ -337,15 +339,68 @@ __global__ __launch_bounds__(256, 8) void k_one(const uint8_t *in, size_t plane,
     if (lds_words) a ^= pad[threadIdx.x ^ 1] & 1u;
     float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
           fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
-    out[q * 3 + 0] = make_float4(fa, fb, fc, fa);
-    out[q * 3 + 1] = make_float4(fb, fc, fa, fb);
-    out[q * 3 + 2] = make_float4(fc, fa, fb, fc);
-    outv[q] = a;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v0 = {fa, fb, fc, fa}, v1 = {fb, fc, fa, fb}, v2 = {fc, fa, fb, fc};
+    f32x4 *o = (f32x4 *)out;
+    if (ST >= 2) {
+        const size_t w0 = (q & ~(size_t)63) * 3, l = q & 63;   // (the data would come across lanes from LDS: free in the fused kernel)
+        if (ST == 3) {
+            __builtin_nontemporal_store(v0, o + w0 + l);
+            __builtin_nontemporal_store(v1, o + w0 + 64 + l);
+            __builtin_nontemporal_store(v2, o + w0 + 128 + l);
+            __builtin_nontemporal_store(a, outv + q);
+        } else {
+            o[w0 + l] = v0; o[w0 + 64 + l] = v1; o[w0 + 128 + l] = v2;
+            outv[q] = a;
+        }
+    } else if (ST == 1) {
+        __builtin_nontemporal_store(v0, o + q * 3);
+        __builtin_nontemporal_store(v1, o + q * 3 + 1);
+        __builtin_nontemporal_store(v2, o + q * 3 + 2);
+        __builtin_nontemporal_store(a, outv + q);
+    } else {
+        o[q * 3 + 0] = v0; o[q * 3 + 1] = v1; o[q * 3 + 2] = v2;
+        outv[q] = a;
+    }
+}
+
+template <int ST>
+static void run_store_form(const uint8_t *fr, size_t vpx, int nviews, float4 *o, unsigned *ov, hipEvent_t e0, hipEvent_t e1, const char *name)
+{
+    constexpr int P = 47;
+    const size_t nq = vpx * nviews / 4;   // the views as ONE run of pixels: plane stride = all of them
+    const int launches = nviews == 1 ? 300 : 40;
+    float best = 1e9;
+    for (int pass = 0; pass < 3; pass++) {
+        CHK(hipEventRecord(e0));
+        for (int i = 0; i < launches; i++) hipLaunchKernelGGL((k_one<P, false, ST>), dim3((nq + 255) / 256), dim3(256), 0, 0, fr, vpx * nviews, o, ov, nq, 0);
+        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass && ms < best) best = ms;
+    }
+    CHK(hipGetLastError());
+    const double us = best * 1e3 / launches, bytes = (double)vpx * nviews * (P + 13);
+    printf("store form %-44s %2d view(s) per launch: %8.2f us  %6.0f GB/s  %5.1f Gpx/s\n", name, nviews, us, bytes / us / 1e3, vpx * nviews / us / 1e3);
 }
 
 int main(int argc, char **argv)
 {
     constexpr int P = 47;
+    if (argc > 1 && !strcmp(argv[1], "stores")) {  // the data path alone with each store form, 1 and 16 views of 1080p per launch
+        const size_t vpx = 1920 * 1080;
+        uint8_t *fr; float4 *o; unsigned *ov;
+        CHK(hipMalloc(&fr, vpx * 47 * 16 + 64)); CHK(hipMalloc(&o, vpx * 12 * 16)); CHK(hipMalloc(&ov, vpx * 16));
+        CHK(hipMemset(fr, 0x5a, vpx * 47 * 16 + 64));
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; rep++)
+            for (int nviews : {1, 16}) {
+                run_store_form<0>(fr, vpx, nviews, o, ov, e0, e1, "16-B pieces");
+                run_store_form<1>(fr, vpx, nviews, o, ov, e0, e1, "16-B pieces, non-temporal");
+                run_store_form<2>(fr, vpx, nviews, o, ov, e0, e1, "whole 1-KiB runs");
+                run_store_form<3>(fr, vpx, nviews, o, ov, e0, e1, "whole 1-KiB runs, non-temporal");
+            }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "oneview")) {
         const size_t vpx = 1920 * 1080, nq = vpx / 4;
         uint8_t *fr; float4 *o; unsigned *ov;
