@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/ab4
+q='import json,sys; d=json.loads(sys.stdin.read()); c=d.get("to_compacted_clouds",{}); print(d["value"], d["roofline"]["frac"], "us/step", round(d["ms_per_step"]*1e3,2), "| clouds kernel-only", (c.get("kernel_only") or {}).get("value"))'
+for rep in 1 2 3; do for lib in 3dscan_amd/libsl3d.so ab/libsl3d_pipe0.so ab/libsl3d_ntl0.so; do
+  echo "rep$rep $(basename $lib) views=16: $(SL3D_LIB=$PWD/$lib python3 bench.py --no-cpu-baseline --no-side --steps 1500 --warmup 300 2>/dev/null | python3 -c "$q")"
+done; done 2>&1 | tee gpurun_out/ab4/ab.log
