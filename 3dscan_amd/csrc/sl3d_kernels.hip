@@ -56,6 +56,9 @@
 #ifndef SL3D_NT_COALESCED
 #define SL3D_NT_COALESCED 1 /* the coalesced store path (whole 1-KiB runs per instruction) carries the non-temporal hint, see store_quad */
 #endif
+#ifndef SL3D_NT_AUX
+#define SL3D_NT_AUX 0 /* the hint on the valid-byte dword of a quad as well: measured, 361.8-362.8 us against 359.4-359.9 (profiles/r03_pipe_ntloads_ab.txt) */
+#endif
 #ifndef SL3D_NT_SEG
 #define SL3D_NT_SEG 1 /* the same hint on the segment stores (and the valid dword) of the segmented clouds */
 #endif
@@ -210,7 +213,8 @@ struct MaskQuad {
 __device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, int cq, int row)
 {
     MaskQuad m;
-    m.band = *(const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + cq * 4);
+    const unsigned *bp = (const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + cq * 4);
+    m.band = SL3D_NT_AUX ? __builtin_nontemporal_load(bp) : *bp;  // read once per view, by one lane
     return m;
 }
 
