@@ -1766,7 +1766,10 @@ int fused_tiles(const KParams &P)
 // Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT: plane tests fold away)
 // and for the unroll bounds 8 / 12 / 16 otherwise; the parity mode and the 4-/5-step fringes use the bounds only.
 // launches of at most this many views take the instantiation without the LDS reciprocal table (dense 3-step timed kernels)
+// (re-measured with the streaming stores: 8 views 185.6-187.5 us through it against 183.8-184.7, 16 views +-0: stays at 4)
+#ifndef SL3D_SMALL_LAUNCH_VIEWS
 #define SL3D_SMALL_LAUNCH_VIEWS 4
+#endif
 template <bool KEEP, bool FGEN, int RIG, int COMPACT>
 static void launch_fused_n(int nv, int nh, dim3 grid, dim3 block, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
