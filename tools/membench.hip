@@ -383,9 +383,97 @@ static void run_store_form(const uint8_t *fr, size_t vpx, int nviews, float4 *o,
     printf("store form %-44s %2d view(s) per launch: %8.2f us  %6.0f GB/s  %5.1f Gpx/s\n", name, nviews, us, bytes / us / 1e3, vpx * nviews / us / 1e3);
 }
 
+// scope / cache-policy bits of gfx950 global loads and stores on the fused kernel's data path (one dword per lane and plane in,
+// whole 1-KiB runs out): LD 0 plain, 1 nt (the builtin), 2 "sc1", 3 "sc0 sc1", 4 "sc0 sc1 nt"; ST 0 nt (the builtin), 1 "sc1",
+// 2 "sc0 sc1", 3 "sc0 sc1 nt", 4 plain.  The asm forms wait with an explicit s_waitcnt.
+#define MB_LOAD_ASM(BITS)  asm volatile("global_load_dword %0, %1, off " BITS : "=v"(v[p]) : "v"(a) : "memory")
+#define MB_STORE_ASM(BITS, ptr, val) asm volatile("global_store_dwordx4 %0, %1, off " BITS :: "v"(ptr), "v"(val) : "memory")
+template <int P, int LD, int ST>
+__global__ __launch_bounds__(256, 8) void k_scope(const uint8_t *in, size_t plane, float4 *out, unsigned *outv, size_t nquads)
+{
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    unsigned v[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const unsigned *a = (const unsigned *)(in + p * plane + q * 4);
+        if (LD == 0) v[p] = *a;
+        else if (LD == 1) v[p] = __builtin_nontemporal_load(a);
+        else if (LD == 2) MB_LOAD_ASM("sc1");
+        else if (LD == 3) MB_LOAD_ASM("sc0 sc1");
+        else MB_LOAD_ASM("sc0 sc1 nt");
+    }
+    if (LD >= 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < P; p++) asm volatile("" : "+v"(v[p]));
+    }
+    unsigned a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+    float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+          fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v0 = {fa, fb, fc, fa}, v1 = {fb, fc, fa, fb}, v2 = {fc, fa, fb, fc};
+    f32x4 *o = (f32x4 *)out;
+    const size_t w0 = (q & ~(size_t)63) * 3, l = q & 63;
+    f32x4 *p0 = o + w0 + l, *p1 = o + w0 + 64 + l, *p2 = o + w0 + 128 + l;
+    if (ST == 0) {
+        __builtin_nontemporal_store(v0, p0); __builtin_nontemporal_store(v1, p1); __builtin_nontemporal_store(v2, p2);
+        __builtin_nontemporal_store(a, outv + q);
+    } else if (ST == 4) {
+        *p0 = v0; *p1 = v1; *p2 = v2; outv[q] = a;
+    } else {
+        if (ST == 1) { MB_STORE_ASM("sc1", p0, v0); MB_STORE_ASM("sc1", p1, v1); MB_STORE_ASM("sc1", p2, v2); }
+        else if (ST == 2) { MB_STORE_ASM("sc0 sc1", p0, v0); MB_STORE_ASM("sc0 sc1", p1, v1); MB_STORE_ASM("sc0 sc1", p2, v2); }
+        else { MB_STORE_ASM("sc0 sc1 nt", p0, v0); MB_STORE_ASM("sc0 sc1 nt", p1, v1); MB_STORE_ASM("sc0 sc1 nt", p2, v2); }
+        __builtin_nontemporal_store(a, outv + q);
+    }
+}
+
+template <int LD, int ST>
+static void run_scope(const uint8_t *fr, size_t vpx, int nviews, float4 *o, unsigned *ov, hipEvent_t e0, hipEvent_t e1)
+{
+    constexpr int P = 47;
+    const size_t nq = vpx * nviews / 4;
+    const int launches = 40;
+    float best = 1e9;
+    for (int pass = 0; pass < 3; pass++) {
+        CHK(hipEventRecord(e0));
+        for (int i = 0; i < launches; i++) hipLaunchKernelGGL((k_scope<P, LD, ST>), dim3((nq + 255) / 256), dim3(256), 0, 0, fr, vpx * nviews, o, ov, nq);
+        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass && ms < best) best = ms;
+    }
+    CHK(hipGetLastError());
+    static const char *ld[] = {"plain", "nt", "sc1", "sc0 sc1", "sc0 sc1 nt"}, *st[] = {"nt", "sc1", "sc0 sc1", "sc0 sc1 nt", "plain"};
+    const double us = best * 1e3 / launches, bytes = (double)vpx * nviews * (P + 13);
+    printf("loads %-11s stores %-11s %2d views per launch: %8.2f us  %6.0f GB/s  %5.1f Gpx/s\n", ld[LD], st[ST], nviews, us, bytes / us / 1e3, vpx * nviews / us / 1e3);
+}
+
 int main(int argc, char **argv)
 {
     constexpr int P = 47;
+    if (argc > 1 && !strcmp(argv[1], "scope")) {
+        const size_t vpx = 1920 * 1080;
+        uint8_t *fr; float4 *o; unsigned *ov;
+        CHK(hipMalloc(&fr, vpx * 47 * 16 + 64)); CHK(hipMalloc(&o, vpx * 12 * 16)); CHK(hipMalloc(&ov, vpx * 16));
+        CHK(hipMemset(fr, 0x5a, vpx * 47 * 16 + 64));
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; rep++) {
+            run_scope<0, 0>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<1, 0>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<2, 0>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<3, 0>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<4, 0>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<1, 4>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<1, 1>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<1, 2>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<1, 3>(fr, vpx, 16, o, ov, e0, e1);
+            run_scope<4, 3>(fr, vpx, 16, o, ov, e0, e1);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "stores")) {  // the data path alone with each store form, 1 and 16 views of 1080p per launch
         const size_t vpx = 1920 * 1080;
         uint8_t *fr; float4 *o; unsigned *ov;
