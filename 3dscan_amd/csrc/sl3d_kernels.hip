@@ -588,6 +588,18 @@ __device__ __forceinline__ unsigned opaque_u32(unsigned v)
 // dword at (wave-uniform base) + (32-bit lane offset): the saddr + voffset form of global_load_dword.
 // The base is hidden behind an empty asm: otherwise the optimiser re-associates (view base + lane offset) + plane
 // offset and spends one 64-bit VALU add per load (46 v_lshl_add_u64 per quad) instead of two SALU adds.
+// A/B (SL3D_BUF_LOADS): the same dword through a raw buffer load -- resource of the view, lane offset, SCALAR plane offset -- whose
+// cache-policy operand reaches the scope bits the global-load builtins do not (aux: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef SL3D_BUF_LOADS
+#define SL3D_BUF_LOADS 0
+#endif
+#ifndef SL3D_BUF_AUX
+#define SL3D_BUF_AUX 19
+#endif
+__device__ __forceinline__ unsigned ldb32(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned plane_off)
+{
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)plane_off, SL3D_BUF_AUX);
+}
 __device__ __forceinline__ unsigned ldg32(const GLOBAL_AS uint8_t *base, unsigned off)
 {
     asm volatile("" : "+s"(base));
@@ -1157,6 +1169,18 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
         const unsigned psv = opaque_u32(ps);  // per-view copy: plane offsets are recomputed, not kept live
         unsigned lo = lane_off;
         asm volatile("" : "+v"(lo));
+        if (SL3D_BUF_LOADS) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)(const uint8_t *)vb, 0, (int)P.view_stride, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
+                f[a][0] = ldb32(r, lo, p0);
+                f[a][1] = ldb32(r, lo, p0 + psv);
+                f[a][2] = ldb32(r, lo, p0 + 2u * psv);
+                f[a][3] = (FGEN && F == 4) ? ldb32(r, lo, p0 + 3u * psv) : 0u;
+            }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
@@ -1171,6 +1195,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
         const unsigned psv = opaque_u32(ps);
         unsigned lo = lane_off;
         asm volatile("" : "+v"(lo));
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(const uint8_t *)vb, 0, (int)P.view_stride, 0x00020000);
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const int N = a == 0 ? Nv : Nh;
@@ -1180,8 +1205,13 @@ __global__ __launch_bounds__(SL3D_BLOCK, CMODE == 1 ? SL3D_OCC_COMPACT : SL3D_OC
                 // an axis with fewer than NMAX planes: the surplus loads are not issued (wave-uniform test; decode ignores them)
                 g[a][i] = iv[a][i] = 0u;
                 if (EXACT || i < N) {
-                    g[a][i] = ldg32(vb + (size_t)(pg + (unsigned)i * psv), lo);
-                    iv[a][i] = ldg32(vb + (size_t)(pg + (unsigned)(N + i) * psv), lo);
+                    if (SL3D_BUF_LOADS) {
+                        g[a][i] = ldb32(rg, lo, pg + (unsigned)i * psv);
+                        iv[a][i] = ldb32(rg, lo, pg + (unsigned)(N + i) * psv);
+                    } else {
+                        g[a][i] = ldg32(vb + (size_t)(pg + (unsigned)i * psv), lo);
+                        iv[a][i] = ldg32(vb + (size_t)(pg + (unsigned)(N + i) * psv), lo);
+                    }
                 }
             }
         }
