@@ -75,6 +75,13 @@ def parse():
     ap.add_argument("--no-clouds", action="store_true", help="skip the frames -> compacted clouds leg (A/B builds of the dense kernel only)")
     ap.add_argument("--no-side", action="store_true", help="skip the side figures (1 view latency, other rigs, N=9)")
     ap.add_argument("--no-assemble", action="store_true", help="skip the assembly measurements (N>1)")
+    ap.add_argument("--shim-timing", action="store_true",
+                    help="also time the Level-1 drop-in path (tools/shim_bench.cpp: compiles with g++, writes BMP files, minutes of wall time); "
+                         "off by default so that the driver's line depends on the GPU only")
+    ap.add_argument("--one-view-cold-only", action="store_true",
+                    help="run only side.one_view_cold (one view per launch, a different resident view each launch: frames from HBM, not from "
+                         "the Infinity Cache) and print it -- the command tools/profile.sh puts under rocprofv3 for that figure")
+    ap.add_argument("--cold-views", type=int, default=8, help="resident views the one-view-cold figure rotates over (8 x 97.5 MB of frames > 256 MiB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--devices", default="", help="comma-separated HIP device per rank (default: LOCAL_RANK). Repeating a device "
                                                   "is refused with nccl and allowed with gloo (plumbing tests on one GPU)")
@@ -211,6 +218,43 @@ def device_copy_rate(torch, dev, nbytes=1 << 30, reps=20):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
+    """The reference's real call pattern (m_tech_project_console.cpp:366-395: ONE scan per loop iteration) measured from HBM: `cold_views`
+    views are resident (8 x 97.5 MB of frames + 8 x 27 MB of results: three times the 256 MiB Infinity Cache), every launch processes ONE
+    view and the next launch a DIFFERENT one, round robin -- by the time a view comes round again 7 x 124 MB have gone through the cache.
+    HIP events on the kernel's stream around `launches` back-to-back launches."""
+    W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
+    V = max(2, args.cold_views)
+    full_mask = syn.default_mask(W, H)
+    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index) as sc:
+        sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
+        for v in range(V):
+            sc.set_mask(full_mask, view=v)
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=args.noise)
+        sc.synchronize()
+        run = (lambda v: sc.run_clouds(v, 1)) if clouds else (lambda v: sc.run(v, 1))
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < 200.0:
+            for i in range(40):
+                run(i % V)
+            sc.synchronize()
+        sc.timer_start()
+        for i in range(launches):
+            run(i % V)
+        ms = sc.timer_stop() / launches
+        alg = 20 + 4 * N
+        # what this launch really moves: the camera-side table (8 B/px for the radial model of the reference rig, 16 with tangential
+        # terms) is read once per LAUNCH, and nothing amortises it when a launch is one view
+        tab = sc.cam_table_bytes_per_pixel() if hasattr(sc, "cam_table_bytes_per_pixel") else 8
+        moved = alg + tab
+        return {"value": round(W * H / ms / 1e3, 1), "unit": "Mpixels/s", "launch_us": round(ms * 1e3, 2),
+                "frac": round(alg * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": alg,
+                "frac_on_moved_bytes": round(moved * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "moved_bytes_per_pixel": moved,
+                "resident_views": V, "launches": launches,
+                "note": f"1 view per launch, a different one of {V} resident views each launch (frames + results {V * (alg + 0) * W * H / 2**20:.0f} MiB "
+                        f"> 256 MiB Infinity Cache): the frames come from HBM"}
+
+
 def side_figures(args, scm, syn, np, dev_index):
     """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
@@ -230,8 +274,12 @@ def side_figures(args, scm, syn, np, dev_index):
     try:
         with ctx("reference", N, 1) as sc:   # the reference's real usage: one view per scan (m_tech_project_console.cpp:372-395)
             v, f, ms = steady_rate(sc, 1, W * H, 20 + 4 * N, 2000)
-            out["one_view_latency"] = {"value": v, "unit": "Mpixels/s", "frac": f, "launch_us": round(ms * 1e3, 2),
-                                       "note": "1 view per launch, back to back; the 124 MB working set sits in the Infinity Cache"}
+            out["one_view_cache_resident"] = {"value": v, "unit": "Mpixels/s", "frac_of_hbm_peak_but_served_by_the_infinity_cache": f,
+                                              "launch_us": round(ms * 1e3, 2),
+                                              "note": "the SAME view launched back to back: its 124 MB working set sits in the 256 MiB Infinity Cache, so this is "
+                                                      "not an HBM figure (round 3 reported it as one_view_latency); one_view_cold is"}
+        out["one_view_cold"] = one_view_cold(args, scm, syn, np, dev_index)
+        out["one_view_cold_clouds"] = one_view_cold(args, scm, syn, np, dev_index, launches=1000, clouds=True)
         # the other way to ordered clouds, same workload, same box: contiguous clouds in one pass by a decoupled look-back
         # (SL3D_FLAG_CLOUDS_LOOKBACK); `to_compacted_clouds` above is the segmented default
         with ctx("reference", N, args.views, clouds_lookback=True) as sc:
@@ -250,12 +298,14 @@ def side_figures(args, scm, syn, np, dev_index):
         out["error"] = repr(e)
     # the Level-1 drop-in path: the reference's six stage calls + save_point_cloud() through the shim at the reference's own
     # 1600x1200 (tools/shim_bench.cpp: host wall time per scan, BMP files / memory, device-side [col][row] globals vs host transposes)
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import shim_timing
-        out["shim_scan_ms"] = shim_timing.run(scans=5)
-    except Exception as e:
-        out["shim_scan_ms"] = {"error": repr(e)}
+    # (behind --shim-timing since round 4: it needs a host compiler and disk I/O; the committed figure is profiles/r04_shim_scan_ms.json)
+    if args.shim_timing:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import shim_timing
+            out["shim_scan_ms"] = shim_timing.run(scans=5)
+        except Exception as e:
+            out["shim_scan_ms"] = {"error": repr(e)}
     return out
 
 
@@ -342,6 +392,10 @@ def main():
     row0, rows = dmod.shard_rows(H, world, rank)
     n_views = V * world  # batch grows with the GPU count; each GPU holds `rows` rows of every view
 
+    if args.one_view_cold_only:
+        emit(json.dumps({"one_view_cold": one_view_cold(args, scm, syn, np, dev_index, launches=max(args.steps, 200))}))
+        return
+
     # ---- synthetic inputs, generated on the device, resident in HBM before the timed region ----
     # every view is a different plane seen by the same rig, with its own noise stream (sl3d_synth_view / k_synth)
     cal = rig_calibration(syn, np, args.rig, W, H, PW, PH)
@@ -360,6 +414,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # before anything has warmed the device: 20 launches from idle clocks, no preconditioning (side.cold_20_steps -- how much of
+    # `value` hangs on the preconditioning below is then part of the driver's record)
+    cold20 = None
+    if world == 1:
+        sc.timer_start()
+        for _ in range(20):
+            sc.run(0, n_views)
+        cms = sc.timer_stop() / 20
+        cold20 = {"value": round(n_views * rows * W / cms / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(cms, 4),
+                  "frac": round((2 * 3 + 4 * N + 14) * n_views * rows * W / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "note": "the first 20 launches of the process, idle clocks, no preconditioning, HIP events"}
     # setup: bring the device out of its idle power state (reported in the JSON; not part of the W + K steps)
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
@@ -500,6 +565,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_side:
         out["side"] = side_figures(args, scm, syn, np, dev_index)
+        out["side"]["cold_20_steps"] = cold20
         try:   # the same roofline against what a device copy reaches on this very box, right now (never `frac`)
             copy = device_copy_rate(torch, dev)
             out["roofline"]["device_copy"] = {"GBps": round(copy, 1), "frac_of_it": round(achieved / copy, 4),

@@ -489,6 +489,46 @@ int main(int argc, char **argv)
             }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "oneview_cold")) {
+        // round 4: the data path of a one-view launch FROM HBM -- 8 resident views (8 x 97.5 MB of planes + 8 x 27 MB of results:
+        // three times the 256 MiB Infinity Cache), one view per launch, a different one each launch; the shipped access forms
+        // (nt dword loads, whole 1-KiB nt stores: k_scope<P, 1, 0>) and the plain ones; next to it the same view over and over
+        // (cache resident, what `oneview` measures).  P = 47 planes (46 + the valid-map byte) or 55 (+ the 8 B/px camera table).
+        const size_t vpx = 1920 * 1080, nq = vpx / 4;
+        const int NV = 8;
+        uint8_t *fr; float4 *o; unsigned *ov;
+        CHK(hipMalloc(&fr, vpx * 55 * NV + 64)); CHK(hipMalloc(&o, vpx * 12 * NV)); CHK(hipMalloc(&ov, vpx * NV));
+        CHK(hipMemset(fr, 0x5a, vpx * 55 * NV + 64));
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; rep++)
+            for (int planes : {47, 55})
+                for (int form = 0; form < 2; form++)
+                    for (int cold = 0; cold < 2; cold++) {
+                        const int launches = 400;
+                        float ms = 0;
+                        for (int pass = 0; pass < 2; pass++) {
+                            CHK(hipEventRecord(e0));
+                            for (int i = 0; i < launches; i++) {
+                                const int v = cold ? i % NV : 0;
+                                const uint8_t *f = fr + (size_t)v * vpx * 55;
+                                float4 *oo = (float4 *)((float *)o + (size_t)v * vpx * 3);
+                                unsigned *vv = ov + (size_t)v * vpx / 4;
+                                if (planes == 47 && form == 0) hipLaunchKernelGGL((k_scope<47, 1, 0>), dim3((nq + 255) / 256), dim3(256), 0, 0, f, vpx, oo, vv, nq);
+                                if (planes == 47 && form == 1) hipLaunchKernelGGL((k_scope<47, 0, 4>), dim3((nq + 255) / 256), dim3(256), 0, 0, f, vpx, oo, vv, nq);
+                                if (planes == 55 && form == 0) hipLaunchKernelGGL((k_scope<55, 1, 0>), dim3((nq + 255) / 256), dim3(256), 0, 0, f, vpx, oo, vv, nq);
+                                if (planes == 55 && form == 1) hipLaunchKernelGGL((k_scope<55, 0, 4>), dim3((nq + 255) / 256), dim3(256), 0, 0, f, vpx, oo, vv, nq);
+                            }
+                            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                            CHK(hipEventElapsedTime(&ms, e0, e1));
+                        }
+                        CHK(hipGetLastError());
+                        const double us = ms * 1e3 / launches, bytes = (double)vpx * (planes + 13);
+                        printf("one view per launch, %d B/px read, %s, %s: %6.2f us per launch  %6.0f GB/s moved  frac of 8 TB/s on 60 B/px %.3f\n", planes,
+                               form == 0 ? "nt loads + whole-line nt stores" : "plain loads + plain whole-line stores", cold ? "8 views round robin (HBM)" : "same view (Infinity Cache)",
+                               us, bytes / us / 1e3, 60.0 * vpx / us / 1e3 / 8000.0);
+                    }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "oneview")) {
         const size_t vpx = 1920 * 1080, nq = vpx / 4;
         uint8_t *fr; float4 *o; unsigned *ov;
