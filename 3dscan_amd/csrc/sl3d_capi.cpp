@@ -104,7 +104,6 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     sl3d_ctx *x = new sl3d_ctx();
     x->cfg = c;
     x->keep = (c.flags & SL3D_FLAG_KEEP_STAGES) != 0;
-    x->clouds_lookback = (c.flags & SL3D_FLAG_CLOUDS_LOOKBACK) != 0;
 #define CREATE_CHK(call)                                                                 \
     do {                                                                                 \
         hipError_t e_ = (call);                                                          \
@@ -133,10 +132,6 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
 #ifdef SL3D_MEASURE
     P.ablate = getenv("SL3D_ABLATE") ? atoi(getenv("SL3D_ABLATE")) : 0;
 #endif
-    {
-        int ncu = 0;
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess) P.n_cus = ncu;
-    }
     P.pitch = (c.width + 15) & ~15;
     P.planes_per_view = 2 * P.F + 2 * P.Nv + 2 * P.Nh;
     P.plane_stride = (size_t)P.pitch * P.H;
@@ -244,14 +239,6 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
     if (!x) return;
     DeviceGuard dev_guard_(x->cfg.device);
     if (x->stream) (void)hipStreamSynchronize(x->stream);
-#ifdef SL3D_MEASURE
-    if (x->d_lookback_err) {  // look-back counters of a -DSL3D_CX=64 build: calls, rounds, re-polls, clock ticks, tiles walked back
-        unsigned long long st[8] = {0};
-        if (hipMemcpy(st, x->d_lookback_err, sizeof st, hipMemcpyDeviceToHost) == hipSuccess && st[1])
-            fprintf(stderr, "[sl3d look-back] calls %llu rounds/call %.2f repolls/call %.2f us/call %.2f tiles_back/call %.1f calls_that_waited %.3f\n", st[1],
-                    (double)st[2] / st[1], (double)st[3] / st[1], (double)st[4] / st[1] / 100.0, (double)st[5] / st[1], (double)st[6] / st[1]);
-    }
-#endif
     for (void *p : x->allocs) (void)hipFree(p);
     if (x->h_counts) (void)hipHostFree(x->h_counts);
     for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
@@ -534,7 +521,12 @@ extern "C" int sl3d_set_frames_range(sl3d_ctx *x, int view, int axis, int first_
         for (int i = 0; i < n_planes; i++)
             HIPCHK_DRAIN(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
     }
-    if (!is_pinned_host(planes[0])) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
+    // a pageable source is consumed before we return; the hand-over is asynchronous only if EVERY plane of the call is pinned
+    // (callers mix sources: a pinned image next to file-decoded pageable frames)
+    bool all_pinned = true;
+    for (int i = 0; i < n_planes && all_pinned; i++)
+        if ((i == 0 || !back_to_back) && !is_pinned_host(planes[i])) all_pinned = false;
+    if (!all_pinned) HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
 
@@ -695,6 +687,15 @@ extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE(x);
     return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream));
+}
+
+// the k_fused instantiation sl3d_run / sl3d_run_clouds launches for a batch of n_views views of this context, as rocprofv3 spells it
+extern "C" int sl3d_fused_kernel_name(sl3d_ctx *x, int n_views, int clouds, char *buf, size_t capacity)
+{
+    if (!x || !buf || capacity == 0 || n_views < 1) return fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: null argument");
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called (the rig class is part of the name)");
+    const int n = fused_kernel_name(x->P, x->rig, n_views, x->keep, clouds ? 2 : 0, buf, capacity);
+    return n > 0 && (size_t)n < capacity ? SL3D_OK : fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: buffer too small");
 }
 
 extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
@@ -942,11 +943,8 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
     if (!rc && !x->d_totals) rc = dev_alloc(x, &x->d_totals, mv);
     if (rc) return rc;
     P.n_tiles = fused_tiles(P);
-    if (!x->d_tile_status) rc = dev_alloc(x, &x->d_tile_status, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE);
-    if (!rc && !x->d_ticket) rc = dev_alloc(x, &x->d_ticket, (size_t)1);
-    if (!rc && !x->d_lookback_err) rc = dev_alloc(x, &x->d_lookback_err, (size_t)16);  // [0] = error flag; measurement builds keep counters behind it
     P.n_segs = 4 * P.n_tiles;
-    if (!rc && !x->d_seg_counts) rc = dev_alloc(x, &x->d_seg_counts, mv * (size_t)P.n_segs);
+    if (!x->d_seg_counts) rc = dev_alloc(x, &x->d_seg_counts, mv * (size_t)P.n_segs);
     if (!rc && !x->d_seg_offsets) rc = dev_alloc(x, &x->d_seg_offsets, mv * (size_t)P.n_segs);
     if (rc) return rc;
     // a wave of the last tile that owns no row never stores its count: zero once, for good
@@ -954,36 +952,23 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
     HIPCHK(x, hipMemsetAsync(x->d_seg_offsets, 0, mv * (size_t)P.n_segs * sizeof(unsigned long long), x->stream));
     P.seg_counts = x->d_seg_counts;
     P.seg_offsets = x->d_seg_offsets;
-    HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, mv * (size_t)P.n_tiles * SL3D_ST_STRIDE * sizeof(unsigned long long), x->stream));
-    HIPCHK(x, hipMemsetAsync(x->d_lookback_err, 0, 16 * sizeof(int), x->stream));
-    HIPCHK(x, hipMemsetAsync(x->d_ticket, 0, sizeof(unsigned), x->stream));
-    x->tickets_drawn = 0;
-    P.ticket = x->d_ticket;
     P.clouds = x->d_clouds;
-    P.tile_status = x->d_tile_status;
-    // the per-view counts and the error flag live in pinned HOST memory the kernel writes directly (one 8-byte store per view):
+    // the per-view counts live in pinned HOST memory the scan kernel writes directly (one 8-byte store per view):
     // sl3d_get_cloud_counts then only has to wait for the stream, no device-to-host copy in the launch -> counts path
     if (!x->h_counts) {
-        HIPCHK(x, hipHostMalloc((void **)&x->h_counts, (mv + 1) * sizeof(unsigned long long), hipHostMallocMapped));
-        memset(x->h_counts, 0, (mv + 1) * sizeof(unsigned long long));
+        HIPCHK(x, hipHostMalloc((void **)&x->h_counts, mv * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(x->h_counts, 0, mv * sizeof(unsigned long long));
     }
     void *mapped = nullptr;
     HIPCHK(x, hipHostGetDevicePointer(&mapped, x->h_counts, 0));
     P.cloud_totals = (unsigned long long *)mapped;
-    P.lookback_flag = (int *)((unsigned long long *)mapped + mv);
-    P.lookback_err = x->d_lookback_err;
-#ifdef SL3D_MEASURE
-    if (!x->P.dbg) rc = dev_alloc(x, &x->P.dbg, mv * (size_t)P.n_tiles * 4);
-    if (rc) return rc;
-    HIPCHK(x, hipMemsetAsync(x->P.dbg, 0, mv * (size_t)P.n_tiles * 4 * sizeof(unsigned long long), x->stream));
-#endif
-    P.epoch = 0;
     x->clouds_ready = true;
     return SL3D_OK;
 }
 
-// The fused kernel with the compaction of 8/save_point_cloud.cpp:85-104 inside it (k_fused<..., COMPACT>): one launch reads
-// every frame byte once and writes the valid map and the compacted cloud of every view; no dense xyz plane, no second pass.
+// The fused kernel with the compaction of 8/save_point_cloud.cpp:85-104 inside it (k_fused<..., CMODE = 2>: segmented ordered
+// clouds): one launch reads every frame byte once and writes the valid map and the compacted points of every view -- no dense xyz
+// plane, no second pass over the results -- then one small scan launch turns the segment counts into offsets and totals.
 extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
 {
     int rc = check_view(x, first_view, n_views);
@@ -993,16 +978,9 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
     ON_DEVICE(x);
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
-    if (!x->clouds_lookback) {  // segmented clouds: the fused kernel, then the offsets / totals of its segment counts
-        rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 2, x->stream));
-        if (rc) return rc;
-        return launched(x, launch_seg_scan(x->P, first_view, n_views, x->stream));
-    }
-    if (++x->P.epoch >= (1u << 30)) {  // the generation tag is 30 bits: start over with cleared words
-        HIPCHK(x, hipMemsetAsync(x->d_tile_status, 0, (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * SL3D_ST_STRIDE * sizeof(unsigned long long), x->stream));
-        x->P.epoch = 1;
-    }
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 1, x->stream, &x->tickets_drawn));
+    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 2, x->stream));
+    if (rc) return rc;
+    return launched(x, launch_seg_scan(x->P, first_view, n_views, x->stream));
 }
 
 static int ensure_packed(sl3d_ctx *x)
@@ -1019,29 +997,20 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
     ON_DEVICE(x);
-    // the kernel stored the counts (and, never expected, the error flag) into pinned host memory itself: wait for it, read them
+    // the scan kernel stored the counts into pinned host memory itself: wait for it, read them
     HIPCHK(x, hipStreamSynchronize(x->stream));
     volatile unsigned long long *t = x->h_counts;
-    volatile int *flag = (volatile int *)(x->h_counts + (size_t)x->cfg.max_views);
-    if (*flag) {
-        *flag = 0;
-        return fail(x, SL3D_E_HIP, "fused compaction: a tile look-back timed out");
-    }
     for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[first_view + v];
-    if (device_xyz) {
-        if (x->clouds_lookback) {
-            *device_xyz = x->d_clouds + 3 * (size_t)first_view * x->P.px_view_stride;
-        } else {  // segmented clouds: the contiguous copy is made now, by one gap-closing launch over these views
-            rc = ensure_packed(x);
-            if (rc) return rc;
-            float *dst = x->d_packed + 3 * (size_t)first_view * x->P.px_view_stride;
-            rc = launched(x, launch_seg_close(x->P, first_view, n_views, dst, x->P.px_view_stride, x->stream));
-            if (rc) return rc;
-            // the copy is handed to consumers on OTHER streams too (a group's communication stream, a caller's RCCL stream):
-            // like the counts, it is complete when this call returns
-            HIPCHK(x, hipStreamSynchronize(x->stream));
-            *device_xyz = dst;
-        }
+    if (device_xyz) {  // the contiguous copy is made now, by one gap-closing launch over these views
+        rc = ensure_packed(x);
+        if (rc) return rc;
+        float *dst = x->d_packed + 3 * (size_t)first_view * x->P.px_view_stride;
+        rc = launched(x, launch_seg_close(x->P, first_view, n_views, dst, x->P.px_view_stride, x->stream));
+        if (rc) return rc;
+        // the copy is handed to consumers on OTHER streams too (a group's communication stream, a caller's RCCL stream):
+        // like the counts, it is complete when this call returns
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+        *device_xyz = dst;
     }
     if (view_stride_points) *view_stride_points = x->P.px_view_stride;
     return SL3D_OK;
@@ -1053,7 +1022,6 @@ extern "C" int sl3d_get_cloud_segments(sl3d_ctx *x, int first_view, int n_views,
     if (rc) return rc;
     if (!out) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
-    if (x->clouds_lookback) return fail(x, SL3D_E_STATE, "the context writes contiguous clouds (SL3D_FLAG_CLOUDS_LOOKBACK): use sl3d_get_cloud_counts");
     if (counts) {
         rc = sl3d_get_cloud_counts(x, first_view, n_views, nullptr, nullptr, counts);
         if (rc) return rc;
@@ -1063,7 +1031,7 @@ extern "C" int sl3d_get_cloud_segments(sl3d_ctx *x, int first_view, int n_views,
     out->counts = x->d_seg_counts + (size_t)first_view * P.n_segs;
     out->offsets = (const uint64_t *)(x->d_seg_offsets + (size_t)first_view * P.n_segs);
     out->n_segments = P.n_segs;
-    out->segment_points = 256;
+    out->segment_points = SL3D_SEG_POINTS;
     out->view_stride_points = P.px_view_stride;
     out->view_stride_segments = (size_t)P.n_segs;
     return SL3D_OK;
@@ -1071,8 +1039,7 @@ extern "C" int sl3d_get_cloud_segments(sl3d_ctx *x, int first_view, int n_views,
 
 // The host copy of the clouds of the last sl3d_run_clouds, back to back (8/save_point_cloud.cpp:85-104 fills a host cloud).
 // Segmented clouds + pinned destination: the gap-closing kernel stores straight into the (mapped) host buffer -- the PCIe link is
-// the bound either way, so closing the gaps costs nothing; pageable destination or look-back clouds: a contiguous device copy
-// goes down by DMA.
+// the bound either way, so closing the gaps costs nothing; pageable destination: a contiguous device copy goes down by DMA.
 extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts)
 {
     int rc = check_view(x, first_view, n_views);
@@ -1086,7 +1053,7 @@ extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, fl
     for (int v = 0; v < n_views; v++) total += counts[v];
     void *mapped = nullptr;
     const char *zc = getenv("SL3D_ZEROCOPY");
-    const bool zero_copy = !x->clouds_lookback && total <= capacity && !(zc && atoi(zc) == 0) && is_pinned_host(xyz) &&
+    const bool zero_copy = total <= capacity && !(zc && atoi(zc) == 0) && is_pinned_host(xyz) &&
                            hipHostGetDevicePointer(&mapped, xyz, 0) == hipSuccess && mapped;
     if (!zero_copy) (void)hipGetLastError();
     if (zero_copy) {
@@ -1285,10 +1252,7 @@ extern "C" int sl3d_register_clouds(sl3d_ctx *x, int first_view, int n_views, fl
     if (rc) return rc;
     if (!total) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     std::vector<int64_t> counts((size_t)n_views);
-    const float *clouds = nullptr;
-    size_t stride = 0;
-    // (look-back clouds are contiguous already: they go through the plain transform kernel)
-    rc = sl3d_get_cloud_counts(x, first_view, n_views, x->clouds_lookback ? &clouds : nullptr, &stride, counts.data());
+    rc = sl3d_get_cloud_counts(x, first_view, n_views, nullptr, nullptr, counts.data());
     if (rc) return rc;
     ON_DEVICE(x);
     const KParams &P = x->P;
@@ -1303,8 +1267,7 @@ extern "C" int sl3d_register_clouds(sl3d_ctx *x, int first_view, int n_views, fl
         const float R4[4] = {(float)cos(theta * 22.0 / 7.0 / 180.0), (float)(-1.0f * sin(theta * 22.0 / 7.0 / 180.0)),
                              (float)sin(theta * 22.0 / 7.0 / 180.0), (float)cos(theta * 22.0 / 7.0 / 180.0)};
         if (n > 0) {
-            if (x->clouds_lookback) rc = launched(x, launch_register(clouds + 3 * (size_t)k * stride, x->d_reg + 3 * off, (long)n, R4, tx, ty, tz, x->stream));
-            else rc = launched(x, launch_seg_register(P, first_view + k, x->d_reg + 3 * off, R4, tx, ty, tz, x->stream));
+            rc = launched(x, launch_seg_register(P, first_view + k, x->d_reg + 3 * off, R4, tx, ty, tz, x->stream));
             if (rc) return rc;
         }
         off += n;
@@ -1450,13 +1413,13 @@ extern "C" int sl3d_generate_pattern(sl3d_ctx *x, int kind, int axis, int index,
 }
 
 #ifdef SL3D_MEASURE
-// measurement builds: the look-back clock stamps [view][tile][4] (publish, look-back start, look-back end, xcc | base << 32)
+// measurement builds (-DSL3D_TRACE): the per-wave phase stamps of the dense kernel (tools/phase_trace.py)
 extern "C" int sl3d_debug_buffer(sl3d_ctx *x, const void **dev, size_t *bytes, int *n_tiles)
 {
-    if (!x || !x->P.dbg) return SL3D_E_STATE;
+    if (!x || !x->P.dbg || !x->dbg_words) return SL3D_E_STATE;
     *dev = x->P.dbg;
-    *bytes = x->dbg_words ? x->dbg_words * sizeof(unsigned long long) : (size_t)x->cfg.max_views * (size_t)x->P.n_tiles * 4 * sizeof(unsigned long long);
-    *n_tiles = x->P.n_tiles;
+    *bytes = x->dbg_words * sizeof(unsigned long long);
+    *n_tiles = fused_tiles(x->P);
     return SL3D_OK;
 }
 #endif

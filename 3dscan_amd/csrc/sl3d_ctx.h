@@ -44,16 +44,11 @@ struct sl3d_ctx {
     float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
     unsigned *d_blk_cnt_all = nullptr;
     unsigned long long *d_blk_off_all = nullptr, *d_totals = nullptr;
-    unsigned long long *d_tile_status = nullptr;  // sl3d_run_clouds: look-back words [view][tile] of the fused compaction
-    int *d_lookback_err = nullptr;
-    bool clouds_lookback = false;             // SL3D_FLAG_CLOUDS_LOOKBACK: contiguous clouds by a decoupled look-back; else segmented clouds
-    unsigned *d_seg_counts = nullptr;         // segmented clouds: [view][n_segs] counts, their exclusive scan,
+    unsigned *d_seg_counts = nullptr;         // sl3d_run_clouds (segmented clouds): [view][n_segs] counts, their exclusive scan,
     unsigned long long *d_seg_offsets = nullptr;
     float *d_packed = nullptr;                // and the contiguous copy made on demand (also the output of sl3d_compact_views)
     bool clouds_ready = false;                // ensure_cloud_buffers ran to its end: every pointer sl3d_run_clouds needs is set
-    unsigned *d_ticket = nullptr;             // work-item counter of the persistent compacting kernel
-    unsigned long long *h_counts = nullptr;   // pinned: the per-view counts (+ error flag) sl3d_get_cloud_counts reads back
-    unsigned tickets_drawn = 0;               // its value once every enqueued launch has run
+    unsigned long long *h_counts = nullptr;   // pinned + mapped: the per-view counts k_seg_scan stores, sl3d_get_cloud_counts reads
     uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)
     uint8_t *d_cloud_rgb = nullptr;           // r,g,b of the compacted cloud of one view
     std::vector<char> have_texture;

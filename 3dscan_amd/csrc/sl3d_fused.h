@@ -1,0 +1,817 @@
+// sl3d_fused.h -- k_fused: stages 3(v) 3(h) 4(v) 4(h) 5 7 + the f32 cast of stage 8 in ONE pass over the frames (gfx950, wave64).
+//
+// One lane owns 4 horizontally adjacent pixels = one dword of every 8-bit plane, so a wave reads 256 contiguous bytes of each of
+// the 2F+2Nv+2Nh planes (coalesced) and writes 3 KiB of xyz + 256 B of valid.  No MFMA: this is a per-pixel map bounded by HBM
+// bandwidth and by fp64 VALU.  The kernel is a template; its instantiations are compiled by the sl3d_fused_*.hip translation units
+// (one family each, in parallel) and picked by launch_fused (sl3d_fused_launch.hip).
+//
+// The body of k_fused is a sequence of named phases, each a __device__ __forceinline__ function below:
+//   item_begin        what depends on the pixel only: tile -> row / column, the first valid-map dword, camera-side T1 (cam_table_*)
+//   issue_fringe/gray all plane dwords of a view requested back to back (memory-level parallelism: ~12 KiB in flight per wave)
+//   decode_gray       S4b, byte-parallel over the lane's 4 pixels
+//   phase_A           S3c + S4c + C2 of the 4 pixels -> correspondences parked in the LDS staging area
+//   gather_B/phase_B  T1 (projector table) + T2 + T3 + O1 -> xyz in the LDS staging area
+//   store_quad        dense results: whole 1-KiB runs per store instruction, non-temporal
+//   store_segment     segmented clouds (CMODE 2): the wave's valid points compacted in scan order into its own slot
+//   parity_pixels     the parity mode (KEEP): every stage-boundary plane the reference keeps in globals
+// What was measured and rejected on the way (XCD-banded tile order, buffer loads with scope bits, non-temporal 16-byte pieces,
+// start stagger, un-split pixel loop, the single-pass look-back compaction, other block sizes / occupancies) is recorded in
+// DESIGN.md section 4 and profiles/README.md; git history has the code.
+#pragma once
+#include "sl3d_device.h"
+
+#define SL3D_BLOCK 256 /* threads per block: a block is a 1024-pixel tile of the scan, 4 waves = 4 segments of 256 pixels */
+#define SL3D_OCC 4     /* waves per SIMD the fused kernel is compiled for (128 VGPRs) */
+
+// measurement only (tools/ab.sh builds with -DSL3D_MEASURE -DSL3D_ABLATE=n): 2 = no mask reads, 4 = no xyz stores.  Results are wrong
+// by construction; the shipped build has neither the compile-time switch nor the run-time hooks (SL3D_VPT / SL3D_CAMTAB
+// environment variables, KParams::ablate).
+#if !defined(SL3D_MEASURE) || !defined(SL3D_ABLATE)
+#undef SL3D_ABLATE
+#define SL3D_ABLATE 0
+#endif
+// measurement builds only (-DSL3D_MEASURE -DSL3D_TRACE): wall-clock stamps (100 MHz) of every wave of the dense timed kernel at
+// its phase boundaries, first view of the item: 0 entry, 1 reciprocal table filled, 2 item set up (camera table entries, first
+// mask dword requested), 3 plane loads issued, 4 planes landed + decoded, 5 phase A done, 6 phase B done, 7 stores issued
+// -> KParams::dbg [block][wave][8] (tools/phase_trace.py)
+#if defined(SL3D_MEASURE) && defined(SL3D_TRACE)
+#define SL3D_STAMP(k)                                                                                                               \
+    do {                                                                                                                            \
+        /* every lane of the wave stores the same (scalar) clock to the same word: no divergent branch in the instrumented code */   \
+        if (CMODE == 0 && !KEEP && P.dbg)                                                                                           \
+            P.dbg[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64();              \
+    } while (0)
+#else
+#define SL3D_STAMP(k)
+#endif
+#ifdef SL3D_MEASURE
+#define SL3D_ABLATE_RT(P) ((P).ablate)
+#else
+#define SL3D_ABLATE_RT(P) 0
+#endif
+
+namespace sl3d {
+
+// RIG (stage 7 of the timed fused kernel, chosen by launch_fused from the calibration):
+//   0  general: any K, any distortion, everything evaluated in the kernel with the reference's operation order
+//      (also what the parity mode and the per-stage kernels run)
+//   1  camera K upper triangular + affine (fx, skew, fy, cx, cy), projector without distortion and with a plain K (the reference's
+//      own calibration): camera-frame least squares, the projector point is the correspondence itself
+//   2  the same camera, any other projector: camera-frame least squares; the undistorted projector point comes from the
+//      per-calibration table KParams::proj_disp (one float2 displacement per projector pixel, built by k_proj_table with
+//      the same 5-iteration undistortion) -- the reference also tabulates it (7/triangulation.cpp:363-378), per scan
+
+// ---- parity mode: one pixel, everything after the byte loads (stage 4 unwrap, stage 5, stage 7, stage 8 cast), every
+// stage-boundary value stored where the reference keeps it.  (cu,cv) = undistorted camera pixel coordinates of this pixel
+// (T1, depends on the pixel only); (wv,wh) = wrapped phases, already shifted by +Pi where stage 4 shifts them.
+struct PixelResult {
+    float x, y, z;
+    bool valid;
+};
+
+template <typename CalP>
+__device__ __forceinline__ PixelResult parity_chain(const KParams &P, CalP Cp, const PinnedRows &PR, int gx, int gy, double cu, double cv, float wv,
+                                                    float wh, int code_v, int code_h, size_t keep_off)
+{
+    PixelResult R;
+    const float nanv = __builtin_nanf("");
+    R.x = R.y = R.z = nanv;
+    // stage 4: the unwrap skips the first/last column (v) or row (h) of the frame; unwrapped stays unset (0 here)
+    const bool in_v = gx >= 1 && gx <= P.fullW - 2;  // 4/phase_unwrap.cpp:285
+    const bool in_h = gy >= 1 && gy <= P.fullH - 2;  // 4/phase_unwrap.cpp:304
+    const float uvv = unwrap_value(wv, code_v), uhv = unwrap_value(wh, code_h);
+    const float uv = in_v ? uvv : 0.0f;
+    const float uh = in_h ? uhv : 0.0f;
+    long cx, cy;
+    double cxd, cyd;
+    const bool okx = correspond(uv, P.fwv, P.PW, cx, cxd);
+    const bool oky = correspond(uh, P.fwh, P.PH, cy, cyd);
+    R.valid = okx && oky;
+    P.wrapped[0][keep_off] = wv;
+    P.wrapped[1][keep_off] = wh;
+    P.unwrapped[0][keep_off] = uv;
+    P.unwrapped[1][keep_off] = uh;
+    P.code[0][keep_off] = code_v;
+    P.code[1][keep_off] = code_h;
+    // rejected pixels are never compared; store 0 for those
+    P.cpmap[2 * keep_off + 0] = R.valid ? cx : 0;
+    P.cpmap[2 * keep_off + 1] = R.valid ? cy : 0;
+    if (R.valid) {
+        double up, vp, X[3];
+        const auto &C = *Cp;
+        if (C.proj.identity) {
+            up = cxd;
+            vp = cyd;
+        } else {
+            undistort_reproject(cxd, cyd, C.proj, up, vp);
+        }
+        triangulate_px(C, PR, cu, cv, up, vp, X);
+        R.x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
+        R.y = (float)X[1];
+        R.z = (float)X[2];
+        P.ipoints[3 * keep_off + 0] = X[0];
+        P.ipoints[3 * keep_off + 1] = X[1];
+        P.ipoints[3 * keep_off + 2] = X[2];
+    }
+    return R;
+}
+
+// ---- timed mode: the same chain in two halves.  Stages 4 + 5 of one pixel -> its correspondence (bit-exact chain, both axes in
+// one basic block), and stage 7 + the cast of stage 8 from that correspondence.
+__device__ __forceinline__ bool correspond_px(const KParams &P, int gx, int gy, float wv, float wh, int code_v, int code_h, int &cx, int &cy)
+{
+    const bool in_v = gx >= 1 && gx <= P.fullW - 2;  // 4/phase_unwrap.cpp:285
+    const bool in_h = gy >= 1 && gy <= P.fullH - 2;  // 4/phase_unwrap.cpp:304
+    // keep the two phase chains out of divergent branches (the optimiser would sink each atan2 into its own `if (in range)` block
+    // and serialise them) so that they interleave in one basic block
+    float uvv = unwrap_value(wv, code_v), uhv = unwrap_value(wh, code_h);
+    asm volatile("" : "+v"(uvv));
+    asm volatile("" : "+v"(uhv));
+    // select the 32-bit value (the optimiser would move the select behind the conversion to double: 2 ops each)
+    float uv = in_v ? uvv : 0.0f;
+    float uh = in_h ? uhv : 0.0f;
+    asm volatile("" : "+v"(uv));
+    asm volatile("" : "+v"(uh));
+    long lx, ly;
+    double dxd, dyd;
+    const bool okx = correspond(uv, P.fwv, P.PW, lx, dxd);
+    const bool oky = correspond(uh, P.fwh, P.PH, ly, dyd);
+    cx = (int)lx;
+    cy = (int)ly;
+    return okx && oky;
+}
+
+template <int RIG, typename CalP>
+__device__ __forceinline__ void triangulate_from(const KParams &P, CalP Cp, const PinnedRows &PR, double cu, double cv, int cx, int cy, float2 d, bool table,
+                                                 float &x, float &y, float &z)
+{
+    const auto &C = *Cp;
+    const double cxd = (double)cx, cyd = (double)cy;
+    double X[3];
+    bool singular = false;
+    if (RIG == 1) {
+        // the projector's undistort + re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px),
+        // and (cu,cv) are the camera's undistorted NORMALISED coordinates for the camera-frame solve
+        triangulate_camframe(C, PR, cu, cv, cxd, cyd, X, singular);
+    } else if (RIG == 2) {
+        triangulate_camframe(C, PR, cu, cv, cxd + (double)d.x, cyd + (double)d.y, X, singular);
+    } else {
+        double up = cxd, vp = cyd;
+        if (table) {  // timed mode: the per-calibration table of the same values (see RIG 2)
+            up = cxd + (double)d.x;
+            vp = cyd + (double)d.y;
+        } else if (!C.proj.identity) {
+            undistort_reproject(cxd, cyd, C.proj, up, vp);
+        }
+        triangulate_px(C, PR, cu, cv, up, vp, X);
+    }
+    x = (float)X[0];  // 8/save_point_cloud.cpp:100-102
+    y = (float)X[1];
+    z = (float)X[2];
+    if (RIG != 0 && singular) x = y = z = 0.0f;  // cvInvert's zero matrix: V = 0
+}
+
+// ---- the lane's work item: one quad (4 pixels of a row) of a 1024-pixel tile, for one group of `vpt` views -----------------------
+// grid.x covers the quads of one window, grid.y covers groups of `vpt` views: a lane keeps its 4 pixels and walks through the
+// views of its group, so whatever depends on the pixel only (the camera-side undistortion: the most expensive per-pixel constant
+// of stage 7) is set up once per pixel, not once per pixel per view.
+struct Item {
+    unsigned tile;      // 1024-pixel tile of the scan = blockIdx.x
+    int cq, row;        // quad column, window row
+    int gx0, gy;        // frame coordinates of the quad's first pixel
+    int v_begin, v_end; // views of this item
+    bool alive;         // the lane owns pixels (segmented clouds keep the lanes past the last row: a wave stores its segment whole)
+    unsigned lane_off;  // byte offset of the quad inside any plane
+};
+
+// the camera-table entries of the lane's 4 pixels: kind 1 = one double per pixel (factor of the last undistortion iteration of a
+// radial model), kind 2 = the normalised point itself (tangential terms).  Request and use are separate so that the small-launch
+// instantiation can put its plane requests in between.
+__device__ __forceinline__ void cam_table_request(const KParams &P, const Item &it, double (&t)[8])
+{
+    const size_t i0 = (size_t)it.row * P.pitch + (size_t)it.cq * 4;
+    if (P.use_cam_table == 1) {
+        const double2 *tp = (const double2 *)(P.cam_tab + i0);
+        const double2 a = tp[0], b = tp[1];
+        t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
+    } else {
+        const double2 *tp = (const double2 *)(P.cam_tab + 2 * i0);
+        const double2 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y; t[4] = c.x; t[5] = c.y; t[6] = d.x; t[7] = d.y;
+    }
+}
+
+// table entries -> the camera coordinates stage 7 uses (normalised for the camera-frame rigs, re-projected pixels for RIG 0), kept
+// in LDS so that the rolled pixel loops can index them (each lane reads back only what it wrote: no barrier).  The doubles are the
+// ones the in-kernel iteration produces.
+template <int RIG>
+__device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal *Cglobal, const Item &it, const double (&t)[8], double *my_cam)
+{
+    const auto &I = opaque_const(Cglobal)->cam;
+    if (P.use_cam_table == 1) {
+        const double y0 = ((double)it.gy - I.cy) * I.ify;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double xn = (((double)(it.gx0 + k)) - I.cx) * I.ifx * t[k], yn = y0 * t[k];
+            if (RIG == 0) reproject(xn, yn, I, xn, yn);
+            my_cam[2 * k] = xn;
+            my_cam[2 * k + 1] = yn;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double xn = t[2 * k], yn = t[2 * k + 1];
+            if (RIG == 0) reproject(xn, yn, I, xn, yn);
+            my_cam[2 * k] = xn;
+            my_cam[2 * k + 1] = yn;
+        }
+    }
+}
+
+// Everything of an item that depends on the pixel only; false if this lane has nothing to do.
+// EARLY (the small-launch instantiation): the camera-table entries are only REQUESTED here (camt); the caller issues the first
+// view's plane loads right behind them and then calls cam_table_finish -- one round trip instead of two in front of the first
+// decode.  (Round 3 measured the other order for large launches -- set-up loads before the reciprocal-table fill, consumed behind
+// the plane loads: 16 views +-0, profiles/r03_prologue_ab.txt.)
+template <int RIG, bool SEG, bool EARLY>
+__device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglobal, unsigned tile_, int group, int first_view, int n_views, int vpt, Item &it,
+                                           MaskQuad &mq_first, double (&camt)[8], double *my_cam)
+{
+    const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
+    it.tile = tile_;
+    it.v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
+    it.v_end = min(it.v_begin + vpt, first_view + n_views);
+    const long q = (long)tile_ * SL3D_BLOCK + threadIdx.x;
+    const int row_q = (int)(q / qpr);
+    it.cq = (int)(q - (long)row_q * qpr);
+    // SEG: a wave stores its segment with all 64 lanes (whole 16-byte chunks, lane after lane), so the lanes past the last row
+    // stay, without a valid pixel; only the blocks the grid was padded with leave (they own no segment)
+    if (SEG && tile_ >= (unsigned)P.n_tiles) return false;
+    if (!SEG && row_q >= P.H) return false;
+    it.alive = row_q < P.H;
+    it.row = SEG ? min(row_q, P.H - 1) : row_q;
+    it.gx0 = P.col0 + it.cq * 4;
+    it.gy = P.row0 + it.row;
+    it.lane_off = (unsigned)it.row * (unsigned)P.pitch + (unsigned)it.cq * 4u;
+    // the valid bits of the item's first view are requested now, so that they travel together with the camera table
+    // entries below instead of after them (one round trip less before the first plane loads can leave)
+    mq_first = load_mask_quad(P, min(it.v_begin, first_view + n_views - 1), it.cq, it.row);
+    if (EARLY && P.use_cam_table) {
+        cam_table_request(P, it, camt);
+        return true;
+    }
+    if (P.use_cam_table) {
+        double t[8];
+        cam_table_request(P, it, t);
+        cam_table_finish<RIG>(P, Cglobal, it, t, my_cam);
+        return true;
+    }
+    // no table (a camera without distortion, or the parity mode): T1 of the camera evaluated here
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        double cu = 0.0, cv = 0.0;
+        if (it.cq * 4 < P.W && !(SL3D_ABLATE_RT(P) & 4)) {
+            if (RIG != 0) undistort_normalized((double)(it.gx0 + k), (double)it.gy, opaque_const(Cglobal)->cam, cu, cv);  // camera-frame solve
+            else undistort_reproject((double)(it.gx0 + k), (double)it.gy, opaque_const(Cglobal)->cam, cu, cv);
+        }
+        my_cam[2 * k] = cu;
+        my_cam[2 * k + 1] = cv;
+    }
+    return true;
+}
+
+// the third rows of the projection matrices and the translation, pinned in VGPRs (see PinnedRows)
+template <int RIG>
+__device__ __forceinline__ PinnedRows pinned_rows(const DevCal *Cglobal)
+{
+    PinnedRows PR;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        PR.c2[j] = RIG != 0 ? 0.0 : Cglobal->Ac[8 + j];
+        PR.p2[j] = RIG != 0 ? Cglobal->Apc[8 + j] : Cglobal->Ap[8 + j];
+        if (RIG == 0) asm volatile("" : "+v"(PR.c2[j]));
+        asm volatile("" : "+v"(PR.p2[j]));  // stay in VGPRs
+        if (j < 3) {
+            PR.t[j] = RIG != 0 ? Cglobal->tcn[j] : 0.0;
+            if (RIG != 0) asm volatile("" : "+v"(PR.t[j]));
+        }
+    }
+    return PR;
+}
+
+// ---- plane loads ---------------------------------------------------------------------------------------------------------------
+// planes of a view: vertical axis (fringe F, gray Nv, inverse Nv), then the horizontal axis.  Plane offsets are added to the scalar
+// view base (SALU); every load uses the same 32-bit VGPR offset.  Instruction selection works per basic block: the zero-extension
+// of the lane offset has to happen in the block of the loads for them to select the (SGPR base + 32-bit VGPR offset) form, hence
+// the per-call copy behind an empty asm.
+template <bool FGEN>
+__device__ __forceinline__ void issue_fringe(const KParams &P, int view, unsigned lane_off, int F, int Nv, unsigned (&f)[2][4])
+{
+    const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
+    const unsigned psv = opaque_u32((unsigned)P.plane_stride);  // per-view copy: plane offsets are recomputed, not kept live
+    unsigned lo = lane_off;
+    asm volatile("" : "+v"(lo));
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const unsigned p0 = a == 0 ? 0u : (unsigned)(F + 2 * Nv) * psv;
+        f[a][0] = ldg32(vb + (size_t)p0, lo);
+        f[a][1] = ldg32(vb + (size_t)(p0 + psv), lo);
+        f[a][2] = ldg32(vb + (size_t)(p0 + 2u * psv), lo);
+        f[a][3] = (FGEN && F == 4) ? ldg32(vb + (size_t)(p0 + 3u * psv), lo) : 0u;
+    }
+}
+
+// NMAX is the compile-time unroll bound of the Gray planes; EXACT = both axes have exactly NMAX planes (the plane clamps and the
+// per-plane tests fold away); otherwise an axis with fewer planes skips the surplus loads through a wave-uniform test
+template <int NMAX, bool EXACT>
+__device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned lane_off, int F, int Nv, int Nh, unsigned (&g)[2][NMAX], unsigned (&iv)[2][NMAX])
+{
+    const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
+    const unsigned psv = opaque_u32((unsigned)P.plane_stride);
+    unsigned lo = lane_off;
+    asm volatile("" : "+v"(lo));
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int N = a == 0 ? Nv : Nh;
+        const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) {
+            g[a][i] = iv[a][i] = 0u;
+            if (EXACT || i < N) {
+                g[a][i] = ldg32(vb + (size_t)(pg + (unsigned)i * psv), lo);
+                iv[a][i] = ldg32(vb + (size_t)(pg + (unsigned)(N + i) * psv), lo);
+            }
+        }
+    }
+}
+
+// ---- S4b: Gray decode, byte-parallel over the 4 pixels of the lane ---------------------------------------------------------------
+// G_i = (gray - inverse >= 0) (4/phase_unwrap.cpp:183) for 4 bytes at once: the low 7 bits are compared by a
+// borrow-protected subtraction, bit 7 decides unless the top bits are equal (one v_bitop3 on x, y, t).
+// B_0 = G_0, B_i = B_{i-1} xor G_i (:187-191) is a running xor of the masks; the code sum B_i 2^(N-1-i) (:193) is
+// accumulated per byte, the LAST 8 planes in `lo`, the ones before them in `hi`, so that the 16-bit code of a pixel
+// is (hi byte, lo byte) and one v_perm per pixel pair builds it: code[a][j] = codes of pixels 2j (low half), 2j+1.
+template <int NMAX>
+__device__ __forceinline__ void decode_gray(const unsigned (&g)[2][NMAX], const unsigned (&iv)[2][NMAX], int Nv, int Nh, unsigned (&code)[2][2])
+{
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int N = a == 0 ? Nv : Nh;
+        const unsigned H = 0x80808080u;
+        unsigned bacc = 0;  // running binary bit of pixel k at bit 8k+7
+        unsigned hi = 0, lo = 0;
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) {
+            if (i < N) {
+                const unsigned x = g[a][i], y = iv[a][i];
+                const unsigned t = (x | H) - (y & ~H);                           // bit 8k+7: (x & 0x7f) >= (y & 0x7f)
+                const unsigned ge = __builtin_amdgcn_bitop3_b32(x, y, t, 0xB2);  // (x & ~y) | (~(x ^ y) & t): byte x >= byte y
+                bacc = __builtin_amdgcn_bitop3_b32(bacc, ge, H, 0x78);           // bacc ^ (ge & H)
+                if (i < N - 8) hi = (hi << 1) | (bacc >> 7);
+                else lo = (lo << 1) | (bacc >> 7);
+            }
+        }
+        code[a][0] = __builtin_amdgcn_perm(hi, lo, 0x05010400u);  // bytes (lo0, hi0, lo1, hi1); selectors 0-3 = lo, 4-7 = hi
+        code[a][1] = __builtin_amdgcn_perm(hi, lo, 0x07030602u);  // bytes (lo2, hi2, lo3, hi3)
+    }
+}
+
+// ---- phase A: stages 3..5 of the lane's 4 pixels ---------------------------------------------------------------------------------
+// The correspondences are parked in the LDS staging area (slots 3k, 3k+1 of pixel k, which its own result overwrites later).
+// Between A and B the plane registers are dead -- that is where a table rig asks for its 4 projector-table entries at once (instead
+// of one dependent gather inside every pixel's chain), and where the pipelined loop requests the next view's planes.
+// `i` (0 or 1, compile-time after inlining) is the pixel's place in the CURRENT pair: the pair loop shifts the fringe dwords, the
+// code words and the valid bits down after each pair, so every operand sits at a fixed byte / half-word (static sub-dword selects
+// instead of shifts by a loop counter); k = 2*pair + i only addresses LDS and the frame.
+template <bool RCP_TAB>
+__device__ __forceinline__ unsigned pixel_A(const KParams &P, const Item &it, int F, int i, int k, unsigned vbits, const unsigned (&f)[2][4],
+                                            const unsigned (&code)[2][2], const double *s_rcp, int *my_cp)
+{
+    const int sh = 8 * i;
+    const int code_v = (int)((code[0][0] >> (16 * i)) & 0xffffu);
+    const int code_h = (int)((code[1][0] >> (16 * i)) & 0xffffu);
+    const AtanK AK = atan_consts<true>();
+    float wv = wrapped_phase<RCP_TAB>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+    float wh = wrapped_phase<RCP_TAB>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+    // stage 4 shifts by +Pi only inside its loop range (4/phase_unwrap.cpp:285,290,304,308); outside it the unwrapped value is 0
+    // whatever the wrapped one is (correspond_px), and the timed mode does not keep wrapped
+    wv = shift_pi(wv);
+    wh = shift_pi(wh);
+    int cx, cy;
+    const bool ok = correspond_px(P, it.gx0 + k, it.gy, wv, wh, code_v, code_h, cx, cy) && ((vbits >> i) & 1u);
+    my_cp[3 * k] = ok ? cx : 0;  // a rejected pixel keeps a harmless table index
+    my_cp[3 * k + 1] = ok ? cy : 0;
+    return ok ? 1u : 0u;
+}
+
+// the 4 pixels of a lane as two pairs: two independent fp64 dependency chains per iteration for the scheduler to interleave
+// (tools/ab.sh: 1 pixel per iteration -3 %, all 4 unrolled +1 % but 12 more VGPRs)
+template <bool RCP_TAB>
+__device__ __forceinline__ unsigned phase_A(const KParams &P, const Item &it, int F, unsigned vbits, unsigned (&f)[2][4], unsigned (&code)[2][2],
+                                            const double *s_rcp, int *my_cp)
+{
+    unsigned vout = 0;
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+        const unsigned ok0 = pixel_A<RCP_TAB>(P, it, F, 0, 2 * j, vbits, f, code, s_rcp, my_cp),
+                       ok1 = pixel_A<RCP_TAB>(P, it, F, 1, 2 * j + 1, vbits, f, code, s_rcp, my_cp);
+        vout = (vout >> 16) | (ok0 << 16) | (ok1 << 24);  // after two pairs: valid byte of pixel k at byte k
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) f[a][p] >>= 16;
+            code[a][0] = code[a][1];
+        }
+        vbits >>= 2;
+    }
+    return vout;
+}
+
+// ---- phase B: stage 7 + the cast of stage 8 ------------------------------------------------------------------------------------
+// neighbouring camera pixels see neighbouring projector pixels: the 4 gathers stay within a few cache lines per wave
+__device__ __forceinline__ void gather_B(const KParams &P, bool proj_table, const int *my_cp, float2 (&d)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[k] = make_float2(0.f, 0.f);
+    if (proj_table) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = P.proj_disp[(size_t)my_cp[3 * k + 1] * (size_t)P.PW + (size_t)my_cp[3 * k]];
+    }
+}
+
+template <int RIG>
+__device__ __forceinline__ void phase_B(const KParams &P, const DevCal *Cglobal, const PinnedRows &PR, bool proj_table, unsigned vout, float2 (&d)[4],
+                                        const double *my_cam, const int *my_cp, float *my_xyz)
+{
+    const float nanv = __builtin_nanf("");
+    unsigned vb = vout;
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int k = 2 * j + i;
+            float x, y, z;
+            triangulate_from<RIG>(P, opaque_const(Cglobal), PR, my_cam[2 * k], my_cam[2 * k + 1], my_cp[3 * k], my_cp[3 * k + 1], d[i], proj_table, x, y, z);
+            const bool ok = ((vb >> (8 * i)) & 1u) != 0u;
+            my_xyz[3 * k + 0] = ok ? x : nanv;
+            my_xyz[3 * k + 1] = ok ? y : nanv;
+            my_xyz[3 * k + 2] = ok ? z : nanv;
+        }
+        d[0] = d[2];
+        d[1] = d[3];
+        vb >>= 16;
+    }
+}
+
+// ---- parity mode (KEEP): the 4 pixels of the lane, one after the other, every stage-boundary plane stored ----------------------------
+template <bool RCP_TAB>
+__device__ __forceinline__ unsigned parity_pixels(const KParams &P, const DevCal *Cglobal, const PinnedRows &PR, const Item &it, int F, unsigned vbits,
+                                                  const unsigned (&f)[2][4], const unsigned (&code)[2][2], const double *s_rcp, const double *my_cam,
+                                                  float *my_xyz, size_t px)
+{
+    unsigned vout = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        if ((vbits >> k) & 1u) {
+            const int sh = 8 * k;
+            const int code_v = (int)((code[0][k >> 1] >> (16 * (k & 1))) & 0xffffu);
+            const int code_h = (int)((code[1][k >> 1] >> (16 * (k & 1))) & 0xffffu);
+            // stage 3: wrapped phase of both axes; stage 4 shifts it by +Pi inside its loop range
+            const AtanK AK = atan_consts<true>();
+            float wv = wrapped_phase<RCP_TAB>(F, (f[0][0] >> sh) & 255, (f[0][1] >> sh) & 255, (f[0][2] >> sh) & 255, (f[0][3] >> sh) & 255, s_rcp, AK);
+            float wh = wrapped_phase<RCP_TAB>(F, (f[1][0] >> sh) & 255, (f[1][1] >> sh) & 255, (f[1][2] >> sh) & 255, (f[1][3] >> sh) & 255, s_rcp, AK);
+            wv = shift_pi_if(wv, it.gx0 + k >= 1 && it.gx0 + k <= P.fullW - 2);  // 4/phase_unwrap.cpp:285,290
+            wh = shift_pi_if(wh, it.gy >= 1 && it.gy <= P.fullH - 2);            // 4/phase_unwrap.cpp:304,308
+            const double cu = my_cam[2 * k], cv = my_cam[2 * k + 1];
+            const PixelResult R = parity_chain(P, opaque_const(Cglobal), PR, it.gx0 + k, it.gy, cu, cv, wv, wh, code_v, code_h, px + k);
+            if (R.valid) {
+                my_xyz[3 * k + 0] = R.x;
+                my_xyz[3 * k + 1] = R.y;
+                my_xyz[3 * k + 2] = R.z;
+                vout |= 1u << (8 * k);
+            }
+        }
+    }
+    return vout;
+}
+
+// the planes the reference initialises before its loops (code = -1: 4/phase_unwrap.cpp:143; everything else the zero a fresh
+// allocation reads as)
+__device__ __forceinline__ void parity_init(const KParams &P, size_t px, unsigned vbits)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        for (int a = 0; a < 2; a++) {
+            P.wrapped[a][px + k] = 0.f;
+            P.unwrapped[a][px + k] = 0.f;
+            P.code[a][px + k] = -1;
+            P.valid_axis[a][px + k] = (vbits >> k) & 1u;
+        }
+        P.cpmap[2 * (px + k)] = 0;
+        P.cpmap[2 * (px + k) + 1] = 0;
+        P.ipoints[3 * (px + k)] = P.ipoints[3 * (px + k) + 1] = P.ipoints[3 * (px + k) + 2] = 0.0;
+    }
+}
+
+// ---- results out ---------------------------------------------------------------------------------------------------------------
+// A wave's LDS instructions execute in order, but the COMPILER knows nothing of that: every hand-off of staged results from the
+// lane that wrote them to another lane of the same wave (store_quad's read-back across lanes, store_segment's in-place
+// compaction and its chunk read-back) is fenced at wavefront scope -- a release fence + a wave barrier: no instruction of their
+// own, they pin the order of the ds_write / ds_read the optimiser may not disambiguate.
+__device__ __forceinline__ void wave_lds_handoff()
+{
+#ifndef SL3D_NO_WAVE_FENCE /* (A/B only, tools/ab.sh: the fences must cost nothing) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// Dense results.  The 48 B of xyz a lane produces are staged in LDS (the rolled pixel loops index them).  A full wave's 64 x 48 B
+// are 3 KB contiguous in LDS AND in the dense plane (quads are consecutive in the pitch-padded layout): the wave reads them back
+// ACROSS lanes and every store instruction writes 1 KiB of whole lines, lane after lane -- and because they are whole lines they
+// carry the non-temporal hint: nothing is left for the L2 to merge, the lines stream out instead of sitting dirty in the L2 until
+// they are evicted or the kernel ends.  Round 3, alternating (profiles/r03_nt_coalesced_ab.txt): 16 views per launch +6...8 %, one
+// view 29.2 -> 27.3 us, other rigs +7 %; each half alone LOSES (coalesced without the hint -2.4 %; the hint on 16-byte pieces
+// -11 %: every piece becomes a memory write of its own).  A wave that is not whole (the last rows of a window) and the parity mode
+// store three 16-B pieces per lane, each lane what it wrote itself.
+template <bool KEEP>
+__device__ __forceinline__ void store_quad(const KParams &P, const float *s_xyz, const float *my_xyz, size_t px, unsigned vout)
+{
+    float4 *out_xyz = (float4 *)(P.points + 3 * px);
+    const float4 *sx = (const float4 *)my_xyz;
+    if (!(SL3D_ABLATE & 4) || KEEP || sx[0].x == 12345.f) {
+        if (!KEEP && __ballot(true) == ~0ull) {
+            wave_lds_handoff();
+            const unsigned lane_ = threadIdx.x & 63u;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 *w4 = (const f32x4 *)(s_xyz + (threadIdx.x >> 6) * (64u * 12u));
+            f32x4 *q4 = (f32x4 *)(P.points + 3 * (px - 4u * lane_));
+            __builtin_nontemporal_store(w4[lane_], q4 + lane_);
+            __builtin_nontemporal_store(w4[64u + lane_], q4 + 64u + lane_);
+            __builtin_nontemporal_store(w4[128u + lane_], q4 + 128u + lane_);
+            __builtin_nontemporal_store(vout, (unsigned *)(P.valid + px));
+            wave_lds_handoff();  // ... and every lane has read them before the next view's phase A reuses the area
+            return;
+        }
+        out_xyz[0] = sx[0];
+        out_xyz[1] = sx[1];
+        out_xyz[2] = sx[2];
+    }
+    *(unsigned *)(P.valid + px) = vout;
+}
+
+__device__ __forceinline__ void fill_nan(float *my_xyz)
+{
+    const float nanv = __builtin_nanf("");
+#pragma unroll
+    for (int i = 0; i < 12; i++) my_xyz[i] = nanv;
+}
+
+// Segmented clouds (CMODE 2; O1 / N2: 8/save_point_cloud.cpp:33-37 counts the valid pixels, :85-104 appends them in row-major scan
+// order) -- no dependency between tiles at all.  A wave owns 256 consecutive pixels of the scan; it ranks ITS valid pixels (4
+// ballots + mbcnt, no block barrier), compacts their points in place inside its own 3 KB of the LDS staging area (every lane first
+// reads its 12 floats, then writes its valid points at their compacted position, which is never above its own) and stores
+// ceil(3*count/4) whole 16-byte chunks, lane after lane (1 KiB per store instruction, non-temporal), into its own fixed slot of
+// the cloud buffer -- points [256*seg, 256*seg + count) with seg = 4*tile + wave -- plus the count.  Scan order is preserved inside
+// a segment and across segments, so the cloud of a view is the concatenation of its segments; k_seg_scan turns the counts into
+// offsets, and the consumers that exist anyway close the gaps (k_seg_close into a contiguous device / mapped host buffer, the
+// registration, the pack before an RCCL send).  Lanes past the last row take part with no valid pixel.
+// (A chunk may run up to 3 floats past the last point: still inside the slot.)
+__device__ __forceinline__ void store_segment(const KParams &P, const Item &it, int view, size_t px, unsigned vout, float *s_xyz, const float *my_xyz)
+{
+    if (it.alive) __builtin_nontemporal_store(vout, (unsigned *)(P.valid + px));
+    const unsigned long long b0 = __ballot((vout & 0x00000001u) != 0u), b1 = __ballot((vout & 0x00000100u) != 0u),
+                             b2 = __ballot((vout & 0x00010000u) != 0u), b3 = __ballot((vout & 0x01000000u) != 0u);
+    auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+    unsigned rank = below(b0) + below(b1) + below(b2) + below(b3);  // valid pixels of the lanes below this one
+    const unsigned total = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+    const unsigned lane_ = threadIdx.x & 63u, wave_ = threadIdx.x >> 6;
+    const unsigned seg = it.tile * 4u + wave_;
+    if (lane_ == 0u) P.seg_counts[(size_t)view * (size_t)P.n_segs + seg] = total;
+    float *slot = P.clouds + 3 * ((size_t)view * P.px_view_stride + (size_t)seg * SL3D_SEG_POINTS);
+    const float4 *sx = (const float4 *)my_xyz;
+    const float4 a = sx[0], b = sx[1], c = sx[2];
+    const float q[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    wave_lds_handoff();  // every lane has read its own 12 floats before any lane overwrites a slot
+    float *wbase = s_xyz + wave_ * (64u * 12u);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if ((vout >> (8 * k)) & 1u) {
+            wbase[3 * rank + 0] = q[3 * k + 0];
+            wbase[3 * rank + 1] = q[3 * k + 1];
+            wbase[3 * rank + 2] = q[3 * k + 2];
+            rank++;
+        }
+    wave_lds_handoff();  // the compacted points are in place before the chunks are read back across lanes
+    const unsigned chunks = (3u * total + 3u) >> 2;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 *wb4 = (const f32x4 *)wbase;
+    f32x4 *out4 = (f32x4 *)slot;
+#pragma unroll
+    for (int c3 = 0; c3 < 3; c3++) {
+        const unsigned i = (unsigned)c3 * 64u + lane_;
+        if (i < chunks) __builtin_nontemporal_store(wb4[i], out4 + i);
+    }
+    wave_lds_handoff();  // ... and read before the next view's phase A parks its correspondences in the same area
+}
+
+// F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
+template <bool KEEP, bool FGEN, bool SEG>
+__device__ __forceinline__ unsigned valid_bits(const Item &it, int F, const MaskQuad &m)
+{
+    if (SEG && !it.alive) return 0u;
+    return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(m);
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------------------------------------
+// KEEP  parity mode: the stage-boundary planes are written too (RIG 0, dense results)
+// NMAX / EXACT  unroll bound of the Gray planes / both axes have exactly NMAX planes
+// FGEN  false: 3-step fringes (the reference's configuration) with the F test folded at compile time
+// RIG   stage 7, see above
+// CMODE 0: dense xyz + valid planes; 2: segmented ordered clouds + the valid plane (sl3d_run_clouds)
+// RCPT  true: 1/d of the atan2 quotient from an LDS table (6 KB per block, 768 IEEE divisions + a block barrier to fill it);
+//       false: the instantiation for SMALL launches (a handful of views: the reference's one scan per call) -- v_rcp_f64 + one
+//       Newton step instead of the table, whose fill nothing amortises when a block lives for one or two views, and the first
+//       view's planes requested before the mask is known (EARLY).  Both quotients are proven equal to the host's libm on the whole
+//       lattice by the device self-check.  Round 3, alternating on one box: 1 view 30.3 against 31.6 us, 2 views -2.7 %, 4 views
+//       -1 %; at 16 views per launch the table is as fast (dense) or 1.4 % faster (clouds) -- profiles/r03_rcp_table_ab*.txt.
+template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE = 0, bool RCPT = true>
+__global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+{
+    constexpr bool SEG = CMODE == 2;
+    static_assert(CMODE == 0 || CMODE == 2, "0 = dense planes, 2 = segmented clouds (1 was round 2's look-back compaction)");
+    static_assert(!(KEEP && CMODE != 0), "the parity mode writes dense planes");
+    static_assert(!(KEEP && RIG != 0), "the parity mode evaluates everything with the reference's operation order");
+    __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];  // staging area: correspondences, then xyz, of the lane's 4 pixels
+    __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
+    __shared__ __attribute__((aligned(16))) double s_rcp[RCPT ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
+    SL3D_STAMP(0);
+    if (RCPT) {
+        fill_rcp_table(s_rcp);
+        __syncthreads();
+    }
+    SL3D_STAMP(1);
+    const int F = FGEN ? P.F : 3;
+    float *my_xyz = s_xyz + threadIdx.x * 12;
+    double *my_cam = s_cam + threadIdx.x * 8;
+    int *my_cp = (int *)my_xyz;
+    // PIPE (timed kernels): the planes of view v+1 are requested in the middle of view v -- after phase A, when the plane
+    // registers of view v are dead, before stage 7 -- so a wave's own arithmetic runs under its own memory requests
+    // (the general rig's stage 7 is too register-hungry for it: 44 bytes of scratch per lane, -9 %)
+    constexpr bool PIPE = !KEEP && RIG != 0;
+    // EARLY (the small-launch instantiation of the pipelined dense kernels): the first view's planes are requested
+    // UNCONDITIONALLY, right behind the item's mask / camera-table requests and before any of those is waited for, at the price of
+    // plane loads for quads that turn out to be masked off (profiles/r03_early_planes_ab.txt)
+    constexpr bool EARLY = !RCPT && CMODE == 0 && PIPE;
+
+    const PinnedRows PR = pinned_rows<RIG>(Cglobal);
+    // EXACT: both axes have exactly NMAX Gray planes (the usual case)
+    const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
+    const bool proj_table = RIG == 2 || (RIG == 0 && !KEEP && P.proj_disp != nullptr);
+
+    Item it;
+    MaskQuad mq;
+    double camt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // EARLY: the lane's camera-table entries between their request and cam_table_finish
+    unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
+    // gridDim.x is a multiple of 8 (launch_fused): consecutive tiles go round-robin over the 8 XCDs on purpose (the XCD-banded
+    // order was measured at -4 %: DRAM locality across XCDs beats L2 locality for 2 % of shared bytes)
+    if (!item_begin<RIG, SEG, EARLY>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
+    if (EARLY) {  // planes of the first view right behind the set-up requests; then the set-up results are consumed
+        issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
+        issue_gray<NMAX, EXACT>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
+        if (P.use_cam_table) cam_table_finish<RIG>(P, Cglobal, it, camt, my_cam);
+    }
+    SL3D_STAMP(2);
+    // The mask dword of the NEXT view is requested a view ahead, so a wave never waits a full memory round trip for it before it
+    // can ask for its 11.5 KB of planes.  (Round 3 read the ISA of this loop: the wait-count pass puts an s_waitcnt vmcnt(0) at the
+    // pipeline point and at the loop latch -- one in-order counter for loads and stores; a schedule without either was built and
+    // measured at +-0.3 %, profiles/r03_mask_early_ab.txt.  The simpler code stays.)
+    unsigned vb_next = 0;
+    if (PIPE) {
+        vb_next = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+        if (it.v_begin + 1 < it.v_end) mq = load_mask_quad(P, it.v_begin + 1, it.cq, it.row);
+        if (!EARLY && vb_next != 0) {  // (EARLY: they are in flight already)
+            issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
+            issue_gray<NMAX, EXACT>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
+        }
+    }
+    for (int view = it.v_begin; view < it.v_end; view++) {
+        unsigned vbits;
+        if (PIPE) {
+            vbits = vb_next;
+        } else {
+            vbits = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+            if (view + 1 < it.v_end) mq = load_mask_quad(P, view + 1, it.cq, it.row);
+        }
+        const size_t px = (size_t)view * P.px_view_stride + (size_t)it.lane_off;  // first pixel of the quad
+        unsigned vout = 0;
+        if (KEEP) parity_init(P, px, vbits);
+        if (!SEG && (KEEP || vbits == 0)) fill_nan(my_xyz);
+        if (!PIPE && vbits != 0) {  // every load of the view is issued before the first one is consumed
+            issue_fringe<FGEN>(P, view, it.lane_off, F, Nv, f);
+            issue_gray<NMAX, EXACT>(P, view, it.lane_off, F, Nv, Nh, g, iv);
+        }
+        if (view == it.v_begin) SL3D_STAMP(3);
+        if (vbits != 0) decode_gray<NMAX>(g, iv, Nv, Nh, code);  // waits for the planes of this view
+        if (view == it.v_begin) SL3D_STAMP(4);
+        if (vbits != 0) {
+            if (KEEP) vout = parity_pixels<RCPT>(P, Cglobal, PR, it, F, vbits, f, code, s_rcp, my_cam, my_xyz, px);
+            else vout = phase_A<RCPT>(P, it, F, vbits, f, code, s_rcp, my_cp);
+        }
+        if (view == it.v_begin) SL3D_STAMP(5);
+        // (Round 3 read the ISA of the table rigs: their 4 projector-table entries are requested BEHIND the next view's 46 plane
+        // loads, so -- vmcnt counts in issue order -- phase B starts only once those planes have landed.  Requesting them first was
+        // built and measured: distorted rig 77.8-78.2 Gpx/s against 79.0-79.5 for this order, profiles/r03_gather_first_ab.txt.)
+        if (PIPE && view + 1 < it.v_end) {
+            vb_next = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+            if (view + 2 < it.v_end) mq = load_mask_quad(P, view + 2, it.cq, it.row);
+            if (vb_next != 0) {
+                issue_fringe<FGEN>(P, view + 1, it.lane_off, F, Nv, f);
+                issue_gray<NMAX, EXACT>(P, view + 1, it.lane_off, F, Nv, Nh, g, iv);
+            }
+        }
+        if (!KEEP && vbits != 0) {
+            float2 d[4];
+            gather_B(P, proj_table, my_cp, d);
+            phase_B<RIG>(P, Cglobal, PR, proj_table, vout, d, my_cam, my_cp, my_xyz);
+        }
+        if (SEG) {
+            store_segment(P, it, view, px, vout, s_xyz, my_xyz);
+            continue;
+        }
+        if (view == it.v_begin) SL3D_STAMP(6);
+        store_quad<KEEP>(P, s_xyz, my_xyz, px, vout);
+        if (view == it.v_begin) SL3D_STAMP(7);
+    }
+}
+
+// ---- launch plumbing -------------------------------------------------------------------------------------------------------------
+// Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT: plane tests fold away) and for
+// the unroll bounds 8 / 12 / 16 otherwise; the parity mode and the 4-/5-step fringes use the bounds only.  Dense 3-step launches
+// of at most SL3D_SMALL_LAUNCH_VIEWS views take the instantiation without the LDS reciprocal table (re-measured with the streaming
+// stores: 8 views 185.6-187.5 us through it against 183.8-184.7, 16 views +-0: stays at 4).
+#define SL3D_SMALL_LAUNCH_VIEWS 4
+struct FusedChoice {
+    int nmax;
+    bool exact, small;
+};
+inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh, int n_views)
+{
+    FusedChoice c;
+    const int m = nv > nh ? nv : nh;
+    c.exact = !keep && !fgen && nv == nh && nv >= 6 && nv <= 12;
+    c.nmax = c.exact ? nv : (m <= 8 ? 8 : (m <= 12 ? 12 : SL3D_MAX_GRAY));
+    c.small = !keep && !fgen && cmode == 0 && n_views <= SL3D_SMALL_LAUNCH_VIEWS;
+    return c;
+}
+
+template <bool KEEP, bool FGEN, int RIG, int CMODE>
+static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
+{
+    const dim3 block(SL3D_BLOCK, 1, 1);
+    const FusedChoice c = choose_fused(KEEP, FGEN, CMODE, nv, nh, n_views);
+    constexpr bool HAS_SMALL = !KEEP && !FGEN && CMODE == 0;  // (the only family that has the second instantiation)
+#define SL3D_LAUNCH(NM, EX)                                                                                                                \
+    do {                                                                                                                                   \
+        if constexpr (HAS_SMALL) {                                                                                                         \
+            if (c.small) {                                                                                                                 \
+                hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE, false>), grid, block, 0, st, P, C, first_view, n_views, vpt);   \
+                break;                                                                                                                     \
+            }                                                                                                                              \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE>), grid, block, 0, st, P, C, first_view, n_views, vpt);                  \
+    } while (0)
+    if constexpr (!KEEP && !FGEN) {
+        if (c.exact) {
+            switch (c.nmax) {
+            case 6: SL3D_LAUNCH(6, true); break;
+            case 7: SL3D_LAUNCH(7, true); break;
+            case 8: SL3D_LAUNCH(8, true); break;
+            case 9: SL3D_LAUNCH(9, true); break;
+            case 10: SL3D_LAUNCH(10, true); break;
+            case 11: SL3D_LAUNCH(11, true); break;
+            default: SL3D_LAUNCH(12, true); break;
+            }
+            return;
+        }
+    }
+    if (c.nmax == 8) SL3D_LAUNCH(8, false);
+    else if (c.nmax == 12) SL3D_LAUNCH(12, false);
+    else SL3D_LAUNCH(SL3D_MAX_GRAY, false);
+#undef SL3D_LAUNCH
+}
+
+// one family of instantiations per translation unit (sl3d_fused_*.hip; they compile in parallel): 3-step timed kernels per rig,
+// dense and segmented; the 4-/5-step timed kernels; the parity mode
+#define SL3D_FUSED_FAMILY_ARGS int nv, int nh, dim3 grid, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt
+void fused_dense_rig0(SL3D_FUSED_FAMILY_ARGS);
+void fused_dense_rig1(SL3D_FUSED_FAMILY_ARGS);
+void fused_dense_rig2(SL3D_FUSED_FAMILY_ARGS);
+void fused_clouds_rig0(SL3D_FUSED_FAMILY_ARGS);
+void fused_clouds_rig1(SL3D_FUSED_FAMILY_ARGS);
+void fused_clouds_rig2(SL3D_FUSED_FAMILY_ARGS);
+void fused_fgen(int rig, int cmode, SL3D_FUSED_FAMILY_ARGS);  // 4-step (and the all-invalid 5-step) fringes: the F test stays a run-time branch
+void fused_parity(bool fgen, SL3D_FUSED_FAMILY_ARGS);
+
+}  // namespace sl3d

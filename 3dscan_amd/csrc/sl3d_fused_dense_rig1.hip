@@ -1,0 +1,6 @@
+// the 3-step timed dense kernels of rig class 1 (sl3d_fused.h): N = 6..12 exact + the unroll bounds 8 / 12 / 16, each with and
+// without the LDS reciprocal table
+#include "sl3d_fused.h"
+namespace sl3d {
+void fused_dense_rig1(SL3D_FUSED_FAMILY_ARGS) { launch_fused_n<false, false, 1, 0>(nv, nh, grid, st, P, C, first_view, n_views, vpt); }
+}  // namespace sl3d

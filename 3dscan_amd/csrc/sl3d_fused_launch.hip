@@ -1,0 +1,80 @@
+// sl3d_fused_launch.hip -- launch_fused: grid shape, views per lane and the choice of the k_fused instantiation.  The
+// instantiations themselves live in the sl3d_fused_*.hip translation units (one family each; sl3d_fused.h).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "sl3d_fused.h"
+
+namespace sl3d {
+
+// number of 1024-pixel tiles (= blocks along x that own pixels) of one view
+int fused_tiles(const KParams &P)
+{
+    const long quads = (long)(P.pitch >> 2) * P.H;
+    return (int)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK);
+}
+
+// views per lane: as many as possible up to SL3D_VPT_MAX (amortises the set-up of a block and the camera table entries) while
+// the grid still has >= ~8 blocks per CU to balance the tail.  (Rounds 1-2: 8.  With the stores streaming past the L2 the
+// optimum moved: 16 views per launch 354.5 us at 4 against 359.6 at 8 and 359.3 at 2, 372.7 at 16; 32 views 700 against 708,
+// profiles/r03_vpt_sweep4.txt; configs[2], 3 views of 12 Mpx: 1 / 2 / 3 views per lane 0.670 / 0.681 / 0.685,
+// profiles/c2_r04_views_vpt_sweep.txt.)
+#define SL3D_VPT_MAX 4
+static int views_per_lane(unsigned bx, int n_views, int cam_table_kind)
+{
+    int vpt = 1;
+    // (a two-double camera table -- tangential terms -- costs a block 16 B/px: those rigs keep 8 views per lane, measured -0.6 % at 4)
+    const int cap = cam_table_kind == 2 ? 8 : SL3D_VPT_MAX;
+    while (vpt < cap && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
+#ifdef SL3D_MEASURE
+    if (getenv("SL3D_VPT") && atoi(getenv("SL3D_VPT")) >= 1) vpt = atoi(getenv("SL3D_VPT"));
+#endif
+    return vpt;
+}
+
+static int timed_rig(const KParams &P, int rig) { return rig == 1 ? 1 : (rig == 2 && P.proj_disp) ? 2 : 0; }
+
+// rig: 0 / 1 / 2 (sl3d_fused.h; the host knows the calibration, the timed kernels fold it at compile time).
+// cmode: 0 = dense xyz + valid planes, 2 = segmented clouds (KParams::clouds / seg_counts must be set).
+// Returns the hipError_t of THIS launch.
+int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream)
+{
+    KParams P = P_;
+    const long quads = (long)(P.pitch >> 2) * P.H;
+    const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: consecutive tiles go round the 8 XCDs
+    const int vpt = views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0);
+    const dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1);
+    // the timed kernels read the camera-side T1 from the per-calibration table whatever the batch is: with 8 views per lane it
+    // costs nothing (1 B/px/view), with 1..4 it saves the iteration (+2..13 %), and a view's result does not depend on the
+    // batch it was launched in
+    P.use_cam_table = P.cam_tab != nullptr ? P.cam_tab_kind : 0;
+#ifdef SL3D_MEASURE
+    if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 0) P.use_cam_table = 0;
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's
+    const int r = timed_rig(P, rig);
+    if (keep) {
+        fused_parity(P.F != 3, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+    } else if (P.F != 3) {
+        fused_fgen(r, cmode, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+    } else if (cmode == 2) {
+        (r == 1 ? fused_clouds_rig1 : r == 2 ? fused_clouds_rig2 : fused_clouds_rig0)(P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+    } else {
+        (r == 1 ? fused_dense_rig1 : r == 2 ? fused_dense_rig2 : fused_dense_rig0)(P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+    }
+    return (int)hipGetLastError();
+}
+
+// the instantiation launch_fused picks for such a launch, spelled as rocprofv3 prints it (bench.py names the kernel its roofline
+// figure is about; derived from the same choose_fused / timed_rig the launch uses, so it cannot go stale)
+int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap)
+{
+    const bool fgen = P.F != 3;
+    const FusedChoice c = choose_fused(keep, fgen, cmode, P.Nv, P.Nh, n_views);
+    auto b = [](bool v) { return v ? "true" : "false"; };
+    return snprintf(buf, cap, "sl3d::k_fused<%s, %d, %s, %s, %d, %d, %s>", b(keep), c.nmax, b(fgen), b(c.exact), keep ? 0 : timed_rig(P, rig), keep ? 0 : cmode,
+                    b(!c.small));
+}
+
+}  // namespace sl3d

@@ -7,11 +7,18 @@
 // root's dense [view][row] planes -- or plain (peer) device copies for stripes that share the root's GPU.  RCCL is bound at
 // run time (dlopen of librccl.so.1: the process may already hold torch's copy of it); a group that has to cross GPUs without
 // it falls back to hipMemcpyPeerAsync, and says so in sl3d_group_transport().
+//
+// What a one-GPU box can and cannot execute of this file (DESIGN.md section 7 has the line-by-line list): with
+// SL3D_FLAG_GROUP_DISTINCT_SIDES every stripe gets its own GpuSide (communication stream + event) although the devices repeat,
+// so every `S.gpu != 0` branch, the peer-copy transport and -- through a test double of librccl selected with SL3D_RCCL_LIB
+// (tests/native/fake_rccl.cpp) -- the N-rank send/recv pairing, the 256-message group split and the variable-size cloud gather
+// run with N > 1 sides.  The real ncclCommInitAll over several devices, xGMI, and contexts on device != 0 stay unexecuted.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -39,9 +46,19 @@ RcclApi &rccl()
     static RcclApi R;
     static std::once_flag once;
     std::call_once(once, [] {
+        // SL3D_RCCL_LIB: another library with the same seven entry points (tests bind a test double that pairs sends with
+        // receives itself, so that the N-rank exchange runs on one GPU); never set in production
+        const char *override_lib = getenv("SL3D_RCCL_LIB");
+        if (override_lib && *override_lib) {
+            R.lib = dlopen(override_lib, RTLD_NOW | RTLD_LOCAL);
+            if (!R.lib) {
+                R.err = std::string("dlopen(SL3D_RCCL_LIB=") + override_lib + "): " + dlerror();
+                return;
+            }
+        }
         for (const char *name : {"librccl.so.1", "librccl.so"}) {
-            R.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (R.lib) break;
+            R.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!R.lib) {
             R.err = std::string("dlopen(librccl.so.1): ") + dlerror();
@@ -66,7 +83,7 @@ RcclApi &rccl()
     return R;
 }
 
-struct GpuSide {  // one per distinct device of the group
+struct GpuSide {  // one per distinct device of the group (one per STRIPE with SL3D_FLAG_GROUP_DISTINCT_SIDES)
     int device = 0;
     hipStream_t comm = nullptr;    // communication stream of this GPU
     hipEvent_t ev_comm = nullptr;  // the last exchange enqueued on it
@@ -85,7 +102,7 @@ struct sl3d_group {
     sl3d_config cfg{};
     std::vector<Stripe> st;
     std::vector<GpuSide> gpus;  // gpus[0] = the root's
-    bool use_rccl = false, force_rccl = false;
+    bool use_rccl = false, force_rccl = false, distinct_sides = false;
     std::string err;
     int pitch = 0;
     size_t px_view_stride = 0;   // pitch * height: elements per view of the assembled planes
@@ -169,6 +186,7 @@ extern "C" int sl3d_group_create(const sl3d_config *cfg, const int *devices, int
     if (g->cfg.full_height == 0) g->cfg.full_height = cfg->height;
     if (g->cfg.max_views <= 0) g->cfg.max_views = 1;
     g->force_rccl = (cfg->flags & SL3D_FLAG_GROUP_FORCE_RCCL) != 0;
+    g->distinct_sides = (cfg->flags & SL3D_FLAG_GROUP_DISTINCT_SIDES) != 0;
     const int base = cfg->height / n, rem = cfg->height % n;
     auto bail = [&](int code, const std::string &msg) {
         sl3d_group_destroy(g);
@@ -181,7 +199,7 @@ extern "C" int sl3d_group_create(const sl3d_config *cfg, const int *devices, int
         s.row0 = i * base + std::min(i, rem);
         s.device = devices[i];
         int gi = -1;
-        for (size_t k = 0; k < g->gpus.size(); k++)
+        for (size_t k = 0; k < g->gpus.size() && !g->distinct_sides; k++)
             if (g->gpus[k].device == s.device) gi = (int)k;
         if (gi < 0) {
             GpuSide u;
@@ -230,6 +248,7 @@ extern "C" int sl3d_group_create(const sl3d_config *cfg, const int *devices, int
         DeviceGuard dg(g->gpus[0].device);
         for (size_t k = 1; k < g->gpus.size(); k++) {
             int can = 0;
+            if (g->gpus[k].device == g->gpus[0].device) continue;  // (distinct sides on one device: nothing to enable)
             if (hipDeviceCanAccessPeer(&can, g->gpus[0].device, g->gpus[k].device) == hipSuccess && can) {
                 const hipError_t e = hipDeviceEnablePeerAccess(g->gpus[k].device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
@@ -502,6 +521,19 @@ extern "C" int sl3d_group_process_views(sl3d_group *g, int n_views, const uint8_
     const size_t ppv = (size_t)g->st[0].ctx->P.planes_per_view, np = (size_t)n_views * ppv;
     for (size_t i = 0; i < np; i++)
         if (!planes[i]) return gfail(g, SL3D_E_INVALID_ARG, "group_process_views: null plane");
+    // the pipelines overwrite result slots [0, min(n_views, max_views)) of every stripe: an asynchronous gather may still be
+    // reading them (sl3d_group_gather / _gather_clouds only mark the views busy) -- an RCCL send on the communication stream of the
+    // stripe's own GPU, a (peer) copy on the root's.  The stripe's stream waits for both, as group_launch does; the enqueue below
+    // then drains that stream before it reuses a slot.
+    const int slots = std::min(n_views, g->cfg.max_views);
+    if (overlaps(g, 0, slots)) {
+        for (size_t s = 0; s < g->st.size(); s++) {
+            Stripe &S = g->st[s];
+            DeviceGuard dg(S.device);
+            GHIP(g, hipStreamWaitEvent(S.ctx->stream, g->gpus[(size_t)S.gpu].ev_comm, 0));
+            if (S.gpu != 0) GHIP(g, hipStreamWaitEvent(S.ctx->stream, g->gpus[0].ev_comm, 0));
+        }
+    }
     int first_rc = SL3D_OK;
     std::string first_err;
     std::vector<const uint8_t *> sub(np);

@@ -11,6 +11,7 @@
 #define SL3D_ATAN_T1 511        // t1 = I0 - I2        in [-255, 255]
 #define SL3D_ATAN_T2 1021       // t2 = 2*I1 - I0 - I2 in [-510, 510]
 #define SL3D_MAX_GRAY 16
+#define SL3D_SEG_POINTS 256     // pixels (point slots) per segment of the segmented clouds = one wave of the fused kernel
 
 namespace sl3d {
 
@@ -61,7 +62,6 @@ struct KParams {
     int F, Nv, Nh;
     int fwv, fwh;
     int ncodes_v, ncodes_h;
-    int stagger;               // measurement builds only (env SL3D_STAGGER): artificial start delay of the first round of blocks, see k_fused
     int ablate;                // measurement builds only (-DSL3D_MEASURE, env SL3D_ABLATE): bit2 skips the camera undistortion; 0 otherwise
     int pitch;                 // bytes per row of every u8 plane (multiple of 16)
     int planes_per_view;
@@ -81,24 +81,16 @@ struct KParams {
     float *points;             // [view][row][pitch][3] f32
     uint8_t *valid;            // [view][row][pitch]    merged valid map
     size_t px_view_stride;     // pitch * H   (elements per view of every per-pixel plane)
-    // compacted clouds written by the fused kernel itself (sl3d_run_clouds; NULL until first used)
-    float *clouds;             // [view][px_view_stride][3]: the valid points of a view in row-major scan order
-    unsigned long long *tile_status;   // [view][n_tiles][SL3D_ST_STRIDE] decoupled look-back words (the first of each group): epoch << 34 | flag << 32 | count
-    unsigned long long *cloud_totals;  // [view] number of valid points -- HOST memory mapped into the device: the last tile of a view stores
-                                       // the count where sl3d_get_cloud_counts reads it after the stream has drained (no copy)
-    int *lookback_flag;        // host-mapped too: set if a look-back gave up waiting (never expected; reported by sl3d_get_cloud_counts)
-    int *lookback_err;         // device: measurement builds (-DSL3D_CX=64) keep their look-back counters at [2..]
-    unsigned epoch;            // launch generation of tile_status (words of older generations read as "not ready")
-    unsigned *ticket;          // work-item counter of the persistent COMPACT kernel (never reset: ticket_base is its value at launch)
-    unsigned ticket_base;
-    int n_cus;                 // compute units of the device (persistent grid of the COMPACT kernel)
+    // ordered clouds written by the fused kernel itself (sl3d_run_clouds; NULL until first used)
+    float *clouds;             // [view][px_view_stride][3]: per view 4*n_tiles segments of SL3D_SEG_POINTS point slots
+    unsigned long long *cloud_totals;  // [view] number of valid points -- HOST memory mapped into the device: k_seg_scan stores the
+                                       // count where sl3d_get_cloud_counts reads it after the stream has drained (no copy)
     int n_tiles;               // 1024-pixel tiles per view = blocks of the fused kernel along x that own pixels
-    // segmented clouds (sl3d_run_clouds, default): `clouds` holds, per view, 4*n_tiles segments of 256 point slots; a segment's
-    // first seg_counts[view][seg] slots are its valid points in scan order
+    // a segment's first seg_counts[view][seg] slots are its valid points in scan order
     unsigned *seg_counts;              // [view][n_segs]
-    unsigned long long *seg_offsets;   // [view][n_segs] exclusive scan of the counts (k_compact_scan)
+    unsigned long long *seg_offsets;   // [view][n_segs] exclusive scan of the counts (k_seg_scan)
     int n_segs;                        // 4 * n_tiles
-    unsigned long long *dbg;   // measurement builds (-DSL3D_CX=128): [view][tile][4] clock stamps of the look-back; NULL otherwise
+    unsigned long long *dbg;   // measurement builds (-DSL3D_TRACE): [block][wave][8] clock stamps of the dense kernel's phases; NULL otherwise
     // stage-boundary planes (NULL unless SL3D_FLAG_KEEP_STAGES)
     float *wrapped[2];
     float *unwrapped[2];
@@ -110,23 +102,17 @@ struct KParams {
     double *ipoints;           // [view][row][pitch][3]
 };
 
-// launchers (sl3d_kernels.hip); `stream` is a hipStream_t
-// tickets_drawn (compact only): host mirror of *KParams::ticket, advanced by what this launch will draw
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int compact, void *stream,
-                 unsigned *tickets_drawn = nullptr);
+// launchers (sl3d_fused_launch.hip, sl3d_kernels.hip); `stream` is a hipStream_t
+// cmode: 0 = dense xyz + valid planes, 2 = segmented clouds
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream);
+// the k_fused instantiation such a launch runs, as rocprofv3 spells it; returns snprintf's value
+int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap);
 // segmented clouds: offsets / totals of views [first_view, first_view + n_views) from the counts the fused kernel stored
 int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream);
 // segments -> contiguous: view first_view+k's points to dst + 3*k*dst_view_stride_points (dst: device memory or mapped host memory)
 int launch_seg_close(const KParams &P, int first_view, int n_views, float *dst, size_t dst_view_stride_points, void *stream);
 // register_point_clouds on segmented input: view first_view+k rotated by R4[4*k..], written at out + 3*(out_base[k] + offset)
 int launch_seg_register(const KParams &P, int view, float *out, const float R4[4], float tx, float ty, float tz, void *stream);
-// 8-byte words between the look-back status words of two neighbouring tiles.  8 = every word in a 64-byte line of its own:
-// neighbouring tiles publish from different XCDs at about the same time, and with the words packed those write-through
-// 8-byte stores (and the polls of them) contend for one line -- measured on the 16 x 1080p batch, three alternating runs:
-// packed 71.0-71.3 Gpx/s kernel-only, 64-byte stride 72.6-73.3, 128-byte 72.6-73.0
-#ifndef SL3D_ST_STRIDE
-#define SL3D_ST_STRIDE 8
-#endif
 int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)
 int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream);  // raw: staged bytes in the layout of one mask plane
 int launch_to_colrow(const KParams &P, int view, int which, void *dst, void *stream);  // a global in the reference's [col][row] layout

@@ -12,8 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SL3D_LIB") or os.path.join(_HERE, "libsl3d.so")
 
 SL3D_FLAG_KEEP_STAGES = 1
-SL3D_FLAG_GROUP_FORCE_RCCL, SL3D_FLAG_GROUP_NO_RCCL = 2, 4
-SL3D_FLAG_CLOUDS_LOOKBACK = 8
+SL3D_FLAG_GROUP_FORCE_RCCL, SL3D_FLAG_GROUP_NO_RCCL, SL3D_FLAG_GROUP_DISTINCT_SIDES = 2, 4, 16
 AXIS_VERTICAL, AXIS_HORIZONTAL = 0, 1
 PATTERN_FRINGE, PATTERN_GRAY, PATTERN_INVERSE_GRAY, PATTERN_BINARY = 0, 1, 2, 3
 VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
@@ -23,7 +22,7 @@ ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
     "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_mask_colrow", "sl3d_set_frames_range", "sl3d_get_global_colrow", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
-    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
+    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
     "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
@@ -103,6 +102,7 @@ def load_library(path=None):
     L.sl3d_download_clouds.argtypes = [vp, i, i, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_register_clouds.argtypes = [vp, i, i, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_run_timed.argtypes = [vp, i, i, C.POINTER(C.c_float)]
+    L.sl3d_fused_kernel_name.argtypes = [vp, i, i, C.c_char_p, C.c_size_t]
     L.sl3d_synchronize.argtypes = [vp]
     L.sl3d_timer_start.argtypes = [vp]
     L.sl3d_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -174,12 +174,12 @@ class Scanner:
 
     def __init__(self, width, height, proj_width, proj_height, n_gray_v, n_gray_h, fringe_width_v, fringe_width_h,
                  n_fringe=3, n_codes_v=0, n_codes_h=0, max_views=1, device=0, keep_stages=False,
-                 full_size=None, origin=(0, 0), stream=None, clouds_lookback=False):
+                 full_size=None, origin=(0, 0), stream=None):
         self.L = load_library()
         fw, fh = full_size if full_size else (width, height)
         self.cfg = Config(width, height, fw, fh, origin[0], origin[1], proj_width, proj_height, n_fringe,
                           n_gray_v, n_gray_h, fringe_width_v, fringe_width_h, n_codes_v, n_codes_h,
-                          max_views, device, (SL3D_FLAG_KEEP_STAGES if keep_stages else 0) | (SL3D_FLAG_CLOUDS_LOOKBACK if clouds_lookback else 0), stream)
+                          max_views, device, SL3D_FLAG_KEEP_STAGES if keep_stages else 0, stream)
         self.W, self.H = width, height
         self._h = C.c_void_p()
         rc = self.L.sl3d_create(C.byref(self.cfg), C.byref(self._h))
@@ -365,6 +365,12 @@ class Scanner:
     def _d2h(self, arr, dev_ptr):
         """Device -> host copy of an address the library handed out (sl3d_download)."""
         self._chk(self.L.sl3d_download(self._h, arr.ctypes.data, dev_ptr, arr.nbytes), "sl3d_download")
+
+    def fused_kernel_name(self, n_views=1, clouds=False):
+        """The k_fused instantiation a launch over n_views views runs, as rocprofv3 prints it."""
+        buf = C.create_string_buffer(256)
+        self._chk(self.L.sl3d_fused_kernel_name(self._h, n_views, 1 if clouds else 0, buf, len(buf)), "sl3d_fused_kernel_name")
+        return buf.value.decode()
 
     def run_timed(self, first_view=0, n_views=1):
         ms = C.c_float(0)

@@ -245,9 +245,9 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
         alg = 20 + 4 * N
         # what this launch really moves: the camera-side table (8 B/px for the radial model of the reference rig, 16 with tangential
         # terms) is read once per LAUNCH, and nothing amortises it when a launch is one view
-        tab = sc.cam_table_bytes_per_pixel() if hasattr(sc, "cam_table_bytes_per_pixel") else 8
+        tab = 8 if args.rig == "reference" else 16
         moved = alg + tab
-        return {"value": round(W * H / ms / 1e3, 1), "unit": "Mpixels/s", "launch_us": round(ms * 1e3, 2),
+        return {"value": round(W * H / ms / 1e3, 1), "unit": "Mpixels/s", "launch_us": round(ms * 1e3, 2), "kernel": sc.fused_kernel_name(1, clouds=clouds),
                 "frac": round(alg * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": alg,
                 "frac_on_moved_bytes": round(moved * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "moved_bytes_per_pixel": moved,
                 "resident_views": V, "launches": launches,
@@ -280,11 +280,6 @@ def side_figures(args, scm, syn, np, dev_index):
                                                       "not an HBM figure (round 3 reported it as one_view_latency); one_view_cold is"}
         out["one_view_cold"] = one_view_cold(args, scm, syn, np, dev_index)
         out["one_view_cold_clouds"] = one_view_cold(args, scm, syn, np, dev_index, launches=1000, clouds=True)
-        # the other way to ordered clouds, same workload, same box: contiguous clouds in one pass by a decoupled look-back
-        # (SL3D_FLAG_CLOUDS_LOOKBACK); `to_compacted_clouds` above is the segmented default
-        with ctx("reference", N, args.views, clouds_lookback=True) as sc:
-            v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 300, clouds=True)
-            out["clouds_lookback_kernel_only"] = {"value": v, "unit": "Mpixels/s", "ms_per_launch": ms}
         # (distorted: projector k1,k2,p1,p2 + camera tangential terms; general: a skewed camera matrix as well -- since round 3 both
         # take the pipelined table kernel, RIG 2; the un-pipelined general kernel is left with perspective rows in K)
         for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig2_general_skewed_camera")):
@@ -451,11 +446,8 @@ def main():
     launch_s = ev_ms / 1e3 / args.steps
     achieved = alg_bytes_px * px_per_launch / launch_s / 1e9
 
-    exact = 6 <= N <= 12                                   # the instantiation launch_fused picks (sl3d_kernels.hip)
-    nmax = N if exact else next(m for m in (8, 12, 16) if m >= N)
-    rig_id = {"reference": 1, "distorted": 2, "general": 0}[args.rig]
-    small = n_views <= 4                                    # SL3D_SMALL_LAUNCH_VIEWS: the instantiation without the LDS reciprocal table
-    kernel_name = f"sl3d::k_fused<false, {nmax}, false, {'true' if exact else 'false'}, {rig_id}, 0, {'false' if small else 'true'}>"
+    kernel_name = sc.fused_kernel_name(n_views)            # the instantiation this launch ran, from the library's own dispatch rules
+    kernel_name_clouds = sc.fused_kernel_name(n_views, clouds=True)
     traffic, traffic_src = measured_traffic(px_per_launch) if alg_bytes_px == 60 else (None, None)
 
     out = {
@@ -531,7 +523,7 @@ def main():
                                       "roofline": {"bound": "hbm", "achieved": round(cl_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                    "frac": round(cl_achieved / HBM_PEAK_GBS, 4), "traffic": cl_traffic,
                                                    "traffic_source": cl_traffic_src and f"{cl_traffic_src} (committed PMC run of this command, scaled to this launch; not measured in this run)",
-                                                   "kernel": kernel_name.rsplit(", 0, ", 1)[0] + ", 2, true>", "launches": "the fused kernel + k_seg_scan (both between the HIP events)",
+                                                   "kernel": kernel_name_clouds, "launches": "the fused kernel + k_seg_scan (both between the HIP events)",
                                                    "avg_launch_ms": round(kms, 4)},
                                       "how": "sl3d_run_clouds: the fused kernel writes SEGMENTED ordered clouds (every wave compacts its 256 scan pixels into its own "
                                              "slot: no tile waits for another) + one scan launch for offsets and totals; value = launches + the wait for the "

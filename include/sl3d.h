@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL3D_VERSION_STRING "0.3.0"
+#define SL3D_VERSION_STRING "0.4.0"
 
 typedef struct sl3d_ctx sl3d_ctx;
 
@@ -61,10 +61,14 @@ enum sl3d_flags {
      * root's GPU (exercises the RCCL path on a single-GPU box); NO_RCCL: (peer) device copies even across GPUs. */
     SL3D_FLAG_GROUP_FORCE_RCCL = 2u,
     SL3D_FLAG_GROUP_NO_RCCL = 4u,
-    /* sl3d_run_clouds writes every view's cloud CONTIGUOUSLY in one pass (tile prefixes by a decoupled look-back between the
-     * blocks of the launch: ordered, but every tile waits for its predecessors) instead of the default SEGMENTED clouds (no
-     * waiting; see sl3d_run_clouds).  Pays when the only consumer is a device kernel that needs one contiguous array. */
-    SL3D_FLAG_CLOUDS_LOOKBACK = 8u
+    /* sl3d_group_create only, for tests on a box with fewer GPUs than stripes: every stripe gets its own communication side
+     * (stream, event, communicator rank) even where devices repeat, so that the code paths of a stripe on ANOTHER GPU than the
+     * root's -- peer copies, the waits between the sides' streams, an N-rank exchange -- run with all stripes on one device.
+     * With RCCL this needs a communicator that accepts repeated devices (the test double bound through SL3D_RCCL_LIB). */
+    SL3D_FLAG_GROUP_DISTINCT_SIDES = 16u
+    /* (8u was SL3D_FLAG_CLOUDS_LOOKBACK until 0.3: contiguous clouds in one pass by a decoupled look-back between tiles.  Removed
+     * in 0.4 -- every tile waited for its predecessors, 0.53 of the roofline against 0.67 for the segmented clouds; a consumer
+     * that wants one contiguous device array asks sl3d_get_cloud_counts for it.) */
 };
 
 /* Replaces the compile-time macros and initialised globals of the reference:
@@ -195,21 +199,20 @@ int sl3d_run(sl3d_ctx *ctx, int first_view, int n_views);
  * view's valid points are written once, compacted in the reference's row-major scan order, plus the valid map:
  * ~47 + 12*valid_fraction + 1 bytes per pixel instead of 60 for the dense pass + 25 for a separate compaction.  Timed mode only
  * (no SL3D_FLAG_KEEP_STAGES).  Asynchronous.
- *   Default: SEGMENTED clouds.  Every wave of the kernel compacts the 256 consecutive scan pixels it owns into its own fixed slot
+ *   SEGMENTED clouds.  Every wave of the kernel compacts the 256 consecutive scan pixels it owns into its own fixed slot
  *   (points [256*s, 256*s + count_s) of the view's region) and stores count_s; a small scan kernel turns the counts into offsets.
  *   No tile ever waits for another one, scan order is preserved inside and across segments, so a view's cloud is the
  *   concatenation of its segments -- and the consumers that exist anyway close the gaps for free: sl3d_download_clouds (host
  *   copy), sl3d_register_clouds (turntable registration), the pack before a group's RCCL send, or any device consumer through
  *   sl3d_get_cloud_segments.
- *   With SL3D_FLAG_CLOUDS_LOOKBACK: contiguous clouds in the same single pass (decoupled look-back between tiles).
  * sl3d_get_cloud_counts synchronises and returns, for views [first_view, first_view+n_views), the number of points of each
  * cloud; with device_xyz != NULL also a CONTIGUOUS device copy: view first_view+k's cloud is counts[k] points (3 floats each) at
- * *device_xyz + 3*k*(*view_stride_points), valid until the next sl3d_run_clouds / sl3d_compact_views on this context (segmented
- * mode: produced on demand by one gap-closing launch; pass NULL if only the counts are wanted). */
+ * *device_xyz + 3*k*(*view_stride_points), valid until the next sl3d_run_clouds / sl3d_compact_views on this context (produced
+ * on demand by one gap-closing launch; pass NULL if only the counts are wanted). */
 int sl3d_run_clouds(sl3d_ctx *ctx, int first_view, int n_views);
 int sl3d_get_cloud_counts(sl3d_ctx *ctx, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts);
 
-/* The segmented clouds themselves, for consumers that stay on the device (not available with SL3D_FLAG_CLOUDS_LOOKBACK):
+/* The segmented clouds themselves, for consumers that stay on the device:
  * segment s of view first_view+k holds counts[k*view_stride_segments + s] points at xyz + 3*(k*view_stride_points +
  * s*segment_points); its first point is point number offsets[k*view_stride_segments + s] of the view's cloud. */
 typedef struct sl3d_cloud_segments {
@@ -225,14 +228,18 @@ int sl3d_get_cloud_segments(sl3d_ctx *ctx, int first_view, int n_views, sl3d_clo
 
 /* The reference's consumer is the host (8/save_point_cloud.cpp:85-104 fills a host pcl::PointCloud): the clouds of views
  * [first_view, first_view+n_views) of the last sl3d_run_clouds, back to back in host memory (at most `capacity` points in all;
- * xyz may be NULL: counts only).  Segmented mode + pinned memory (sl3d_host_alloc): the gap-closing kernel writes the host
- * buffer directly; otherwise a contiguous device copy is downloaded.  Synchronises. */
+ * xyz may be NULL: counts only).  Pinned memory (sl3d_host_alloc): the gap-closing kernel writes the host buffer directly;
+ * otherwise a contiguous device copy is downloaded.  Synchronises. */
 int sl3d_download_clouds(sl3d_ctx *ctx, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts);
 
 /* sl3d_register_views on the clouds of the last sl3d_run_clouds (no dense planes, no separate compaction): the rotation of
  * 9/register_point_clouds.cpp:83-128 is applied while the segments are concatenated. */
 int sl3d_register_clouds(sl3d_ctx *ctx, int first_view, int n_views, float tx, float ty, float tz, float rot_step, float *xyz, int64_t capacity,
                          int64_t *total);
+/* Name of the fused-kernel instantiation sl3d_run (clouds = 0) / sl3d_run_clouds (clouds = 1) launches for a batch of n_views views
+ * with this context's configuration and calibration, spelled as rocprofv3 --kernel-trace prints it: benchmarks name the kernel
+ * their roofline figure is about without restating the library's dispatch rules. */
+int sl3d_fused_kernel_name(sl3d_ctx *ctx, int n_views, int clouds, char *buf, size_t capacity);
 /* sl3d_run bracketed by HIP events on the context's stream; returns the kernel time of this launch */
 int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);
 int sl3d_synchronize(sl3d_ctx *ctx);

@@ -29,11 +29,9 @@ def _random_mask(rng, W, H, holes=6):
 # ---- ordered compaction inside the fused kernel ------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(640, 200, 8, 8, 4), (333, 77, 9, 9, 4), (200, 120, 6, 5, 16), (1021, 64, 7, 7, 4), (64, 3, 6, 6, 8)])
 @pytest.mark.parametrize("dist_proj", [False, True])
-@pytest.mark.parametrize("lookback", [False, True])
-def test_fused_compaction_equals_dense(shape, dist_proj, lookback):
-    """sl3d_run_clouds -- segmented clouds (default) and the single-pass look-back (SL3D_FLAG_CLOUDS_LOOKBACK): the cloud of every
-    view equals xyz[valid] of the dense pass (8/save_point_cloud.cpp:85-104 order), the valid map is the same, and repeated
-    launches reuse the look-back words correctly (launch generations)."""
+def test_fused_compaction_equals_dense(shape, dist_proj):
+    """sl3d_run_clouds (segmented ordered clouds written by the fused kernel itself): the cloud of every view equals xyz[valid]
+    of the dense pass (8/save_point_cloud.cpp:85-104 order), the valid map is the same, repeated launches and sub-ranges too."""
     S, syn = _S(), pkg("synth")
     W, H, Nv, Nh, fw = shape
     PW, PH, NV = 512, 384, 5
@@ -42,7 +40,7 @@ def test_fused_compaction_equals_dense(shape, dist_proj, lookback):
     cal = {k: np.array(v, dtype=np.float64).copy() for k, v in caps[0]["cal"].items()}
     if dist_proj:
         cal["dp"] = np.array([0.04, -0.01, 0.001, -0.0005, 0.0])
-    with S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=NV, clouds_lookback=lookback) as sc:
+    with S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=NV) as sc:
         sc.set_calibration(*syn.cal_tuple(cal))
         for v, c in enumerate(caps):
             sc.set_mask(_random_mask(rng, W, H) if v else c["mask"], view=v)
@@ -64,15 +62,16 @@ def test_fused_compaction_equals_dense(shape, dist_proj, lookback):
             assert np.array_equal(sc.cloud(v), dense[v][0][dense[v][1] == 1])
 
 
-@pytest.mark.parametrize("lookback", [False, True])
-def test_fused_compaction_full_hd_batch(lookback):
-    """BASELINE configs[1] shape: 16 views of 1920x1080 in one launch (8100 tiles per view, 8 views per lane): every
-    cloud equals xyz[valid]; a sparse mask and an empty mask included."""
+def test_fused_compaction_full_hd_batch():
+    """BASELINE configs[1] shape: 16 views of 1920x1080 in one launch (2025 tiles per view, 4 views per lane): every
+    cloud equals xyz[valid]; a sparse mask and an empty mask included.  The dense planes AND the clouds of the segmented kernel
+    (k_fused<..., CMODE = 2>) are compared DIRECTLY with the oracle: valid map / point count bit exact, the cloud against the
+    oracle's own row-major append (8/save_point_cloud.cpp:85-104) point by point within 1e-5."""
     S, syn = _S(), pkg("synth")
     W, H, N, fw, NV = 1920, 1080, 10, 2, 16
     cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
     rng = np.random.default_rng(5)
-    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV, clouds_lookback=lookback) as sc:
+    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV) as sc:
         sc.set_calibration(*cal)
         for v in range(NV):
             m = syn.default_mask(W, H)
@@ -107,6 +106,11 @@ def test_fused_compaction_full_hd_batch(lookback):
             oxyz, ovalid, _ = o.run_scan_rowmajor(sc.frames(0, v), sc.frames(1, v))
             assert np.array_equal(dense[v][1], ovalid), v
             assert_points_close(dense[v][0], oxyz, ovalid == 1)
+            # the cloud the compacting instantiation wrote, against the oracle's append in scan order (not against the dense pass)
+            ocloud = oxyz[ovalid == 1]
+            assert clouds[v].shape == ocloud.shape, v
+            if len(ocloud):
+                assert_points_close(clouds[v], ocloud, np.ones(len(ocloud), bool))
 
 
 # ---- mask preparation on the device -------------------------------------------------------------------------------------

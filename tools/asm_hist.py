@@ -10,7 +10,7 @@ import re
 import sys
 
 sub = sys.argv[1] if len(sys.argv) > 1 else "k_fusedILb0ELi10ELb0ELb1ELi1"
-path = sys.argv[2] if len(sys.argv) > 2 else "/tmp/sl3d_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"
+path = sys.argv[2] if len(sys.argv) > 2 else "/tmp/sl3d_asm/sl3d_fused_dense_rig1-hip-amdgcn-amd-amdhsa-gfx950.s"
 s = open(path).read()
 m = re.search(r"^(_ZN4sl3d[^\n]*%s[^\n:]*):[^\n]*\n(.*?)\n\s*s_endpgm" % re.escape(sub), s, re.S | re.M)
 if not m:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-instantiation register / LDS / occupancy table of k_fused from `hipcc -Rpass-analysis=kernel-resource-usage` output.
-    hipcc <flags> -Rpass-analysis=kernel-resource-usage -c sl3d_kernels.hip -o /dev/null 2> res.txt; tools/kres.py res.txt [N ...]"""
+    make -C 3dscan_amd/csrc resources TU=sl3d_fused_dense_rig1 2> res.txt; tools/kres.py res.txt [N ...]"""
 import re
 import sys
 
@@ -17,5 +17,5 @@ for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
 
     def g(k):
         return re.search(k + r": (\d+)", b).group(1)
-    print(f"KEEP={keep} N={nmax} EXACT={exact} RIG={rig} COMPACT={comp} RCPT={rcpt}: VGPR {g('VGPRs')} SGPR {g('SGPRs')} "
+    print(f"KEEP={keep} N={nmax} EXACT={exact} RIG={rig} CMODE={comp} RCPT={rcpt}: VGPR {g('VGPRs')} SGPR {g('SGPRs')} "
           f"scratch {g('ScratchSize .bytes/lane.')} occ {g('Occupancy .waves/SIMD.')} LDS {g('LDS Size .bytes/block.')}")

@@ -48,11 +48,19 @@ def dense_name():
 
 dense = dense_name()
 bench = counters("bench", dense)
-stem = dense.rsplit(", 0, ", 1)[0]   # template arguments: ..., CMODE, RCPT
-compact = counters("bench", stem + ", 2, true>")
-lookback = counters("bench", stem + ", 1, true>")
-out = {"kernel": "sl3d::" + dense, "per_dispatch_mean": bench, "compacting_kernel_per_dispatch_mean": compact,
-       "lookback_kernel_per_dispatch_mean": lookback}
+
+
+def clouds_name():
+    try:
+        return json.loads(open(f"{src}/stats_bench.json").read())["to_compacted_clouds"]["roofline"]["kernel"].replace("sl3d::", "")
+    except Exception:
+        return dense.rsplit(", 0, ", 1)[0] + ", 2, true>"
+
+
+compact_kernel = clouds_name()
+compact = counters("bench", compact_kernel)
+out = {"kernel": "sl3d::" + dense, "per_dispatch_mean": bench, "compacting_kernel": "sl3d::" + compact_kernel,
+       "compacting_kernel_per_dispatch_mean": compact}
 # 2. calibration of FETCH_SIZE / WRITE_SIZE on tools/membench mode 0 (one dword per lane per plane, 47 planes;
 #    three 16-B stores + one dword per lane): the same access widths as the fused kernel, with KNOWN byte counts.
 mem = counters("membench", "k_dword")
@@ -90,7 +98,7 @@ if "FETCH_SIZE" in mem and "WRITE_SIZE" in mem:
                 cbpp = bl["to_compacted_clouds"]["algorithmic_bytes_per_pixel"]
             except Exception:
                 pass
-            tc = {"kernel": "sl3d::" + stem + ", 2, true>", "pixels_per_launch": px_launch, "hbm_read_bytes_per_launch": rdc,
+            tc = {"kernel": "sl3d::" + compact_kernel, "pixels_per_launch": px_launch, "hbm_read_bytes_per_launch": rdc,
                   "hbm_write_bytes_per_launch": wrc, "hbm_bytes_per_launch": rdc + wrc,
                   "algorithmic_bytes_per_pixel": cbpp, "algorithmic_bytes_per_launch": cbpp * px_launch if cbpp else None,
                   "ratio_to_algorithmic": (rdc + wrc) / (cbpp * px_launch) if cbpp else None, "method": traffic["method"],
