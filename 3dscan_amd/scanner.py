@@ -102,7 +102,11 @@ def load_library(path=None):
     L.sl3d_download_clouds.argtypes = [vp, i, i, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_register_clouds.argtypes = [vp, i, i, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sl3d_run_timed.argtypes = [vp, i, i, C.POINTER(C.c_float)]
-    L.sl3d_fused_kernel_name.argtypes = [vp, i, i, C.c_char_p, C.c_size_t]
+    try:
+        L.sl3d_fused_kernel_name.argtypes = [vp, i, i, C.c_char_p, C.c_size_t]
+    except AttributeError:   # an older build of the library under SL3D_LIB (A/B runs against a previous round): the name is cosmetic
+        if not os.environ.get("SL3D_LIB"):
+            raise
     L.sl3d_synchronize.argtypes = [vp]
     L.sl3d_timer_start.argtypes = [vp]
     L.sl3d_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -368,6 +372,8 @@ class Scanner:
 
     def fused_kernel_name(self, n_views=1, clouds=False):
         """The k_fused instantiation a launch over n_views views runs, as rocprofv3 prints it."""
+        if os.environ.get("SL3D_LIB") and not hasattr(self.L, "sl3d_fused_kernel_name"):
+            return "(a build without sl3d_fused_kernel_name)"
         buf = C.create_string_buffer(256)
         self._chk(self.L.sl3d_fused_kernel_name(self._h, n_views, 1 if clouds else 0, buf, len(buf)), "sl3d_fused_kernel_name")
         return buf.value.decode()
