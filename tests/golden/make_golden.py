@@ -232,6 +232,14 @@ def main():
         "_source": "Triangulation/Relative_geometry/proj_cam_rot_mat.xml + proj_cam_trans_vect.xml, written by "
                    "6/system_calibration.cpp:1488-1516 (cvRodrigues2 x2, cvTranspose, cvMatMul x2, cvSub) from the same rc/rp/tc/tp "
                    "7/triangulation.cpp:1069-1083 reads: the reference-held known answer for T0"}
+    # the reference's OTHER projector calibrations: two OpenCV calibrations of the projectors it was used with, both strongly
+    # distorted (k1 = -1.01 / -1.16, k2 = 8.28 / 2.60) -- stage 7 reads whatever proj_intrinsic_mat.xml / proj_distortion_vect.xml
+    # hold (7/triangulation.cpp:152-168), so these are inputs the path really meets (tests/test_gpu_round4.py: table rig)
+    cal["_alt_projectors"] = {
+        name: {"Kp": xml_data(f"Projector_calibration/Matrices/OPencv calib/{name}/Projector_intrinsic_mat.xml"),
+               "dp": xml_data(f"Projector_calibration/Matrices/OPencv calib/{name}/Projector_dist_vect.xml")}
+        for name in ("Sharp", "Viewsonic")}
+    cal["_alt_projectors"]["_source"] = "Projector_calibration/Matrices/OPencv calib/{Sharp,Viewsonic}/Projector_{intrinsic_mat,dist_vect}.xml"
     with open(os.path.join(HERE, "calibration.json"), "w") as f:
         json.dump(cal, f, indent=1)
 
