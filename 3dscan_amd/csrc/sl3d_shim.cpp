@@ -3,14 +3,18 @@
 // See include/sl3d_shim.h.  Plain C++ (no HIP here); links against libsl3d.so.
 #include "../../include/sl3d_shim.h"
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <charconv>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <sched.h>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/sl3d.h"
@@ -42,6 +46,8 @@ struct Shim {
     std::map<std::string, MemImage> images;
     std::map<std::string, std::vector<double>> matrices;
     std::vector<uint8_t> default_mask;  // 1 inside the border, built once
+    uint8_t *staging = nullptr;         // pinned: the decoded planes of one stage call, back to back (file inputs)
+    size_t staging_planes = 0;
     int status = SL3D_OK;
     std::string err;
     // the configuration the context was created with (the scalar globals may change between scans)
@@ -53,6 +59,45 @@ std::string data_root()
     if (g.root_set) return g.root;
     const char *e = getenv("SL3D_DATA_ROOT");
     return e ? std::string(e) : std::string(kReferenceRoot);
+}
+
+// host threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a container may see 256 cores
+// and be granted 16) and by 32
+int usable_threads()
+{
+    static int n = [] {
+        int k = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) k = CPU_COUNT(&set);
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) k = std::min<long>(k, std::max<long>(1, atol(q) / period));
+            fclose(f);
+        }
+        if (const char *e = getenv("SL3D_SHIM_THREADS")) k = atoi(e);
+        return std::max(1, std::min(k, 32));
+    }();
+    return n;
+}
+
+// fn(i) for i in [0, n) on up to usable_threads() threads (work items are handed out one by one); the calling thread takes part
+template <typename Fn>
+void parallel_for(int n, Fn fn)
+{
+    const int t = std::min(n, usable_threads());
+    if (t <= 1) {
+        for (int i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto work = [&] {
+        for (int i; (i = next.fetch_add(1)) < n;) fn(i);
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < t; k++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
 }
 
 bool fail(int code, const std::string &msg)
@@ -74,7 +119,8 @@ bool ok(int rc, const char *what)
 // with OpenCV's fixed-point weights (B 1868, G 9617, R 4899, >> 14).
 inline uint8_t bgr2gray(int b, int gch, int r) { return (uint8_t)((b * 1868 + gch * 9617 + r * 4899 + (1 << 13)) >> 14); }
 
-bool read_bmp_gray(const std::string &path, std::vector<uint8_t> &out)
+// out: W * H bytes, top-down rows of W bytes
+bool read_bmp_gray(const std::string &path, uint8_t *out)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -102,14 +148,13 @@ bool read_bmp_gray(const std::string &path, std::vector<uint8_t> &out)
     bool identity = bpp == 8;  // the grey ramp cvSaveImage writes for a 1-channel image: rows are copied, not looked up
     for (int i = 0; i < 256 && identity; i++) identity = pal[i] == (uint8_t)i;
     std::vector<uint8_t> file(rowbytes * (size_t)H);  // one read for the whole pixel array
-    out.resize((size_t)W * H);
     fseek(f, data_off, SEEK_SET);
     if (fread(file.data(), 1, file.size(), f) != file.size()) { fclose(f); return false; }
     fclose(f);
     for (int i = 0; i < H; i++) {
         const uint8_t *row = file.data() + (size_t)i * rowbytes;
         const int y = hgt > 0 ? H - 1 - i : i;  // bottom-up unless the height is negative
-        uint8_t *dst = out.data() + (size_t)y * W;
+        uint8_t *dst = out + (size_t)y * W;
         if (identity) memcpy(dst, row, (size_t)W);
         else if (bpp == 8)
             for (int x = 0; x < W; x++) dst[x] = pal[row[x]];
@@ -183,11 +228,11 @@ bool write_bmp_gray(const std::string &path, const uint8_t *img, int w = W, int 
 // The ASCII cloud rows the reference's PCL writers produce are built in memory and written with one fwrite: std::to_chars with
 // chars_format::general and precision 9 yields the digits of printf("%.9g") (the C++17 contract), several times faster than a
 // fprintf per point.  `cols`: 1 = one packed 0x00RRGGBB integer (PCD), 3 = red green blue (PLY).
-void append_cloud_ascii(std::string &out, const float *xyz, const uint8_t *rgb, int64_t n, int cols)
+void append_cloud_ascii(std::string &out, const float *xyz, const uint8_t *rgb, int64_t first, int64_t n, int cols)
 {
     out.reserve(out.size() + (size_t)n * 48);
     char buf[64];
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t i = first; i < first + n; i++) {
         for (int k = 0; k < 3; k++) {
             const auto r = std::to_chars(buf, buf + sizeof buf, xyz[3 * i + k], std::chars_format::general, 9);
             out.append(buf, r.ptr);
@@ -208,33 +253,73 @@ void append_cloud_ascii(std::string &out, const float *xyz, const uint8_t *rgb, 
     }
 }
 
+// The rows of a whole cloud: disjoint point ranges are formatted on all host threads into their own buffers (the conversion is
+// what costs: 99 % of a relinked scan's wall time was this loop on one thread) and written in order, one fwrite per buffer --
+// the file is byte for byte what the single loop writes.
+bool write_cloud_ascii(FILE *f, const float *xyz, const uint8_t *rgb, int64_t n, int cols)
+{
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>((n + 16383) / 16384, 4 * usable_threads()));
+    std::vector<std::string> rows((size_t)parts);
+    parallel_for(parts, [&](int k) {
+        const int64_t a = n * k / parts, b = n * (k + 1) / parts;
+        append_cloud_ascii(rows[(size_t)k], xyz, rgb, a, b - a, cols);
+    });
+    for (const auto &r : rows)
+        if (fwrite(r.data(), 1, r.size(), f) != r.size()) return false;
+    return true;
+}
+
 // One input frame: the caller's memory (sl3d_shim_provide_image under one of the names; no copy) or the first readable file of
 // the given names below the data root, decoded into `storage`.
 struct Frame {
     const uint8_t *data = nullptr;
     size_t stride = 0;
-    std::vector<uint8_t> storage;
 };
 
-bool load_frame(const std::vector<std::string> &names, Frame &f)
+// The input frames of one stage call.  names[i] lists the file names frame i may have (the reference's own and the captured-image
+// variant).  A frame provided in memory is used where it lies; all others are decoded from their BMP files ON ALL HOST THREADS AT
+// ONCE into one pinned staging area, back to back -- so the files cost one decode time instead of their sum, and the planes go up
+// as ONE asynchronous 2-D copy (sl3d_set_frames_range takes back-to-back pinned planes as such).  The staging area is reused by
+// the next stage call: every stage function ends with a synchronising getter, so the copy has long finished.
+bool load_frames(const std::vector<std::vector<std::string>> &names, std::vector<Frame> &out)
 {
-    for (const auto &n : names) {
-        auto it = g.images.find(n);
-        if (it != g.images.end()) {
+    const size_t n = names.size();
+    out.assign(n, Frame());
+    std::vector<int> from_file;
+    for (size_t i = 0; i < n; i++) {
+        for (const auto &nm : names[i]) {
+            auto it = g.images.find(nm);
+            if (it == g.images.end()) continue;
             const Shim::MemImage &m = it->second;
-            if (m.width != W || m.height != H || m.channels != 1) return fail(SL3D_E_INVALID_ARG, "provided image " + n + " is not an 8-bit gray image of the camera size");
-            f.data = m.data;
-            f.stride = m.stride;
-            return true;
+            if (m.width != W || m.height != H || m.channels != 1) return fail(SL3D_E_INVALID_ARG, "provided image " + nm + " is not an 8-bit gray image of the camera size");
+            out[i].data = m.data;
+            out[i].stride = m.stride;
+            break;
         }
+        if (!out[i].data) from_file.push_back((int)i);
     }
-    for (const auto &n : names)
-        if (read_bmp_gray(data_root() + "/" + n, f.storage)) {
-            f.data = f.storage.data();
-            f.stride = (size_t)W;
-            return true;
-        }
-    return fail(SL3D_E_INVALID_ARG, "cannot read " + data_root() + "/" + names[0] + " (8/24-bit BMP of " + std::to_string(W) + "x" + std::to_string(H) + ")");
+    if (from_file.empty()) return true;
+    if (g.staging_planes < n) {
+        if (g.staging) sl3d_host_free(g.staging);
+        g.staging = (uint8_t *)sl3d_host_alloc(n * (size_t)W * H);
+        g.staging_planes = g.staging ? n : 0;
+        if (!g.staging) return fail(SL3D_E_NOMEM, "cannot allocate the pinned staging area for the input frames");
+    }
+    std::vector<char> ok_flag(n, 1);
+    const std::string root = data_root();
+    parallel_for((int)from_file.size(), [&](int k) {
+        const size_t i = (size_t)from_file[(size_t)k];
+        uint8_t *dst = g.staging + i * (size_t)W * H;   // slot i: frames that all come from files end up back to back
+        bool got = false;
+        for (const auto &nm : names[i])
+            if (!got && read_bmp_gray(root + "/" + nm, dst)) got = true;
+        ok_flag[i] = got;
+        out[i].data = dst;
+        out[i].stride = (size_t)W;
+    });
+    for (size_t i = 0; i < n; i++)
+        if (!ok_flag[i]) return fail(SL3D_E_INVALID_ARG, "cannot read " + root + "/" + names[i][0] + " (8/24-bit BMP of " + std::to_string(W) + "x" + std::to_string(H) + ")");
+    return true;
 }
 
 // the numbers inside <data>...</data> of an OpenCV XML matrix (cvReadByName of 7/triangulation.cpp:152-168,1069-1083)
@@ -487,13 +572,15 @@ void compute_wrapped_phase(int pattern_type)
 
     // read_image: the F fringe frames of this axis (3/wrapped_phase.cpp:29-58); stage 4 brings the Gray / inverse frames
     const int F = number_of_patterns_fringe;
-    std::vector<Frame> img((size_t)F);
+    std::vector<Frame> img;
+    std::vector<std::vector<std::string>> names((size_t)F);
     char name[256], alt[256];
     for (int i = 0; i < F; i++) {
         snprintf(name, sizeof name, "Captured_patterns/Fringe_patterns/%s/Undistorted/Captured_image_%d.bmp", axis_dir(pattern_type), i);
         snprintf(alt, sizeof alt, "Captured_patterns/Fringe_patterns/%s/Undistorted/Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
-        if (!load_frame({name, alt}, img[(size_t)i])) return;
+        names[(size_t)i] = {name, alt};
     }
+    if (!load_frames(names, img)) return;
     if (!upload_planes(img, pattern_type, 0)) return;
     if (!each_part("sl3d_compute_wrapped_phase", [&](const Part &p) { return sl3d_compute_wrapped_phase(p.ctx, 0, pattern_type); })) return;
 
@@ -524,16 +611,18 @@ void unwrap_phase(int pattern_type)
     // frames of the axis are resident since stage 3
     const int F = number_of_patterns_fringe;
     const int N = pattern_type == 0 ? number_of_patterns_binary_vertical : number_of_patterns_binary_horizontal;
-    std::vector<Frame> img((size_t)(2 * N));
+    std::vector<Frame> img;
+    std::vector<std::vector<std::string>> names((size_t)(2 * N));
     char name[256], alt[256];
     for (int i = 0; i < N; i++) {
         snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/Captured_image_%d.bmp", axis_dir(pattern_type), i);
         snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
-        if (!load_frame({name, alt}, img[(size_t)i])) return;
+        names[(size_t)i] = {name, alt};
         snprintf(name, sizeof name, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Captured_image_%d.bmp", axis_dir(pattern_type), i);
         snprintf(alt, sizeof alt, "Captured_patterns/Coded_patterns/Gray_coded/%s/Undistorted/inverse_Gray_captured_image_%d.bmp", axis_dir(pattern_type), i);
-        if (!load_frame({name, alt}, img[(size_t)(N + i)])) return;
+        names[(size_t)(N + i)] = {name, alt};
     }
+    if (!load_frames(names, img)) return;
     if (N > 0 && !upload_planes(img, pattern_type, F)) return;
     if (!each_part("sl3d_unwrap_phase", [&](const Part &q) { return sl3d_unwrap_phase(q.ctx, 0, pattern_type); })) return;
 
@@ -655,10 +744,10 @@ void save_point_cloud(unsigned cloud_index)
             memcpy(&rec[16 * i + 12], &packed, 4);
         }
         fwrite(rec.data(), 1, rec.size(), f);
-    } else {
-        std::string rows;
-        append_cloud_ascii(rows, xyz.data(), rgb.data(), n, 1);
-        fwrite(rows.data(), 1, rows.size(), f);
+    } else if (!write_cloud_ascii(f, xyz.data(), rgb.data(), n, 1)) {
+        fclose(f);
+        fail(SL3D_E_INVALID_ARG, "short write to " + base + ".pcd");
+        return;
     }
     fclose(f);
     f = fopen((base + ".ply").c_str(), "wb");
@@ -673,10 +762,10 @@ void save_point_cloud(unsigned cloud_index)
             memcpy(&rec[15 * i + 12], &rgb[3 * i], 3);
         }
         fwrite(rec.data(), 1, rec.size(), f);
-    } else {
-        std::string rows;
-        append_cloud_ascii(rows, xyz.data(), rgb.data(), n, 3);
-        fwrite(rows.data(), 1, rows.size(), f);
+    } else if (!write_cloud_ascii(f, xyz.data(), rgb.data(), n, 3)) {
+        fclose(f);
+        fail(SL3D_E_INVALID_ARG, "short write to " + base + ".ply");
+        return;
     }
     fclose(f);
     fprintf(stderr, "Saved %lld data points to %s.pcd / .ply\n", (long long)n, base.c_str());
@@ -791,10 +880,10 @@ void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float 
             memcpy(&rec[15 * i + 12], &all_rgb[3 * i], 3);
         }
         fwrite(rec.data(), 1, rec.size(), f);
-    } else {
-        std::string rows;
-        append_cloud_ascii(rows, all_xyz.data(), all_rgb.data(), (int64_t)n, 3);
-        fwrite(rows.data(), 1, rows.size(), f);
+    } else if (!write_cloud_ascii(f, all_xyz.data(), all_rgb.data(), (int64_t)n, 3)) {
+        fclose(f);
+        fail(SL3D_E_INVALID_ARG, "short write to the registered cloud");
+        return;
     }
     fclose(f);
 }

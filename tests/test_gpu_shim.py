@@ -89,7 +89,7 @@ def test_shim_matches_oracle(tmp_path, devices, mode):
     exe = f"{root}/shim_driver"
     defs = [f"-DCamera_imagewidth={W}", f"-DCamera_imageheight={H}", f"-DProjector_imagewidth={PW}", f"-DProjector_imageheight={PH}"]
     csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", *defs, "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", *defs, "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "native", "shim_driver.cpp"), os.path.join(csrc, "sl3d_shim.cpp"),
                            os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"), "-lsl3d",
                            "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
@@ -170,6 +170,15 @@ def test_shim_matches_oracle(tmp_path, devices, mode):
     assert f"element vertex {len(exp_xyz)}" in ply[:k]
     rows = np.array([ln.split() for ln in ply[k + 1:] if ln])
     assert np.array_equal(rows[:, :3].astype(np.float32), got_xyz) and np.array_equal(rows[:, 3:].astype(np.uint8), exp_rgb)
+    # the rows are formatted on all host threads (disjoint point ranges, written in order) and the input files are decoded in
+    # parallel: one thread must give the same files byte for byte, and the same globals
+    if not devices:
+        first = [open(f"{root}/Point_cloud/point_cloud_3.{e}", "rb").read() for e in ("pcd", "ply")] + [raw]
+        r = subprocess.run([exe, root, out, str(NV), str(NH), str(FWV), str(FWH), str(ncv), str(nch)], capture_output=True, text=True, timeout=300,
+                           env=dict(env, SL3D_SHIM_THREADS="1"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        again = [open(f"{root}/Point_cloud/point_cloud_3.{e}", "rb").read() for e in ("pcd", "ply")] + [open(out, "rb").read()]
+        assert first == again
 
 
 def test_shim_generate_pattern_reproduces_reference_files(tmp_path):
@@ -183,7 +192,7 @@ def test_shim_generate_pattern_reproduces_reference_files(tmp_path):
     exe = f"{root}/shim_driver"
     csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
     defs = [f"-DProjector_imagewidth={PWr}", f"-DProjector_imageheight={PHr}", "-DCamera_imagewidth=64", "-DCamera_imageheight=48"]
-    subprocess.check_call(["g++", "-O2", "-std=c++17", *defs, "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", *defs, "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "native", "shim_driver.cpp"), os.path.join(csrc, "sl3d_shim.cpp"),
                            os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"), "-lsl3d",
                            "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
@@ -227,7 +236,7 @@ def test_shim_register_point_clouds_files(tmp_path, binary):
     exe = f"{root}/shim_driver"
     csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
     defs = ["-DCamera_imagewidth=64", "-DCamera_imageheight=48", "-DProjector_imagewidth=64", "-DProjector_imageheight=48"]
-    subprocess.check_call(["g++", "-O2", "-std=c++17", *defs, "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", *defs, "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "native", "shim_driver.cpp"), os.path.join(csrc, "sl3d_shim.cpp"),
                            os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"), "-lsl3d",
                            "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])

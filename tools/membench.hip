@@ -431,6 +431,35 @@ __global__ __launch_bounds__(256, 8) void k_scope(const uint8_t *in, size_t plan
     }
 }
 
+
+// round 4: the same data path with the planes of a view stored PLANAR ([plane][row][pitch]: a wave's 46 loads go to 46 regions
+// 2 MB apart) or ROW-INTERLEAVED ([row][plane][pitch]: the 46 loads of a wave lie 1920 B apart inside one 88-KB run, consecutive
+// tiles read consecutive memory) -- address = plane * plane_stride + row * row_pitch + 4 * quad column
+template <int P>
+__global__ __launch_bounds__(256, 8) void k_layout(const uint8_t *in, size_t view_stride, unsigned plane_stride, unsigned row_pitch, unsigned qpr, float4 *out,
+                                                   unsigned *outv, size_t nquads_view)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads_view) return;
+    const unsigned row = (unsigned)(q / qpr), cq = (unsigned)(q - (size_t)row * qpr);
+    const uint8_t *base = in + (size_t)blockIdx.y * view_stride + (size_t)row * row_pitch + cq * 4u;
+    unsigned v[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) v[p] = __builtin_nontemporal_load((const unsigned *)(base + (size_t)p * plane_stride));
+    unsigned a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int p = 0; p < P; p++) { a ^= v[p]; b += v[p]; c |= v[p] >> (p & 7); }
+    float fa = __uint_as_float((a & 0x007fffffu) | 0x3f800000u), fb = __uint_as_float((b & 0x007fffffu) | 0x3f800000u),
+          fc = __uint_as_float((c & 0x007fffffu) | 0x3f800000u);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v0 = {fa, fb, fc, fa}, v1 = {fb, fc, fa, fb}, v2 = {fc, fa, fb, fc};
+    const size_t qg = (size_t)blockIdx.y * nquads_view + q;
+    f32x4 *o = (f32x4 *)out;
+    const size_t w0 = (qg & ~(size_t)63) * 3, l = qg & 63;
+    __builtin_nontemporal_store(v0, o + w0 + l); __builtin_nontemporal_store(v1, o + w0 + 64 + l); __builtin_nontemporal_store(v2, o + w0 + 128 + l);
+    __builtin_nontemporal_store(a, outv + qg);
+}
+
 template <int LD, int ST>
 static void run_scope(const uint8_t *fr, size_t vpx, int nviews, float4 *o, unsigned *ov, hipEvent_t e0, hipEvent_t e1)
 {
@@ -487,6 +516,38 @@ int main(int argc, char **argv)
                 run_store_form<2>(fr, vpx, nviews, o, ov, e0, e1, "whole 1-KiB runs");
                 run_store_form<3>(fr, vpx, nviews, o, ov, e0, e1, "whole 1-KiB runs, non-temporal");
             }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "layout")) {
+        // planar vs row-interleaved frames: one view per launch from HBM (8 views round robin) and 16 views per launch (steady)
+        const unsigned Wd = 1920, Hh = 1080, qpr = Wd / 4;
+        const size_t vpx = (size_t)Wd * Hh, nq = vpx / 4;
+        const int NV = 16;
+        uint8_t *fr; float4 *o; unsigned *ov;
+        CHK(hipMalloc(&fr, vpx * 47 * NV + 64)); CHK(hipMalloc(&o, vpx * 12 * NV)); CHK(hipMalloc(&ov, vpx * NV));
+        CHK(hipMemset(fr, 0x5a, vpx * 47 * NV + 64));
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 3; rep++)
+            for (int inter = 0; inter < 2; inter++)
+                for (int batch : {1, 16}) {
+                    const unsigned plane_stride = inter ? Wd : (unsigned)vpx, row_pitch = inter ? 47u * Wd : Wd;
+                    const int launches = batch == 1 ? 800 : 100;
+                    float ms = 0;
+                    for (int pass = 0; pass < 2; pass++) {
+                        CHK(hipEventRecord(e0));
+                        for (int i = 0; i < launches; i++) {
+                            const int v = batch == 1 ? i % 8 : 0;
+                            hipLaunchKernelGGL((k_layout<47>), dim3((nq + 255) / 256, batch), dim3(256), 0, 0, fr + (size_t)v * vpx * 47, vpx * 47, plane_stride, row_pitch,
+                                               qpr, (float4 *)((float *)o + (size_t)v * vpx * 3), ov + (size_t)v * vpx / 4, nq);
+                        }
+                        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                        CHK(hipEventElapsedTime(&ms, e0, e1));
+                    }
+                    CHK(hipGetLastError());
+                    const double us = ms * 1e3 / launches;
+                    printf("%-16s %2d view(s) per launch%s: %8.2f us  %6.0f GB/s  frac of 8 TB/s %.3f\n", inter ? "row-interleaved" : "planar", batch,
+                           batch == 1 ? " (8 views round robin, HBM)" : "", us, 60.0 * vpx * batch / us / 1e3, 60.0 * vpx * batch / us / 1e3 / 8000.0);
+                }
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "oneview_cold")) {

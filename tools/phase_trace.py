@@ -3,7 +3,9 @@
 every wave stamps the 100 MHz wall clock at its phase boundaries (sl3d_kernels.hip, SL3D_STAMP).  Prints where the time of a
 launch goes -- start-up, the rounds of blocks, how many waves sit in which phase at every microsecond -- i.e. what bounds the
 one-view launch (the reference's real usage: one scan per call).
-    SL3D_LIB=$PWD/ab/libsl3d_trace.so python3 tools/phase_trace.py [views]   -> gpurun_out/phase_trace_<views>.npz + a summary"""
+    SL3D_LIB=$PWD/ab/trace_libsl3d.so python3 tools/phase_trace.py [views] [cold]   -> gpurun_out/phase_trace_<views>.npz + a summary
+`cold` (with 1 view per launch): 8 views are resident and every launch takes the next one, so the traced launch reads its frames
+from HBM, not from the Infinity Cache (side.one_view_cold of bench.py)."""
 import ctypes as C
 import importlib
 import os
@@ -18,19 +20,21 @@ scm = importlib.import_module("3dscan_amd.scanner")
 syn = importlib.import_module("3dscan_amd.synth")
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+COLD = len(sys.argv) > 2 and sys.argv[2] == "cold"
+R = 8 if COLD else 1            # resident batches the launches rotate over
 W, H, N, fw = 1920, 1080, 10, 2
-sc = scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V)
+sc = scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V * R)
 sc.set_calibration(*syn.cal_tuple(syn.synth_rig(W, H, W, H)))
 m = syn.default_mask(W, H)
-for v in range(V):
+for v in range(V * R):
     sc.set_mask(m, view=v)
     sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=2)
-for _ in range(500):          # clocks up, caches warm: the launch that is traced is one of a back-to-back series
-    sc.run(0, V)
+for i in range(500):          # clocks up: the launch that is traced is one of a back-to-back series
+    sc.run((i % R) * V, V)
 sc.synchronize()
 sc.timer_start()
-for _ in range(200):
-    sc.run(0, V)
+for i in range(200):
+    sc.run((i % R) * V, V)
 ms = sc.timer_stop() / 200
 sc.synchronize()
 L = sc.L
@@ -45,7 +49,7 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"phase_trace_{V}.npz"), stamps=a, ms_per_launch=ms)
 t = (a - a[:, 0].min()) / 100.0                  # microseconds since the first wave entered the kernel
 names = ["reciprocal table", "item set-up", "issue plane loads", "wait planes + decode", "phase A (stages 3-5)", "phase B (stage 7)", "issue stores"]
-print(f"{V} view(s) per launch, back to back: {ms * 1e3:.2f} us per launch (HIP events, 200 launches); traced launch: "
+print(f"{V} view(s) per launch, back to back{' (8 resident batches round robin: frames from HBM)' if COLD else ''}: {ms * 1e3:.2f} us per launch (HIP events, 200 launches); traced launch: "
       f"{len(t)} waves, first entry -> last store issued {t[:, 7].max():.2f} us")
 print("per-wave phase durations (us): median / p90")
 for k, n in enumerate(names):

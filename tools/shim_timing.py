@@ -19,7 +19,7 @@ def run(scans=5, timeout=600):
     csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
     with tempfile.TemporaryDirectory(prefix="sl3d_shim_") as tmp:
         exe = os.path.join(tmp, "shim_bench")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "shim_bench.cpp"),
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "shim_bench.cpp"),
                                os.path.join(csrc, "sl3d_shim.cpp"), os.path.join(csrc, "sl3d_shim_globals.cpp"), "-L" + os.path.join(ROOT, "3dscan_amd"),
                                "-lsl3d", "-Wl,-rpath," + os.path.join(ROOT, "3dscan_amd"), "-o", exe])
         cal = syn.cal_tuple(syn.synth_rig(1600, 1200, 1280, 720))
