@@ -22,6 +22,7 @@
 
 #define SL3D_BLOCK 256 /* threads per block: a block is a 1024-pixel tile of the scan, 4 waves = 4 segments of 256 pixels */
 #define SL3D_OCC 4     /* waves per SIMD the fused kernel is compiled for (128 VGPRs) */
+#define SL3D_SMALL_BLOCK SL3D_BLOCK /* the small-launch instantiation keeps 256-thread blocks too (round 4: 128 / 64 threads +-0.5 %) */
 
 // measurement only (tools/ab.sh builds with -DSL3D_MEASURE -DSL3D_ABLATE=n): 2 = no mask reads, 4 = no xyz stores.  Results are wrong
 // by construction; the shipped build has neither the compile-time switch nor the run-time hooks (SL3D_VPT / SL3D_CAMTAB
@@ -233,7 +234,7 @@ __device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal 
 // view's plane loads right behind them and then calls cam_table_finish -- one round trip instead of two in front of the first
 // decode.  (Round 3 measured the other order for large launches -- set-up loads before the reciprocal-table fill, consumed behind
 // the plane loads: 16 views +-0, profiles/r03_prologue_ab.txt.)
-template <int RIG, bool SEG, bool EARLY>
+template <int RIG, bool SEG, bool EARLY, int BLK = SL3D_BLOCK>
 __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglobal, unsigned tile_, int group, int first_view, int n_views, int vpt, Item &it,
                                            MaskQuad &mq_first, double (&camt)[8], double *my_cam)
 {
@@ -241,7 +242,7 @@ __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglob
     it.tile = tile_;
     it.v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
     it.v_end = min(it.v_begin + vpt, first_view + n_views);
-    const long q = (long)tile_ * SL3D_BLOCK + threadIdx.x;
+    const long q = (long)tile_ * BLK + threadIdx.x;
     const int row_q = (int)(q / qpr);
     it.cq = (int)(q - (long)row_q * qpr);
     // SEG: a wave stores its segment with all 64 lanes (whole 16-byte chunks, lane after lane), so the lanes past the last row
@@ -405,25 +406,32 @@ __device__ __forceinline__ unsigned pixel_A(const KParams &P, const Item &it, in
 }
 
 // the 4 pixels of a lane as two pairs: two independent fp64 dependency chains per iteration for the scheduler to interleave
-// (tools/ab.sh: 1 pixel per iteration -3 %, all 4 unrolled +1 % but 12 more VGPRs)
+// (tools/ab.sh: 1 pixel per iteration -3 %, all 4 unrolled +1 % but 12 more VGPRs).
+// UNROLL (the small-launch instantiation): both pairs in one basic block = four independent chains.  In a launch of one or two
+// views a SIMD is often NOT saturated by its four waves -- the first round's waves all wait for their planes and then all compute,
+// the last waves of the launch compute alone -- and there a wave's own latency is what the launch waits for.
 template <bool RCP_TAB>
+__device__ __forceinline__ void phase_A_pair(const KParams &P, const Item &it, int F, int j, unsigned &vbits, unsigned (&f)[2][4], unsigned (&code)[2][2],
+                                             const double *s_rcp, int *my_cp, unsigned &vout)
+{
+    const unsigned ok0 = pixel_A<RCP_TAB>(P, it, F, 0, 2 * j, vbits, f, code, s_rcp, my_cp), ok1 = pixel_A<RCP_TAB>(P, it, F, 1, 2 * j + 1, vbits, f, code, s_rcp, my_cp);
+    vout = (vout >> 16) | (ok0 << 16) | (ok1 << 24);  // after two pairs: valid byte of pixel k at byte k
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) f[a][p] >>= 16;
+        code[a][0] = code[a][1];
+    }
+    vbits >>= 2;
+}
+
+template <bool RCP_TAB, bool UNROLL>
 __device__ __forceinline__ unsigned phase_A(const KParams &P, const Item &it, int F, unsigned vbits, unsigned (&f)[2][4], unsigned (&code)[2][2],
                                             const double *s_rcp, int *my_cp)
 {
     unsigned vout = 0;
-#pragma unroll 1
-    for (int j = 0; j < 2; j++) {
-        const unsigned ok0 = pixel_A<RCP_TAB>(P, it, F, 0, 2 * j, vbits, f, code, s_rcp, my_cp),
-                       ok1 = pixel_A<RCP_TAB>(P, it, F, 1, 2 * j + 1, vbits, f, code, s_rcp, my_cp);
-        vout = (vout >> 16) | (ok0 << 16) | (ok1 << 24);  // after two pairs: valid byte of pixel k at byte k
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-#pragma unroll
-            for (int p = 0; p < 4; p++) f[a][p] >>= 16;
-            code[a][0] = code[a][1];
-        }
-        vbits >>= 2;
-    }
+#pragma unroll(UNROLL ? 2 : 1)
+    for (int j = 0; j < 2; j++) phase_A_pair<RCP_TAB>(P, it, F, j, vbits, f, code, s_rcp, my_cp, vout);
     return vout;
 }
 
@@ -439,13 +447,13 @@ __device__ __forceinline__ void gather_B(const KParams &P, bool proj_table, cons
     }
 }
 
-template <int RIG>
+template <int RIG, bool UNROLL>
 __device__ __forceinline__ void phase_B(const KParams &P, const DevCal *Cglobal, const PinnedRows &PR, bool proj_table, unsigned vout, float2 (&d)[4],
                                         const double *my_cam, const int *my_cp, float *my_xyz)
 {
     const float nanv = __builtin_nanf("");
     unsigned vb = vout;
-#pragma unroll 1
+#pragma unroll(UNROLL ? 2 : 1)
     for (int j = 0; j < 2; j++) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -637,14 +645,15 @@ __device__ __forceinline__ unsigned valid_bits(const Item &it, int F, const Mask
 //       lattice by the device self-check.  Round 3, alternating on one box: 1 view 30.3 against 31.6 us, 2 views -2.7 %, 4 views
 //       -1 %; at 16 views per launch the table is as fast (dense) or 1.4 % faster (clouds) -- profiles/r03_rcp_table_ab*.txt.
 template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE = 0, bool RCPT = true>
-__global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
+__global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     constexpr bool SEG = CMODE == 2;
+    constexpr int BLK = RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK;
     static_assert(CMODE == 0 || CMODE == 2, "0 = dense planes, 2 = segmented clouds (1 was round 2's look-back compaction)");
     static_assert(!(KEEP && CMODE != 0), "the parity mode writes dense planes");
     static_assert(!(KEEP && RIG != 0), "the parity mode evaluates everything with the reference's operation order");
-    __shared__ __attribute__((aligned(16))) float s_xyz[SL3D_BLOCK * 12];  // staging area: correspondences, then xyz, of the lane's 4 pixels
-    __shared__ __attribute__((aligned(16))) double s_cam[SL3D_BLOCK * 8];  // undistorted camera coordinates of the lane's 4 pixels
+    __shared__ __attribute__((aligned(16))) float s_xyz[BLK * 12];  // staging area: correspondences, then xyz, of the lane's 4 pixels
+    __shared__ __attribute__((aligned(16))) double s_cam[BLK * 8];  // undistorted camera coordinates of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_rcp[RCPT ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
     SL3D_STAMP(0);
     if (RCPT) {
@@ -664,6 +673,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
     // UNCONDITIONALLY, right behind the item's mask / camera-table requests and before any of those is waited for, at the price of
     // plane loads for quads that turn out to be masked off (profiles/r03_early_planes_ab.txt)
     constexpr bool EARLY = !RCPT && CMODE == 0 && PIPE;
+    constexpr bool UNROLL = !RCPT;  // the small-launch instantiation: both pixel pairs of phases A and B in one basic block (see phase_A)
 
     const PinnedRows PR = pinned_rows<RIG>(Cglobal);
     // EXACT: both axes have exactly NMAX Gray planes (the usual case)
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
     unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     // gridDim.x is a multiple of 8 (launch_fused): consecutive tiles go round-robin over the 8 XCDs on purpose (the XCD-banded
     // order was measured at -4 %: DRAM locality across XCDs beats L2 locality for 2 % of shared bytes)
-    if (!item_begin<RIG, SEG, EARLY>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
+    if (!item_begin<RIG, SEG, EARLY, BLK>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
     if (EARLY) {  // planes of the first view right behind the set-up requests; then the set-up results are consumed
         issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
         issue_gray<NMAX, EXACT>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
         if (view == it.v_begin) SL3D_STAMP(4);
         if (vbits != 0) {
             if (KEEP) vout = parity_pixels<RCPT>(P, Cglobal, PR, it, F, vbits, f, code, s_rcp, my_cam, my_xyz, px);
-            else vout = phase_A<RCPT>(P, it, F, vbits, f, code, s_rcp, my_cp);
+            else vout = phase_A<RCPT, UNROLL>(P, it, F, vbits, f, code, s_rcp, my_cp);
         }
         if (view == it.v_begin) SL3D_STAMP(5);
         // (Round 3 read the ISA of the table rigs: their 4 projector-table entries are requested BEHIND the next view's 46 plane
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(SL3D_BLOCK, SL3D_OCC) void k_fused(const KParams P,
         if (!KEEP && vbits != 0) {
             float2 d[4];
             gather_B(P, proj_table, my_cp, d);
-            phase_B<RIG>(P, Cglobal, PR, proj_table, vout, d, my_cam, my_cp, my_xyz);
+            phase_B<RIG, UNROLL>(P, Cglobal, PR, proj_table, vout, d, my_cam, my_cp, my_xyz);
         }
         if (SEG) {
             store_segment(P, it, view, px, vout, s_xyz, my_xyz);
@@ -772,11 +782,13 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
     const dim3 block(SL3D_BLOCK, 1, 1);
     const FusedChoice c = choose_fused(KEEP, FGEN, CMODE, nv, nh, n_views);
     constexpr bool HAS_SMALL = !KEEP && !FGEN && CMODE == 0;  // (the only family that has the second instantiation)
+    const long quads_ = (long)(P.pitch >> 2) * P.H;
+    const dim3 small_grid((((unsigned)((quads_ + SL3D_SMALL_BLOCK - 1) / SL3D_SMALL_BLOCK)) + 7u) & ~7u, grid.y, 1);
 #define SL3D_LAUNCH(NM, EX)                                                                                                                \
     do {                                                                                                                                   \
         if constexpr (HAS_SMALL) {                                                                                                         \
             if (c.small) {                                                                                                                 \
-                hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE, false>), grid, block, 0, st, P, C, first_view, n_views, vpt);   \
+                hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE, false>), small_grid, dim3(SL3D_SMALL_BLOCK), 0, st, P, C, first_view, n_views, vpt); \
                 break;                                                                                                                     \
             }                                                                                                                              \
         }                                                                                                                                  \

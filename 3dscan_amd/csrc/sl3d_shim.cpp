@@ -10,10 +10,13 @@
 #include <charconv>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <map>
+#include <fcntl.h>
 #include <sched.h>
 #include <string>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -48,6 +51,12 @@ struct Shim {
     std::vector<uint8_t> default_mask;  // 1 inside the border, built once
     uint8_t *staging = nullptr;         // pinned: the decoded planes of one stage call, back to back (file inputs)
     size_t staging_planes = 0;
+    // save_point_cloud()'s buffers, kept between scans (the reference saves a cloud per scan of its 360-degree loop): 1.9 M points
+    // are ~190 MB of text + values, and touching that much FRESH memory costs more than filling it -- every first touch of a page
+    // is a fault under the process-wide mm lock, which is what kept 32 formatting threads from scaling.  sl3d_shim_reset frees them.
+    std::vector<std::string> pcd_rows, ply_rows;
+    std::vector<float> cloud_xyz;
+    std::vector<uint8_t> cloud_rgb;
     int status = SL3D_OK;
     std::string err;
     // the configuration the context was created with (the scalar globals may change between scans)
@@ -61,22 +70,38 @@ std::string data_root()
     return e ? std::string(e) : std::string(kReferenceRoot);
 }
 
-// host threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a container may see 256 cores
-// and be granted 16) and by 32
+// SL3D_SHIM_TIMING=1: the phases of save_point_cloud() on stderr (where a scan's wall time goes once the stages take milliseconds)
+struct PhaseTimer {
+    bool on = getenv("SL3D_SHIM_TIMING") && atoi(getenv("SL3D_SHIM_TIMING")) != 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string line;
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        char b[96];
+        snprintf(b, sizeof b, " %s %.1f ms;", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        line += b;
+        t0 = t1;
+    }
+    void print(const char *who) const
+    {
+        if (on) fprintf(stderr, "[sl3d shim] %s:%s\n", who, line.c_str());
+    }
+};
+
+// host threads for the short bursts below (file decode, text formatting: tens of milliseconds): the affinity mask, at most 32.
+// A cgroup CPU quota is an average over its period, not a core count -- on the GPU boxes (256 cores visible, quota 16) 32 threads
+// finish such a burst in 0.6 of the time 16 take -- so it is not applied here.  SL3D_SHIM_THREADS overrides.
 int usable_threads()
 {
     static int n = [] {
         int k = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof set, &set) == 0) k = CPU_COUNT(&set);
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[32] = {0};
-            long period = 0;
-            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) k = std::min<long>(k, std::max<long>(1, atol(q) / period));
-            fclose(f);
-        }
+        k = std::min(k, 32);
         if (const char *e = getenv("SL3D_SHIM_THREADS")) k = atoi(e);
-        return std::max(1, std::min(k, 32));
+        return std::max(1, std::min(k, 256));
     }();
     return n;
 }
@@ -225,48 +250,83 @@ bool write_bmp_gray(const std::string &path, const uint8_t *img, int w = W, int 
     return true;
 }
 
-// The ASCII cloud rows the reference's PCL writers produce are built in memory and written with one fwrite: std::to_chars with
+// The ASCII cloud rows of the reference's PCL writers (8/save_point_cloud.cpp:211-217), built in memory: std::to_chars with
 // chars_format::general and precision 9 yields the digits of printf("%.9g") (the C++17 contract), several times faster than a
-// fprintf per point.  `cols`: 1 = one packed 0x00RRGGBB integer (PCD), 3 = red green blue (PLY).
-void append_cloud_ascii(std::string &out, const float *xyz, const uint8_t *rgb, int64_t first, int64_t n, int cols)
+// fprintf per point.  The float -> text conversion is what costs, and the PCD and the PLY row of a point share their "x y z "
+// text: it is formatted ONCE and appended to both (pcd / ply may be NULL); the PCD row ends with one packed 0x00RRGGBB integer,
+// the PLY row with "red green blue".
+void append_cloud_rows(std::string *pcd, std::string *ply, const float *xyz, const uint8_t *rgb, int64_t first, int64_t n)
 {
-    out.reserve(out.size() + (size_t)n * 48);
+    // rows are written straight into the strings' storage through raw pointers (a row is at most 3 * 16 + 12 bytes), and the
+    // strings are cut to their real length at the end: no per-value append
+    constexpr size_t kRowMax = 64;
+    const size_t pcd0 = pcd ? pcd->size() : 0, ply0 = ply ? ply->size() : 0;
+    if (pcd) pcd->resize(pcd0 + (size_t)n * kRowMax);
+    if (ply) ply->resize(ply0 + (size_t)n * kRowMax);
+    char *pc = pcd ? &(*pcd)[pcd0] : nullptr, *pl = ply ? &(*ply)[ply0] : nullptr;
     char buf[64];
     for (int64_t i = first; i < first + n; i++) {
+        char *p = buf;
         for (int k = 0; k < 3; k++) {
-            const auto r = std::to_chars(buf, buf + sizeof buf, xyz[3 * i + k], std::chars_format::general, 9);
-            out.append(buf, r.ptr);
-            out.push_back(' ');
+            p = std::to_chars(p, buf + sizeof buf, xyz[3 * i + k], std::chars_format::general, 9).ptr;
+            *p++ = ' ';
         }
-        if (cols == 1) {
+        const size_t len = (size_t)(p - buf);
+        if (pc) {
+            memcpy(pc, buf, len);
             const unsigned packed = ((unsigned)rgb[3 * i] << 16) | ((unsigned)rgb[3 * i + 1] << 8) | (unsigned)rgb[3 * i + 2];
-            const auto r = std::to_chars(buf, buf + sizeof buf, packed);
-            out.append(buf, r.ptr);
-        } else {
+            pc = std::to_chars(pc + len, pc + len + 12, packed).ptr;
+            *pc++ = '\n';
+        }
+        if (pl) {
+            memcpy(pl, buf, len);
+            pl += len;
             for (int k = 0; k < 3; k++) {
-                const auto r = std::to_chars(buf, buf + sizeof buf, (unsigned)rgb[3 * i + k]);
-                out.append(buf, r.ptr);
-                if (k < 2) out.push_back(' ');
+                pl = std::to_chars(pl, pl + 4, (unsigned)rgb[3 * i + k]).ptr;
+                *pl++ = k < 2 ? ' ' : '\n';
             }
         }
-        out.push_back('\n');
     }
+    if (pcd) pcd->resize((size_t)(pc - pcd->data()));
+    if (ply) ply->resize((size_t)(pl - ply->data()));
 }
 
-// The rows of a whole cloud: disjoint point ranges are formatted on all host threads into their own buffers (the conversion is
-// what costs: 99 % of a relinked scan's wall time was this loop on one thread) and written in order, one fwrite per buffer --
-// the file is byte for byte what the single loop writes.
-bool write_cloud_ascii(FILE *f, const float *xyz, const uint8_t *rgb, int64_t n, int cols)
+// header + pieces -> one file, in order.  (Round 4 also tried to give the file its final size, map it and let every thread copy its
+// pieces in: on the GPU boxes' overlay file system the page faults of a shared mapping cost more than write() -- 233 against 155 ms
+// for the two ASCII files of a 1.87-Mpoint cloud -- so the pieces are written one after the other.)
+bool write_pieces(const std::string &path, const std::string &header, const std::vector<std::string> &pieces)
 {
-    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>((n + 16383) / 16384, 4 * usable_threads()));
-    std::vector<std::string> rows((size_t)parts);
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return false;
+    bool good = true;
+    auto put = [&](const char *p, size_t n) {
+        while (good && n) {
+            const ssize_t w = write(fd, p, n);
+            if (w <= 0) good = false;
+            else { p += w; n -= (size_t)w; }
+        }
+    };
+    put(header.data(), header.size());
+    for (const auto &q : pieces) put(q.data(), q.size());
+    return close(fd) == 0 && good;
+}
+
+// the rows of a whole cloud for both files (either may be NULL): disjoint point ranges are formatted on all host threads into
+// their own buffers; concatenated in order they are byte for byte what one loop over all points writes
+int cloud_parts(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 16383) / 16384, 4 * usable_threads())); }
+
+void format_cloud(const float *xyz, const uint8_t *rgb, int64_t n, std::vector<std::string> *pcd, std::vector<std::string> *ply)
+{
+    const int parts = cloud_parts(n);
+    // (resize + clear: a buffer that is being reused keeps its capacity, i.e. its already-touched pages)
+    if (pcd) pcd->resize((size_t)parts);
+    if (ply) ply->resize((size_t)parts);
     parallel_for(parts, [&](int k) {
         const int64_t a = n * k / parts, b = n * (k + 1) / parts;
-        append_cloud_ascii(rows[(size_t)k], xyz, rgb, a, b - a, cols);
+        if (pcd) (*pcd)[(size_t)k].clear();
+        if (ply) (*ply)[(size_t)k].clear();
+        append_cloud_rows(pcd ? &(*pcd)[(size_t)k] : nullptr, ply ? &(*ply)[(size_t)k] : nullptr, xyz, rgb, a, b - a);
     });
-    for (const auto &r : rows)
-        if (fwrite(r.data(), 1, r.size(), f) != r.size()) return false;
-    return true;
 }
 
 // One input frame: the caller's memory (sl3d_shim_provide_image under one of the names; no copy) or the first readable file of
@@ -482,7 +542,14 @@ extern "C" void sl3d_shim_set_data_root(const char *dir)
 extern "C" void sl3d_shim_write_debug_images(int enable) { g.write_debug = enable != 0; }
 extern "C" int sl3d_shim_last_status(void) { return g.status; }
 extern "C" const char *sl3d_shim_last_error(void) { return g.err.c_str(); }
-extern "C" void sl3d_shim_reset(void) { drop_ctx(); }
+extern "C" void sl3d_shim_reset(void)
+{
+    drop_ctx();
+    std::vector<std::string>().swap(g.pcd_rows);
+    std::vector<std::string>().swap(g.ply_rows);
+    std::vector<float>().swap(g.cloud_xyz);
+    std::vector<uint8_t>().swap(g.cloud_rgb);
+}
 extern "C" void sl3d_shim_host_transpose(int enable) { g.host_transpose = enable != 0; }
 extern "C" void sl3d_shim_cloud_format(int binary) { g.binary_clouds = binary != 0; }
 extern "C" void sl3d_shim_provide_image(const char *relative_path, const uint8_t *data, int width, int height, int channels, size_t stride)
@@ -698,6 +765,7 @@ void save_point_cloud(unsigned cloud_index)
 {
     g.status = SL3D_OK;
     if (!g.ctx) { fail(SL3D_E_STATE, "save_point_cloud before triangulate"); return; }
+    PhaseTimer pt;
     std::vector<uint8_t> tex_store;
     const uint8_t *tex = nullptr;
     size_t tex_stride = (size_t)W * 3;
@@ -713,14 +781,18 @@ void save_point_cloud(unsigned cloud_index)
             return;
         }
     }
+    pt.lap("texture read");
     if (!each_part("sl3d_set_texture", [&](const Part &q) { return sl3d_set_texture(q.ctx, 0, tex + (size_t)q.row0 * tex_stride, tex_stride); })) return;
+    pt.lap("texture upload");
     // the parts' clouds one after the other: stripe order = row order = the scan order of :85-104
     int64_t n = 0;
     std::vector<int64_t> cnt(g.parts.size(), 0);
     size_t k = 0;
     if (!each_part("sl3d_get_cloud_rgb", [&](const Part &q) { const int rc = sl3d_get_cloud_rgb(q.ctx, 0, nullptr, nullptr, 0, &cnt[k]); n += cnt[k++]; return rc; })) return;
-    std::vector<float> xyz((size_t)n * 3);
-    std::vector<uint8_t> rgb((size_t)n * 3);
+    std::vector<float> &xyz = g.cloud_xyz;
+    std::vector<uint8_t> &rgb = g.cloud_rgb;
+    xyz.resize((size_t)n * 3);
+    rgb.resize((size_t)n * 3);
     int64_t off = 0;
     k = 0;
     if (!each_part("sl3d_get_cloud_rgb", [&](const Part &q) {
@@ -730,44 +802,51 @@ void save_point_cloud(unsigned cloud_index)
             return rc;
         }))
         return;
+    pt.lap("compaction + download");
     mkdir((data_root() + "/Point_cloud").c_str(), 0777);
     const std::string base = data_root() + "/Point_cloud/point_cloud_" + std::to_string(cloud_index);
-    FILE *f = fopen((base + ".pcd").c_str(), "wb");
-    if (!f) { fail(SL3D_E_INVALID_ARG, "cannot write " + base + ".pcd"); return; }
-    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
-               "WIDTH %lld\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %lld\nDATA %s\n", (long long)n, (long long)n, g.binary_clouds ? "binary" : "ascii");
+    char hdr[512];
+    snprintf(hdr, sizeof hdr, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+                              "WIDTH %lld\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %lld\nDATA %s\n", (long long)n, (long long)n, g.binary_clouds ? "binary" : "ascii");
+    const std::string pcd_header = hdr;
+    snprintf(hdr, sizeof hdr, "ply\nformat %s 1.0\ncomment generated by sl3d (3dscan_amd)\nelement vertex %lld\nproperty float x\nproperty float y\n"
+                              "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n",
+             g.binary_clouds ? "binary_little_endian" : "ascii", (long long)n);
+    const std::string ply_header = hdr;
+    // The pieces of both files are produced on all host threads; then the two files go out side by side, a write() loop each.
+    // (Writers that start on the finished pieces while the rest is still being formatted were measured too: they compete with the
+    // formatting threads for the container's CPU quota -- 97 against 83 ms per save.)
+    std::vector<std::string> &pcd_rows = g.pcd_rows, &ply_rows = g.ply_rows;
+    const int parts = g.binary_clouds ? (int)std::max<int64_t>(1, std::min<int64_t>((n + 65535) / 65536, 4 * usable_threads())) : cloud_parts(n);
+    pcd_rows.resize((size_t)parts);
+    ply_rows.resize((size_t)parts);
     if (g.binary_clouds) {
-        std::vector<uint8_t> rec((size_t)n * 16);
-        for (int64_t i = 0; i < n; i++) {
-            const uint32_t packed = ((uint32_t)rgb[3 * i] << 16) | ((uint32_t)rgb[3 * i + 1] << 8) | (uint32_t)rgb[3 * i + 2];
-            memcpy(&rec[16 * i], &xyz[3 * i], 12);
-            memcpy(&rec[16 * i + 12], &packed, 4);
-        }
-        fwrite(rec.data(), 1, rec.size(), f);
-    } else if (!write_cloud_ascii(f, xyz.data(), rgb.data(), n, 1)) {
-        fclose(f);
-        fail(SL3D_E_INVALID_ARG, "short write to " + base + ".pcd");
-        return;
+        // fixed-size records: PCD x y z + packed rgb (16 bytes), PLY x y z + r g b (15 bytes), little endian
+        parallel_for(parts, [&](int k) {
+            const int64_t a = n * k / parts, b = n * (k + 1) / parts;
+            std::string &pc = pcd_rows[(size_t)k], &pl = ply_rows[(size_t)k];
+            pc.resize((size_t)(b - a) * 16);
+            pl.resize((size_t)(b - a) * 15);
+            for (int64_t i = a; i < b; i++) {
+                const uint32_t packed = ((uint32_t)rgb[3 * i] << 16) | ((uint32_t)rgb[3 * i + 1] << 8) | (uint32_t)rgb[3 * i + 2];
+                memcpy(&pc[(size_t)(i - a) * 16], &xyz[3 * i], 12);
+                memcpy(&pc[(size_t)(i - a) * 16 + 12], &packed, 4);
+                memcpy(&pl[(size_t)(i - a) * 15], &xyz[3 * i], 12);
+                memcpy(&pl[(size_t)(i - a) * 15 + 12], &rgb[3 * i], 3);
+            }
+        });
+    } else {
+        format_cloud(xyz.data(), rgb.data(), n, &pcd_rows, &ply_rows);
     }
-    fclose(f);
-    f = fopen((base + ".ply").c_str(), "wb");
-    if (!f) { fail(SL3D_E_INVALID_ARG, "cannot write " + base + ".ply"); return; }
-    fprintf(f, "ply\nformat %s 1.0\ncomment generated by sl3d (3dscan_amd)\nelement vertex %lld\nproperty float x\nproperty float y\n"
-               "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n",
-            g.binary_clouds ? "binary_little_endian" : "ascii", (long long)n);
-    if (g.binary_clouds) {
-        std::vector<uint8_t> rec((size_t)n * 15);
-        for (int64_t i = 0; i < n; i++) {
-            memcpy(&rec[15 * i], &xyz[3 * i], 12);
-            memcpy(&rec[15 * i + 12], &rgb[3 * i], 3);
-        }
-        fwrite(rec.data(), 1, rec.size(), f);
-    } else if (!write_cloud_ascii(f, xyz.data(), rgb.data(), n, 3)) {
-        fclose(f);
-        fail(SL3D_E_INVALID_ARG, "short write to " + base + ".ply");
-        return;
-    }
-    fclose(f);
+    pt.lap("format");
+    bool pcd_ok = false;
+    std::thread pcd_writer([&] { pcd_ok = write_pieces(base + ".pcd", pcd_header, pcd_rows); });
+    const bool ply_ok = write_pieces(base + ".ply", ply_header, ply_rows);
+    pcd_writer.join();
+    pt.lap("write pcd + ply");
+    pt.print("save_point_cloud");
+    if (!pcd_ok) { fail(SL3D_E_INVALID_ARG, "cannot write " + base + ".pcd"); return; }
+    if (!ply_ok) { fail(SL3D_E_INVALID_ARG, "cannot write " + base + ".ply"); return; }
     fprintf(stderr, "Saved %lld data points to %s.pcd / .ply\n", (long long)n, base.c_str());
 }
 
@@ -867,23 +946,21 @@ void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float 
         theta += rot_step;  // :145
     }
     const std::string outp = data_root() + "/Point_cloud/registered_point_cloud.ply";
-    FILE *f = fopen(outp.c_str(), "wb");
-    if (!f) { fail(SL3D_E_INVALID_ARG, "cannot write " + outp); return; }
     const long long n = (long long)all_xyz.size() / 3;
-    fprintf(f, "ply\nformat %s 1.0\ncomment generated by sl3d (3dscan_amd)\nelement vertex %lld\nproperty float x\nproperty float y\n"
-               "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n",
-            g.binary_clouds ? "binary_little_endian" : "ascii", n);
+    char hdr[512];
+    snprintf(hdr, sizeof hdr, "ply\nformat %s 1.0\ncomment generated by sl3d (3dscan_amd)\nelement vertex %lld\nproperty float x\nproperty float y\n"
+                              "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n",
+             g.binary_clouds ? "binary_little_endian" : "ascii", n);
+    std::vector<std::string> rows;
     if (g.binary_clouds) {
-        std::vector<uint8_t> rec((size_t)n * 15);
+        rows.assign(1, std::string());
+        rows[0].resize((size_t)n * 15);
         for (long long i = 0; i < n; i++) {
-            memcpy(&rec[15 * i], &all_xyz[3 * i], 12);
-            memcpy(&rec[15 * i + 12], &all_rgb[3 * i], 3);
+            memcpy(&rows[0][15 * (size_t)i], &all_xyz[3 * i], 12);
+            memcpy(&rows[0][15 * (size_t)i + 12], &all_rgb[3 * i], 3);
         }
-        fwrite(rec.data(), 1, rec.size(), f);
-    } else if (!write_cloud_ascii(f, all_xyz.data(), all_rgb.data(), (int64_t)n, 3)) {
-        fclose(f);
-        fail(SL3D_E_INVALID_ARG, "short write to the registered cloud");
-        return;
+    } else {
+        format_cloud(all_xyz.data(), all_rgb.data(), (int64_t)n, nullptr, &rows);
     }
-    fclose(f);
+    if (!write_pieces(outp, hdr, rows)) { fail(SL3D_E_INVALID_ARG, "cannot write " + outp); return; }
 }

@@ -29,6 +29,8 @@ def run(scans=5, timeout=600):
         r = subprocess.run([exe, os.path.join(tmp, "cal.bin"), data, str(scans)], capture_output=True, text=True, timeout=timeout)
         if r.returncode != 0:
             raise RuntimeError(f"shim_bench rc={r.returncode}: {r.stderr[-400:]}")
+        if os.environ.get("SL3D_SHIM_TIMING"):
+            sys.stderr.write("".join(l + "\n" for l in r.stderr.splitlines() if "[sl3d shim]" in l))
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
