@@ -672,7 +672,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     // EARLY (the small-launch instantiation of the pipelined dense kernels): the first view's planes are requested
     // UNCONDITIONALLY, right behind the item's mask / camera-table requests and before any of those is waited for, at the price of
     // plane loads for quads that turn out to be masked off (profiles/r03_early_planes_ab.txt)
-    constexpr bool EARLY = !RCPT && CMODE == 0 && PIPE;
+    constexpr bool EARLY = !RCPT && PIPE;
     constexpr bool UNROLL = !RCPT;  // the small-launch instantiation: both pixel pairs of phases A and B in one basic block (see phase_A)
 
     const PinnedRows PR = pinned_rows<RIG>(Cglobal);
@@ -772,7 +772,7 @@ inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh,
     const int m = nv > nh ? nv : nh;
     c.exact = !keep && !fgen && nv == nh && nv >= 6 && nv <= 12;
     c.nmax = c.exact ? nv : (m <= 8 ? 8 : (m <= 12 ? 12 : SL3D_MAX_GRAY));
-    c.small = !keep && !fgen && cmode == 0 && n_views <= SL3D_SMALL_LAUNCH_VIEWS;
+    c.small = !keep && !fgen && n_views <= SL3D_SMALL_LAUNCH_VIEWS;
     return c;
 }
 
@@ -781,7 +781,7 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
 {
     const dim3 block(SL3D_BLOCK, 1, 1);
     const FusedChoice c = choose_fused(KEEP, FGEN, CMODE, nv, nh, n_views);
-    constexpr bool HAS_SMALL = !KEEP && !FGEN && CMODE == 0;  // (the only family that has the second instantiation)
+    constexpr bool HAS_SMALL = !KEEP && !FGEN;  // (the 3-step timed families have the second instantiation, dense and clouds)
     const long quads_ = (long)(P.pitch >> 2) * P.H;
     const dim3 small_grid((((unsigned)((quads_ + SL3D_SMALL_BLOCK - 1) / SL3D_SMALL_BLOCK)) + 7u) & ~7u, grid.y, 1);
 #define SL3D_LAUNCH(NM, EX)                                                                                                                \
