@@ -281,21 +281,27 @@ __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglob
     return true;
 }
 
-// the third rows of the projection matrices and the translation, pinned in VGPRs (see PinnedRows)
+// the third rows of the projection matrices and the translation, pinned in VGPRs (see PinnedRows).  They are read through the
+// constant address space -- scalar loads, all of them in flight at once, one wait -- and only then copied into VGPRs.  (Until
+// round 4 they were read through the plain pointer: six VECTOR loads, each followed by its own s_waitcnt vmcnt(0) because the
+// register pin right behind it consumes the value -- six dependent L2 round trips at the start of every wave, in front of its
+// first plane request.  The caller now also asks for them AFTER the item's first loads have been issued.)
 template <int RIG>
 __device__ __forceinline__ PinnedRows pinned_rows(const DevCal *Cglobal)
 {
+    const auto *C = opaque_const(Cglobal);
     PinnedRows PR;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        PR.c2[j] = RIG != 0 ? 0.0 : Cglobal->Ac[8 + j];
-        PR.p2[j] = RIG != 0 ? Cglobal->Apc[8 + j] : Cglobal->Ap[8 + j];
+        PR.c2[j] = RIG != 0 ? 0.0 : C->Ac[8 + j];
+        PR.p2[j] = RIG != 0 ? C->Apc[8 + j] : C->Ap[8 + j];
+        if (j < 3) PR.t[j] = RIG != 0 ? C->tcn[j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
         if (RIG == 0) asm volatile("" : "+v"(PR.c2[j]));
         asm volatile("" : "+v"(PR.p2[j]));  // stay in VGPRs
-        if (j < 3) {
-            PR.t[j] = RIG != 0 ? Cglobal->tcn[j] : 0.0;
-            if (RIG != 0) asm volatile("" : "+v"(PR.t[j]));
-        }
+        if (j < 3 && RIG != 0) asm volatile("" : "+v"(PR.t[j]));
     }
     return PR;
 }
@@ -675,7 +681,6 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     constexpr bool EARLY = !RCPT && PIPE;
     constexpr bool UNROLL = !RCPT;  // the small-launch instantiation: both pixel pairs of phases A and B in one basic block (see phase_A)
 
-    const PinnedRows PR = pinned_rows<RIG>(Cglobal);
     // EXACT: both axes have exactly NMAX Gray planes (the usual case)
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
     const bool proj_table = RIG == 2 || (RIG == 0 && !KEEP && P.proj_disp != nullptr);
@@ -706,6 +711,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             issue_gray<NMAX, EXACT>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
         }
     }
+    const PinnedRows PR = pinned_rows<RIG>(Cglobal);  // (stage 7 needs them; by now the item's first memory requests are on their way)
     for (int view = it.v_begin; view < it.v_end; view++) {
         unsigned vbits;
         if (PIPE) {
