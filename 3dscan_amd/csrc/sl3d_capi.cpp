@@ -134,6 +134,10 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
 #endif
     P.pitch = (c.width + 15) & ~15;
     P.planes_per_view = 2 * P.F + 2 * P.Nv + 2 * P.Nh;
+    if ((size_t)P.pitch * (size_t)P.H >= ((size_t)1 << 32)) {  // the kernels address a plane with 32-bit byte offsets
+        sl3d_destroy(x);
+        return fail(nullptr, SL3D_E_UNSUPPORTED, "window too large: a plane must stay below 4 GiB (split it into row stripes)");
+    }
     P.plane_stride = (size_t)P.pitch * P.H;
     P.view_stride = (size_t)P.planes_per_view * P.plane_stride;
     P.mpitch = P.pitch + 2 * SL3D_MASK_LPAD;

@@ -238,13 +238,15 @@ template <int RIG, bool SEG, bool EARLY, int BLK = SL3D_BLOCK>
 __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglobal, unsigned tile_, int group, int first_view, int n_views, int vpt, Item &it,
                                            MaskQuad &mq_first, double (&camt)[8], double *my_cam)
 {
-    const int qpr = P.pitch >> 2;  // quads per row, pitch padding included
+    const unsigned qpr = (unsigned)P.pitch >> 2;  // quads per row, pitch padding included
     it.tile = tile_;
     it.v_begin = first_view + group * vpt;  // (block-uniform values first: nothing below may make them look divergent)
     it.v_end = min(it.v_begin + vpt, first_view + n_views);
-    const long q = (long)tile_ * BLK + threadIdx.x;
+    // (32-bit unsigned: a window has fewer than 2^32 quads -- sl3d_create checks it -- and a 64-bit division by a run-time
+    // value is ~120 instructions at the start of every wave)
+    const unsigned q = tile_ * (unsigned)BLK + threadIdx.x;
     const int row_q = (int)(q / qpr);
-    it.cq = (int)(q - (long)row_q * qpr);
+    it.cq = (int)(q - (unsigned)row_q * qpr);
     // SEG: a wave stores its segment with all 64 lanes (whole 16-byte chunks, lane after lane), so the lanes past the last row
     // stay, without a valid pixel; only the blocks the grid was padded with leave (they own no segment)
     if (SEG && tile_ >= (unsigned)P.n_tiles) return false;
@@ -459,17 +461,28 @@ __device__ __forceinline__ void phase_B(const KParams &P, const DevCal *Cglobal,
 {
     const float nanv = __builtin_nanf("");
     unsigned vb = vout;
+    // The pair index reaches the staging addresses through a VGPR.  With the loop counter in an SGPR the rolled loop's address
+    // `base + 24*j` became a v_mad_u64_u32 whose 64-bit addend pairs the LDS base with WHATEVER sits in the next VGPR -- the mask
+    // dword just requested -- and that false read of a pending load put an s_waitcnt vmcnt(0) at the top of this loop: stage 7
+    // waited for every plane of the next view (round 4, read in the ISA).
+    // (so the offset of a pair inside the lane's 48-byte staging slot, 24*j, is built from shifts of a VGPR copy of j, with an
+    // empty asm in between that keeps the optimiser from folding them back into a multiply)
 #pragma unroll(UNROLL ? 2 : 1)
     for (int j = 0; j < 2; j++) {
+        int j8 = j * 8;  // bytes
+        if (!UNROLL) asm volatile("" : "+v"(j8));
+        const int pair_words = UNROLL ? 6 * j : ((j8 << 1) + j8) >> 2;  // 6 floats per pair
+        const int *cp = my_cp + pair_words;
+        float *xyz = my_xyz + pair_words;
+        const double *cam = my_cam + (UNROLL ? 4 * j : j8 >> 1);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const int k = 2 * j + i;
             float x, y, z;
-            triangulate_from<RIG>(P, opaque_const(Cglobal), PR, my_cam[2 * k], my_cam[2 * k + 1], my_cp[3 * k], my_cp[3 * k + 1], d[i], proj_table, x, y, z);
+            triangulate_from<RIG>(P, opaque_const(Cglobal), PR, cam[2 * i], cam[2 * i + 1], cp[3 * i], cp[3 * i + 1], d[i], proj_table, x, y, z);
             const bool ok = ((vb >> (8 * i)) & 1u) != 0u;
-            my_xyz[3 * k + 0] = ok ? x : nanv;
-            my_xyz[3 * k + 1] = ok ? y : nanv;
-            my_xyz[3 * k + 2] = ok ? z : nanv;
+            xyz[3 * i + 0] = ok ? x : nanv;
+            xyz[3 * i + 1] = ok ? y : nanv;
+            xyz[3 * i + 2] = ok ? z : nanv;
         }
         d[0] = d[2];
         d[1] = d[3];
@@ -712,6 +725,19 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         }
     }
     const PinnedRows PR = pinned_rows<RIG>(Cglobal);  // (stage 7 needs them; by now the item's first memory requests are on their way)
+    // DEFER: the results of view v leave AFTER the decode of view v + 1 instead of right behind stage 7.  gfx950 has ONE in-order
+    // vmcnt for loads and stores: stores issued behind the next view's plane loads are what that view's decode ends up waiting for
+    // (its last s_waitcnt vmcnt(0) = planes landed AND those stores acknowledged).  Deferred, they are issued once the planes have
+    // been consumed and have a whole view's arithmetic to complete: 4 views per launch +0.7 %, 12 Mpx x 3 views +1 %, 16 views
+    // and the table rig +0.3 % (profiles/r04_pipeline_point_ab.txt); the staged results wait in LDS, which phase A of the next view
+    // only touches after the store.
+    constexpr bool DEFER = PIPE;
+    unsigned pvout = 0;
+    auto store_view = [&](int v, unsigned vo) {
+        const size_t p = (size_t)v * P.px_view_stride + (size_t)it.lane_off;
+        if (SEG) store_segment(P, it, v, p, vo, s_xyz, my_xyz);
+        else store_quad<KEEP>(P, s_xyz, my_xyz, p, vo);
+    };
     for (int view = it.v_begin; view < it.v_end; view++) {
         unsigned vbits;
         if (PIPE) {
@@ -723,7 +749,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         const size_t px = (size_t)view * P.px_view_stride + (size_t)it.lane_off;  // first pixel of the quad
         unsigned vout = 0;
         if (KEEP) parity_init(P, px, vbits);
-        if (!SEG && (KEEP || vbits == 0)) fill_nan(my_xyz);
+        if (!DEFER && !SEG && (KEEP || vbits == 0)) fill_nan(my_xyz);
         if (!PIPE && vbits != 0) {  // every load of the view is issued before the first one is consumed
             issue_fringe<FGEN>(P, view, it.lane_off, F, Nv, f);
             issue_gray<NMAX, EXACT>(P, view, it.lane_off, F, Nv, Nh, g, iv);
@@ -731,6 +757,10 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         if (view == it.v_begin) SL3D_STAMP(3);
         if (vbits != 0) decode_gray<NMAX>(g, iv, Nv, Nh, code);  // waits for the planes of this view
         if (view == it.v_begin) SL3D_STAMP(4);
+        if (DEFER) {
+            if (view > it.v_begin) store_view(view - 1, pvout);
+            if (!SEG && vbits == 0) fill_nan(my_xyz);
+        }
         if (vbits != 0) {
             if (KEEP) vout = parity_pixels<RCPT>(P, Cglobal, PR, it, F, vbits, f, code, s_rcp, my_cam, my_xyz, px);
             else vout = phase_A<RCPT, UNROLL>(P, it, F, vbits, f, code, s_rcp, my_cp);
@@ -741,7 +771,12 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         // built and measured: distorted rig 77.8-78.2 Gpx/s against 79.0-79.5 for this order, profiles/r03_gather_first_ab.txt.)
         if (PIPE && view + 1 < it.v_end) {
             vb_next = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
-            if (view + 2 < it.v_end) mq = load_mask_quad(P, view + 2, it.cq, it.row);
+            // UNCONDITIONAL (the index is clamped; the last view's dword is asked for once more): with `if (view + 2 < v_end)` the
+            // new value meets the old one in a phi, whose copy the compiler places behind the plane loads below -- and a copy of a
+            // loaded value is a use: s_waitcnt vmcnt(0), i.e. stage 7 of this view waited for ALL of the next view's planes to land
+            // (round 3 read this wait in the ISA and measured a schedule without it at +-0.3 %; with today's kernel: 4 views per
+            // launch +5 %, 16 views +1 %, the table rig +1.5 %, profiles/r04_pipeline_point_ab.txt)
+            mq = load_mask_quad(P, min(view + 2, it.v_end - 1), it.cq, it.row);
             if (vb_next != 0) {
                 issue_fringe<FGEN>(P, view + 1, it.lane_off, F, Nv, f);
                 issue_gray<NMAX, EXACT>(P, view + 1, it.lane_off, F, Nv, Nh, g, iv);
@@ -752,6 +787,10 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             gather_B(P, proj_table, my_cp, d);
             phase_B<RIG, UNROLL>(P, Cglobal, PR, proj_table, vout, d, my_cam, my_cp, my_xyz);
         }
+        if (DEFER) {
+            pvout = vout;
+            continue;
+        }
         if (SEG) {
             store_segment(P, it, view, px, vout, s_xyz, my_xyz);
             continue;
@@ -760,6 +799,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         store_quad<KEEP>(P, s_xyz, my_xyz, px, vout);
         if (view == it.v_begin) SL3D_STAMP(7);
     }
+    if (DEFER) store_view(it.v_end - 1, pvout);
 }
 
 // ---- launch plumbing -------------------------------------------------------------------------------------------------------------
