@@ -344,12 +344,18 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     HIPCHK(x, hipStreamSynchronize(x->stream));  // no launch may still be reading the previous constants
     HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
     // rig class of the timed fused kernel (pixel_chain): 1 = the reference's kind of calibration, 2 = distorted projector
-    // behind a per-calibration undistortion table, 0 = everything else, evaluated in the kernel
+    // behind a per-calibration undistortion table, 3 = a plain projector K with a purely radial model (a 4-KB table of the
+    // radial factor, in LDS; 3-step fringes), 0 = everything else, evaluated in the kernel
     // (camera-frame solve: any upper-triangular affine camera matrix -- a skew term included; only a K with a perspective row
     // or a non-zero K[1][0] is left to the general kernel)
     const bool cam_frame_ok = x->C.cam.affine && Kc[3] == 0.0;
     x->rig = !cam_frame_ok ? 0 : x->C.proj.identity ? 1 : 2;
+    if (x->rig == 2 && !x->keep && x->P.F == 3 && x->C.proj.plain && !x->C.proj.has_tan) x->rig = 3;
+#ifdef SL3D_MEASURE
+    if (x->rig == 3 && getenv("SL3D_NO_RIG3")) x->rig = 2;
+#endif
     x->P.proj_disp = nullptr;
+    x->P.proj_rad = nullptr;
     x->P.cam_tab = nullptr;
     x->P.cam_tab_kind = 0;
     if (!x->keep && x->C.cam.has_dist) {  // timed mode: T1 of the camera per window pixel (k_cam_table)
@@ -370,7 +376,22 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
         x->P.cam_tab = x->d_cam_tab;
         x->P.cam_tab_kind = kind;
     }
-    if (!x->C.proj.identity && !x->keep) {  // a distorted projector (rig 2, or rig 0 in the timed mode)
+    if (x->rig == 3) {
+        // the radial factor over r0^2 in [0, r2max]: r2max from the projector pixel farthest from the principal point
+        if (!x->d_proj_rad) {
+            HIPCHK(x, hipMalloc((void **)&x->d_proj_rad, (size_t)SL3D_RAD_COPIES * SL3D_RAD_STRIDE * sizeof(RadEntry)));
+            x->allocs.push_back(x->d_proj_rad);
+        }
+        const Intr &I = x->C.proj;
+        const double ex = std::max(std::fabs(0.0 - I.cx), std::fabs((double)(x->cfg.proj_width - 1) - I.cx)) * std::fabs(I.ifx);
+        const double ey = std::max(std::fabs(0.0 - I.cy), std::fabs((double)(x->cfg.proj_height - 1) - I.cy)) * std::fabs(I.ify);
+        const double r2max = (ex * ex + ey * ey) * (1.0 + 1e-9) + 1e-300;
+        const int st = launch_radial_table(x->d_cal, 1, r2max, x->d_proj_rad, x->stream);
+        if (st) return fail(x, SL3D_E_HIP, std::string("k_radial_table: ") + hipGetErrorString((hipError_t)st));
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+        x->P.proj_rad = x->d_proj_rad;
+        x->P.proj_rad_scale = (float)((SL3D_RAD_NODES - 1) / r2max);
+    } else if (!x->C.proj.identity && !x->keep) {  // a distorted projector (rig 2, or rig 0 in the timed mode)
         if (!x->d_proj_disp) {
             HIPCHK(x, hipMalloc((void **)&x->d_proj_disp, (size_t)x->cfg.proj_width * x->cfg.proj_height * sizeof(float2)));
             x->allocs.push_back(x->d_proj_disp);

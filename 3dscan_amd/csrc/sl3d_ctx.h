@@ -55,6 +55,7 @@ struct sl3d_ctx {
     double *d_cam_tab = nullptr;              // timed mode: camera-side T1 table of the window (sl3d_set_calibration)
     size_t cam_tab_doubles = 0;
     float2 *d_proj_disp = nullptr;            // RIG 2: projector undistortion table (allocated when a distorted projector is set)
+    RadEntry *d_proj_rad = nullptr;           // RIG 3: the projector's radial table, SL3D_RAD_COPIES copies
     uint8_t *d_pattern = nullptr, *d_profile = nullptr;  // projector pattern image + its 1-D profile (allocated on first use)
     size_t pattern_pitch = 0;
     uint8_t *d_colrow = nullptr;  // staging of one global in the reference's [col][row] layout (sl3d_get_global_colrow), and of a

@@ -98,13 +98,7 @@ struct MaskQuad {
     unsigned band;
 };
 
-__device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, int cq, int row)
-{
-    MaskQuad m;
-    const unsigned *bp = (const unsigned *)(P.band + (size_t)view * P.px_view_stride + (size_t)row * P.pitch + cq * 4);
-    m.band = *bp;  // read once per view, by one lane (the non-temporal hint on it was measured: 361.8-362.8 us against 359.4-359.9)
-    return m;
-}
+__device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, unsigned lane_off);  // (below, with the addressing helpers)
 
 __device__ __forceinline__ unsigned mask_quad_bits(const MaskQuad &m)
 {
@@ -297,6 +291,31 @@ __device__ __forceinline__ void undistort_normalized(double px, double py, const
     yo = y;
 }
 
+// The same iteration for a purely radial model as a function of r0^2 = x0^2 + y0^2 alone: every iterate is (x0, y0) times a
+// factor, so r_j^2 = r0^2 * icd_(j-1)^2 and the result is (x0, y0) * icd_5.  Returns icd_5 - 1 (radial tables, RadEntry).
+template <typename IntrT>
+__device__ __forceinline__ double radial_factor_m1(double r0sq, const IntrT &I)
+{
+    double r2 = r0sq, icd = 1.0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        icd = recip(fma(fma(fma(I.k3, r2, I.k2), r2, I.k1), r2, 1.0));
+        r2 = r0sq * icd * icd;
+    }
+    return icd - 1.0;
+}
+
+// s(r0^2) from a radial table (RadEntry, here in LDS): the node nearest to r0^2 * scale, one 16-byte read, one float FMA + multiply,
+// one double add
+__device__ __forceinline__ double radial_lookup(const RadEntry *tab, float scale, double r0sq)
+{
+    const float t = (float)r0sq * scale;
+    const int i = min(__float2int_rn(t), SL3D_RAD_NODES - 1);  // (a rejected pixel's harmless index 0 and anything past the table end: clamped)
+    const float w = t - (float)i;
+    const RadEntry e = tab[i];
+    return e.c0 + (double)(fmaf(e.c2, w, e.c1) * w);
+}
+
 // K * (x, y, 1) and the homogeneous divide
 template <typename IntrT>
 __device__ __forceinline__ void reproject(double x, double y, const IntrT &I, double &u, double &v)
@@ -439,6 +458,41 @@ __device__ __forceinline__ unsigned ldg32(const GLOBAL_AS uint8_t *base, unsigne
 {
     asm volatile("" : "+s"(base));
     return __builtin_nontemporal_load((const GLOBAL_AS unsigned *)(base + (size_t)off));
+}
+
+// the same form for a cached load and for streaming stores: (wave-uniform base in SGPRs) + (32-bit lane offset); with the base
+// hidden, nothing of the address is loop-invariant VGPR state (hoisted base + lane offset pairs were what the register allocator
+// spilled in the small-launch instantiations)
+__device__ __forceinline__ unsigned ldg32_cached(const GLOBAL_AS uint8_t *base, unsigned off)
+{
+    asm volatile("" : "+s"(base));
+    return *(const GLOBAL_AS unsigned *)(base + (size_t)off);
+}
+// (the builtin is int -> int: widened directly, its result would be SIGN-extended)
+__device__ __forceinline__ unsigned first_lane_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+template <typename T>
+__device__ __forceinline__ void stg_nt(GLOBAL_AS uint8_t *base, unsigned off, T v)
+{
+    asm volatile("" : "+s"(base));
+    __builtin_nontemporal_store(v, (GLOBAL_AS T *)(base + (size_t)off));
+}
+template <typename T>
+__device__ __forceinline__ GLOBAL_AS uint8_t *opaque_out(T *p)
+{
+    // (wave-uniform by construction; said explicitly, because the divergence analysis does not always see it -- folded away where it does)
+    unsigned long long u = (unsigned long long)p;
+    u = ((unsigned long long)first_lane_u32((unsigned)(u >> 32)) << 32) | (unsigned long long)first_lane_u32((unsigned)u);
+    asm volatile("" : "+s"(u));
+    return (GLOBAL_AS uint8_t *)u;
+}
+
+// the valid-map dword of the lane's quad (lane_off = byte offset of the quad inside any plane of a view)
+__device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, unsigned lane_off)
+{
+    MaskQuad m;
+    // read once per view, by one lane (the non-temporal hint on it was measured: 361.8-362.8 us against 359.4-359.9)
+    m.band = ldg32_cached(opaque(P.band + (size_t)view * P.px_view_stride), lane_off);
+    return m;
 }
 
 }  // namespace sl3d

@@ -61,6 +61,10 @@ namespace sl3d {
 //   2  the same camera, any other projector: camera-frame least squares; the undistorted projector point comes from the
 //      per-calibration table KParams::proj_disp (one float2 displacement per projector pixel, built by k_proj_table with
 //      the same 5-iteration undistortion) -- the reference also tabulates it (7/triangulation.cpp:363-378), per scan
+//   3  the same camera, a projector with a plain K and a purely RADIAL distortion model (both of the reference's own OpenCV projector
+//      calibrations are): the undistorted point is pixel + (pixel - principal point) * s(r0^2), s from a 4-KB table of node
+//      quadratics over r0^2 (RadEntry, k_radial_table) that every block copies into LDS -- no global gather in stage 7, so it runs
+//      under the next view's plane loads like rig 1 (rig 2's four gathers sit BEHIND those loads in the in-order vmcnt queue)
 
 // ---- parity mode: one pixel, everything after the byte loads (stage 4 unwrap, stage 5, stage 7, stage 8 cast), every
 // stage-boundary value stored where the reference keeps it.  (cu,cv) = undistorted camera pixel coordinates of this pixel
@@ -144,13 +148,19 @@ __device__ __forceinline__ bool correspond_px(const KParams &P, int gx, int gy, 
 
 template <int RIG, typename CalP>
 __device__ __forceinline__ void triangulate_from(const KParams &P, CalP Cp, const PinnedRows &PR, double cu, double cv, int cx, int cy, float2 d, bool table,
-                                                 float &x, float &y, float &z)
+                                                 const RadEntry *s_rad, float &x, float &y, float &z)
 {
     const auto &C = *Cp;
     const double cxd = (double)cx, cyd = (double)cy;
     double X[3];
     bool singular = false;
-    if (RIG == 1) {
+    if (RIG == 3) {
+        // K * ((x0, y0) * (1 + s)) with a plain K: fx*x0 + cx is the pixel itself, so the undistorted point is pixel + (pixel - c) * s
+        const double dx = cxd - C.proj.cx, dy = cyd - C.proj.cy;
+        const double x0 = dx * C.proj.ifx, y0 = dy * C.proj.ify;
+        const double s = radial_lookup(s_rad, P.proj_rad_scale, fma(x0, x0, y0 * y0));
+        triangulate_camframe(C, PR, cu, cv, fma(dx, s, cxd), fma(dy, s, cyd), X, singular);
+    } else if (RIG == 1) {
         // the projector's undistort + re-project is fx*((x-cx)*(1/fx)) + cx, i.e. x itself up to 2-3 ulp (1e-13 px),
         // and (cu,cv) are the camera's undistorted NORMALISED coordinates for the camera-frame solve
         triangulate_camframe(C, PR, cu, cv, cxd, cyd, X, singular);
@@ -258,7 +268,7 @@ __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglob
     it.lane_off = (unsigned)it.row * (unsigned)P.pitch + (unsigned)it.cq * 4u;
     // the valid bits of the item's first view are requested now, so that they travel together with the camera table
     // entries below instead of after them (one round trip less before the first plane loads can leave)
-    mq_first = load_mask_quad(P, min(it.v_begin, first_view + n_views - 1), it.cq, it.row);
+    mq_first = load_mask_quad(P, min(it.v_begin, first_view + n_views - 1), it.lane_off);
     if (EARLY && P.use_cam_table) {
         cam_table_request(P, it, camt);
         return true;
@@ -443,6 +453,41 @@ __device__ __forceinline__ unsigned phase_A(const KParams &P, const Item &it, in
     return vout;
 }
 
+// SPLIT (the pipelined small-launch instantiations): stage 3 of the lane's 4 pixels runs BEFORE the Gray planes are waited for.
+// The fringe planes are the first 6 of a view's 46 requests and vmcnt counts in issue order, so the 8 wrapped phases (8 floats) need
+// s_waitcnt vmcnt(40) only -- the atan2 arithmetic, most of phase A, runs while the wave's Gray planes are still on their way.  In a
+// launch of one view per lane every wave of a round asks for its planes at the same time and would then compute at the same time:
+// this is arithmetic moved under the wave's OWN memory wait.
+template <bool RCP_TAB>
+__device__ __forceinline__ void wrapped_quad(int F, const unsigned (&f)[2][4], const double *s_rcp, float (&w)[2][4])
+{
+    const AtanK AK = atan_consts<true>();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int sh = 8 * k;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+            w[a][k] = shift_pi(wrapped_phase<RCP_TAB>(F, (f[a][0] >> sh) & 255, (f[a][1] >> sh) & 255, (f[a][2] >> sh) & 255, (f[a][3] >> sh) & 255, s_rcp, AK));
+    }
+}
+
+// stages 4 + 5 of the 4 pixels from their wrapped phases and Gray codes (the rest of phase A behind wrapped_quad); -> valid byte of pixel k at byte k
+__device__ __forceinline__ unsigned correspond_quad(const KParams &P, const Item &it, unsigned vbits, const float (&w)[2][4], const unsigned (&code)[2][2], int *my_cp)
+{
+    unsigned vout = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int code_v = (int)((code[0][k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        const int code_h = (int)((code[1][k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        int cx, cy;
+        const bool ok = correspond_px(P, it.gx0 + k, it.gy, w[0][k], w[1][k], code_v, code_h, cx, cy) && ((vbits >> k) & 1u);
+        my_cp[3 * k] = ok ? cx : 0;
+        my_cp[3 * k + 1] = ok ? cy : 0;
+        vout |= (ok ? 1u : 0u) << (8 * k);
+    }
+    return vout;
+}
+
 // ---- phase B: stage 7 + the cast of stage 8 ------------------------------------------------------------------------------------
 // neighbouring camera pixels see neighbouring projector pixels: the 4 gathers stay within a few cache lines per wave
 __device__ __forceinline__ void gather_B(const KParams &P, bool proj_table, const int *my_cp, float2 (&d)[4])
@@ -457,7 +502,7 @@ __device__ __forceinline__ void gather_B(const KParams &P, bool proj_table, cons
 
 template <int RIG, bool UNROLL>
 __device__ __forceinline__ void phase_B(const KParams &P, const DevCal *Cglobal, const PinnedRows &PR, bool proj_table, unsigned vout, float2 (&d)[4],
-                                        const double *my_cam, const int *my_cp, float *my_xyz)
+                                        const double *my_cam, const int *my_cp, float *my_xyz, const RadEntry *s_rad)
 {
     const float nanv = __builtin_nanf("");
     unsigned vb = vout;
@@ -478,7 +523,7 @@ __device__ __forceinline__ void phase_B(const KParams &P, const DevCal *Cglobal,
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             float x, y, z;
-            triangulate_from<RIG>(P, opaque_const(Cglobal), PR, cam[2 * i], cam[2 * i + 1], cp[3 * i], cp[3 * i + 1], d[i], proj_table, x, y, z);
+            triangulate_from<RIG>(P, opaque_const(Cglobal), PR, cam[2 * i], cam[2 * i + 1], cp[3 * i], cp[3 * i + 1], d[i], proj_table, s_rad, x, y, z);
             const bool ok = ((vb >> (8 * i)) & 1u) != 0u;
             xyz[3 * i + 0] = ok ? x : nanv;
             xyz[3 * i + 1] = ok ? y : nanv;
@@ -570,14 +615,20 @@ __device__ __forceinline__ void store_quad(const KParams &P, const float *s_xyz,
     if (!(SL3D_ABLATE & 4) || KEEP || sx[0].x == 12345.f) {
         if (!KEEP && __ballot(true) == ~0ull) {
             wave_lds_handoff();
-            const unsigned lane_ = threadIdx.x & 63u;
+            // wave-uniform parts as scalars (the wave's number, the first lane's pixel = the start of the wave's run): the store
+            // addresses are an SGPR base + a 32-bit lane offset, nothing of them lives in VGPRs across the view loop
+            unsigned lane_ = threadIdx.x & 63u;
+            asm volatile("" : "+v"(lane_));  // (recomputed here: hoisted out of the view loop the lane offsets were kept as 64-bit pairs, and spilled)
+            const unsigned wave_ = first_lane_u32(threadIdx.x >> 6);
+            const size_t px0 = ((size_t)first_lane_u32((unsigned)(px >> 32)) << 32) | (size_t)first_lane_u32((unsigned)px);
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 *w4 = (const f32x4 *)(s_xyz + (threadIdx.x >> 6) * (64u * 12u));
-            f32x4 *q4 = (f32x4 *)(P.points + 3 * (px - 4u * lane_));
-            __builtin_nontemporal_store(w4[lane_], q4 + lane_);
-            __builtin_nontemporal_store(w4[64u + lane_], q4 + 64u + lane_);
-            __builtin_nontemporal_store(w4[128u + lane_], q4 + 128u + lane_);
-            __builtin_nontemporal_store(vout, (unsigned *)(P.valid + px));
+            const f32x4 *w4 = (const f32x4 *)(s_xyz + wave_ * (64u * 12u));
+            GLOBAL_AS uint8_t *q = opaque_out(P.points + 3 * px0);
+            const unsigned lo = lane_ * 16u;
+            stg_nt(q, lo, w4[lane_]);
+            stg_nt(q, lo + 1024u, w4[64u + lane_]);
+            stg_nt(q, lo + 2048u, w4[128u + lane_]);
+            stg_nt(opaque_out(P.valid + px0), lane_ * 4u, vout);
             wave_lds_handoff();  // ... and every lane has read them before the next view's phase A reuses the area
             return;
         }
@@ -605,16 +656,18 @@ __device__ __forceinline__ void fill_nan(float *my_xyz)
 // offsets, and the consumers that exist anyway close the gaps (k_seg_close into a contiguous device / mapped host buffer, the
 // registration, the pack before an RCCL send).  Lanes past the last row take part with no valid pixel.
 // (A chunk may run up to 3 floats past the last point: still inside the slot.)
-__device__ __forceinline__ void store_segment(const KParams &P, const Item &it, int view, size_t px, unsigned vout, float *s_xyz, const float *my_xyz)
+__device__ __forceinline__ void store_segment(const KParams &P, const Item &it, int view, unsigned vout, float *s_xyz, const float *my_xyz)
 {
-    if (it.alive) __builtin_nontemporal_store(vout, (unsigned *)(P.valid + px));
+    if (it.alive) stg_nt(opaque_out(P.valid + (size_t)view * P.px_view_stride), it.lane_off, vout);
     const unsigned long long b0 = __ballot((vout & 0x00000001u) != 0u), b1 = __ballot((vout & 0x00000100u) != 0u),
                              b2 = __ballot((vout & 0x00010000u) != 0u), b3 = __ballot((vout & 0x01000000u) != 0u);
     auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     unsigned rank = below(b0) + below(b1) + below(b2) + below(b3);  // valid pixels of the lanes below this one
     const unsigned total = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-    const unsigned lane_ = threadIdx.x & 63u, wave_ = threadIdx.x >> 6;
-    const unsigned seg = it.tile * 4u + wave_;
+    unsigned lane_ = threadIdx.x & 63u;
+    asm volatile("" : "+v"(lane_));  // (see store_quad: the wave's number, its segment and its slot are scalars, the lane index is recomputed)
+    const unsigned wave_ = first_lane_u32(threadIdx.x >> 6);
+    const unsigned seg = first_lane_u32(it.tile) * 4u + wave_;
     if (lane_ == 0u) P.seg_counts[(size_t)view * (size_t)P.n_segs + seg] = total;
     float *slot = P.clouds + 3 * ((size_t)view * P.px_view_stride + (size_t)seg * SL3D_SEG_POINTS);
     const float4 *sx = (const float4 *)my_xyz;
@@ -634,11 +687,11 @@ __device__ __forceinline__ void store_segment(const KParams &P, const Item &it, 
     const unsigned chunks = (3u * total + 3u) >> 2;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 *wb4 = (const f32x4 *)wbase;
-    f32x4 *out4 = (f32x4 *)slot;
+    GLOBAL_AS uint8_t *out = opaque_out(slot);
 #pragma unroll
     for (int c3 = 0; c3 < 3; c3++) {
         const unsigned i = (unsigned)c3 * 64u + lane_;
-        if (i < chunks) __builtin_nontemporal_store(wb4[i], out4 + i);
+        if (i < chunks) stg_nt(out, lane_ * 16u + (unsigned)c3 * 1024u, wb4[i]);
     }
     wave_lds_handoff();  // ... and read before the next view's phase A parks its correspondences in the same area
 }
@@ -650,6 +703,20 @@ __device__ __forceinline__ unsigned valid_bits(const Item &it, int F, const Mask
     if (SEG && !it.alive) return 0u;
     return (FGEN && F == 5) ? 0u : (!KEEP && (SL3D_ABLATE & 2)) ? 0xfu : mask_quad_bits(m);
 }
+
+// the LDS copy of rig 3's radial table (no byte of LDS in the kernels of the other rig classes)
+template <int RIG>
+struct RadialLds {
+    __device__ __forceinline__ static RadEntry *get() { return nullptr; }
+};
+template <>
+struct RadialLds<3> {
+    __device__ __forceinline__ static RadEntry *get()
+    {
+        __shared__ RadEntry tab[SL3D_RAD_NODES];
+        return tab;
+    }
+};
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------------
 // KEEP  parity mode: the stage-boundary planes are written too (RIG 0, dense results)
@@ -674,11 +741,14 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     __shared__ __attribute__((aligned(16))) float s_xyz[BLK * 12];  // staging area: correspondences, then xyz, of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_cam[BLK * 8];  // undistorted camera coordinates of the lane's 4 pixels
     __shared__ __attribute__((aligned(16))) double s_rcp[RCPT ? SL3D_RCP_TAB : 1];  // 1/d for the atan2 quotient
+    RadEntry *const s_rad = RadialLds<RIG>::get();                                  // rig 3: the projector's radial table
+    static_assert(RIG != 3 || SL3D_BLOCK == SL3D_RAD_NODES, "one table node per thread");
     SL3D_STAMP(0);
-    if (RCPT) {
-        fill_rcp_table(s_rcp);
-        __syncthreads();
-    }
+    // rig 3: one of the 8 copies of the table (one per XCD, as consecutive blocks go round the XCDs: all blocks of a launch would
+    // otherwise start on the same 32 cache lines of one L2 -- what cost the camera-side radial table 2 us per one-view launch)
+    if (RIG == 3) s_rad[threadIdx.x] = P.proj_rad[(blockIdx.x & 7u) * SL3D_RAD_STRIDE + threadIdx.x];
+    if (RCPT) fill_rcp_table(s_rcp);
+    if (RCPT || RIG == 3) __syncthreads();
     SL3D_STAMP(1);
     const int F = FGEN ? P.F : 3;
     float *my_xyz = s_xyz + threadIdx.x * 12;
@@ -693,6 +763,11 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     // plane loads for quads that turn out to be masked off (profiles/r03_early_planes_ab.txt)
     constexpr bool EARLY = !RCPT && PIPE;
     constexpr bool UNROLL = !RCPT;  // the small-launch instantiation: both pixel pairs of phases A and B in one basic block (see phase_A)
+#ifdef SL3D_NO_SPLIT
+    constexpr bool SPLIT = false;
+#else
+    constexpr bool SPLIT = EARLY;   // ... and stage 3 ahead of the wait for the Gray planes (wrapped_quad)
+#endif
 
     // EXACT: both axes have exactly NMAX Gray planes (the usual case)
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
@@ -718,7 +793,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     unsigned vb_next = 0;
     if (PIPE) {
         vb_next = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
-        if (it.v_begin + 1 < it.v_end) mq = load_mask_quad(P, it.v_begin + 1, it.cq, it.row);
+        if (it.v_begin + 1 < it.v_end) mq = load_mask_quad(P, it.v_begin + 1, it.lane_off);
         if (!EARLY && vb_next != 0) {  // (EARLY: they are in flight already)
             issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
             issue_gray<NMAX, EXACT>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
@@ -735,7 +810,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     unsigned pvout = 0;
     auto store_view = [&](int v, unsigned vo) {
         const size_t p = (size_t)v * P.px_view_stride + (size_t)it.lane_off;
-        if (SEG) store_segment(P, it, v, p, vo, s_xyz, my_xyz);
+        if (SEG) store_segment(P, it, v, vo, s_xyz, my_xyz);
         else store_quad<KEEP>(P, s_xyz, my_xyz, p, vo);
     };
     for (int view = it.v_begin; view < it.v_end; view++) {
@@ -744,7 +819,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             vbits = vb_next;
         } else {
             vbits = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
-            if (view + 1 < it.v_end) mq = load_mask_quad(P, view + 1, it.cq, it.row);
+            if (view + 1 < it.v_end) mq = load_mask_quad(P, view + 1, it.lane_off);
         }
         const size_t px = (size_t)view * P.px_view_stride + (size_t)it.lane_off;  // first pixel of the quad
         unsigned vout = 0;
@@ -755,6 +830,11 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             issue_gray<NMAX, EXACT>(P, view, it.lane_off, F, Nv, Nh, g, iv);
         }
         if (view == it.v_begin) SL3D_STAMP(3);
+        float w[2][4];
+        if (SPLIT && vbits != 0) {
+            wrapped_quad<RCPT>(F, f, s_rcp, w);          // waits for the 6 fringe planes
+            __builtin_amdgcn_sched_barrier(0);           // (the decode below is not to be scheduled up in front of this arithmetic)
+        }
         if (vbits != 0) decode_gray<NMAX>(g, iv, Nv, Nh, code);  // waits for the planes of this view
         if (view == it.v_begin) SL3D_STAMP(4);
         if (DEFER) {
@@ -763,6 +843,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         }
         if (vbits != 0) {
             if (KEEP) vout = parity_pixels<RCPT>(P, Cglobal, PR, it, F, vbits, f, code, s_rcp, my_cam, my_xyz, px);
+            else if (SPLIT) vout = correspond_quad(P, it, vbits, w, code, my_cp);
             else vout = phase_A<RCPT, UNROLL>(P, it, F, vbits, f, code, s_rcp, my_cp);
         }
         if (view == it.v_begin) SL3D_STAMP(5);
@@ -776,7 +857,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             // loaded value is a use: s_waitcnt vmcnt(0), i.e. stage 7 of this view waited for ALL of the next view's planes to land
             // (round 3 read this wait in the ISA and measured a schedule without it at +-0.3 %; with today's kernel: 4 views per
             // launch +5 %, 16 views +1 %, the table rig +1.5 %, profiles/r04_pipeline_point_ab.txt)
-            mq = load_mask_quad(P, min(view + 2, it.v_end - 1), it.cq, it.row);
+            mq = load_mask_quad(P, min(view + 2, it.v_end - 1), it.lane_off);
             if (vb_next != 0) {
                 issue_fringe<FGEN>(P, view + 1, it.lane_off, F, Nv, f);
                 issue_gray<NMAX, EXACT>(P, view + 1, it.lane_off, F, Nv, Nh, g, iv);
@@ -785,14 +866,14 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         if (!KEEP && vbits != 0) {
             float2 d[4];
             gather_B(P, proj_table, my_cp, d);
-            phase_B<RIG, UNROLL>(P, Cglobal, PR, proj_table, vout, d, my_cam, my_cp, my_xyz);
+            phase_B<RIG, UNROLL>(P, Cglobal, PR, proj_table, vout, d, my_cam, my_cp, my_xyz, s_rad);
         }
         if (DEFER) {
             pvout = vout;
             continue;
         }
         if (SEG) {
-            store_segment(P, it, view, px, vout, s_xyz, my_xyz);
+            store_segment(P, it, view, vout, s_xyz, my_xyz);
             continue;
         }
         if (view == it.v_begin) SL3D_STAMP(6);
@@ -866,9 +947,11 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
 void fused_dense_rig0(SL3D_FUSED_FAMILY_ARGS);
 void fused_dense_rig1(SL3D_FUSED_FAMILY_ARGS);
 void fused_dense_rig2(SL3D_FUSED_FAMILY_ARGS);
+void fused_dense_rig3(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig0(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig1(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig2(SL3D_FUSED_FAMILY_ARGS);
+void fused_clouds_rig3(SL3D_FUSED_FAMILY_ARGS);
 void fused_fgen(int rig, int cmode, SL3D_FUSED_FAMILY_ARGS);  // 4-step (and the all-invalid 5-step) fringes: the F test stays a run-time branch
 void fused_parity(bool fgen, SL3D_FUSED_FAMILY_ARGS);
 

@@ -32,9 +32,9 @@ static int views_per_lane(unsigned bx, int n_views, int cam_table_kind)
     return vpt;
 }
 
-static int timed_rig(const KParams &P, int rig) { return rig == 1 ? 1 : (rig == 2 && P.proj_disp) ? 2 : 0; }
+static int timed_rig(const KParams &P, int rig) { return rig == 1 ? 1 : (rig == 2 && P.proj_disp) ? 2 : (rig == 3 && P.proj_rad && P.F == 3) ? 3 : 0; }
 
-// rig: 0 / 1 / 2 (sl3d_fused.h; the host knows the calibration, the timed kernels fold it at compile time).
+// rig: 0 / 1 / 2 / 3 (sl3d_fused.h; the host knows the calibration, the timed kernels fold it at compile time).
 // cmode: 0 = dense xyz + valid planes, 2 = segmented clouds (KParams::clouds / seg_counts must be set).
 // Returns the hipError_t of THIS launch.
 int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream)
@@ -59,9 +59,9 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     } else if (P.F != 3) {
         fused_fgen(r, cmode, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
     } else if (cmode == 2) {
-        (r == 1 ? fused_clouds_rig1 : r == 2 ? fused_clouds_rig2 : fused_clouds_rig0)(P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+        (r == 1 ? fused_clouds_rig1 : r == 2 ? fused_clouds_rig2 : r == 3 ? fused_clouds_rig3 : fused_clouds_rig0)(P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
     } else {
-        (r == 1 ? fused_dense_rig1 : r == 2 ? fused_dense_rig2 : fused_dense_rig0)(P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+        (r == 1 ? fused_dense_rig1 : r == 2 ? fused_dense_rig2 : r == 3 ? fused_dense_rig3 : fused_dense_rig0)(P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
     }
     return (int)hipGetLastError();
 }

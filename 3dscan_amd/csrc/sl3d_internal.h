@@ -27,6 +27,18 @@ struct Intr {
     int identity;                 // plain and no distortion: undistort + re-project returns the pixel itself
 };
 
+// One node of a radial undistortion table: s(r0^2) = (factor of the last of the 5 fixed-point iterations of cvUndistortPoints) - 1 for a
+// purely radial model, as a quadratic around node i of a uniform grid over r0^2 (w = distance to the node in node spacings,
+// |w| <= 1/2):  s = c0 + (c1 + c2*w)*w.  The quadratic interpolates s at the node and at both cell boundaries, so neighbouring
+// cells agree where they meet; with SL3D_RAD_NODES nodes its remainder is ~1e-10 of the normalised coordinate.
+struct __attribute__((aligned(16))) RadEntry {
+    double c0;
+    float c1, c2;
+};
+#define SL3D_RAD_NODES 256
+#define SL3D_RAD_COPIES 8                      // copies of a table the kernels read (one per XCD)
+#define SL3D_RAD_STRIDE (SL3D_RAD_NODES + 16)  // entries between two copies: 4 KB + 256 B, so that the copies start on different channels
+
 // Per-scan constants of stage 7 (T0): A = K*[R|t] for camera and projector.
 struct DevCal {
     double Ac[12], Ap[12];
@@ -73,6 +85,8 @@ struct KParams {
     const uint8_t *mask;       // 0/1 bytes, halo included
     const uint8_t *band;       // [view][row][pitch]: final valid bytes of the quads within 3 px of the frame border (set_mask)
     const float2 *proj_disp;   // [PH][PW] undistorted-minus-raw projector point (set_calibration; NULL unless the projector is distorted)
+    const RadEntry *proj_rad;  // rig 3: SL3D_RAD_NODES nodes of a purely radial projector model over r0^2 in [0, (NODES - 1) / proj_rad_scale]
+    float proj_rad_scale;      // nodes per unit of r0^2
     const double *cam_tab;     // T1 of the camera per window pixel (set_calibration, timed mode): kind 1 = [H][pitch] factor of the last
                                // undistortion iteration (radial model), kind 2 = [H][pitch][2] normalised point (tangential terms)
     int cam_tab_kind;          // 0 = no table (no distortion: nothing to iterate)
@@ -118,6 +132,9 @@ int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *st
 int launch_to_colrow(const KParams &P, int view, int which, void *dst, void *stream);  // a global in the reference's [col][row] layout
 int launch_mask_from_colrow(const KParams &P, const int *sel, int gx0, int gy0, int ncols, int nrows, uint8_t *raw, void *stream);
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);
+// SL3D_RAD_COPIES copies (SL3D_RAD_STRIDE entries apart) of the SL3D_RAD_NODES nodes of the radial factor of the camera (which = 0) or
+// the projector (1) over r0^2 in [0, r2max]
+int launch_radial_table(const DevCal *d_cal, int which, double r2max, RadEntry *out, void *stream);
 int launch_cam_table(const KParams &P, const DevCal *d_cal, int kind, double *out, void *stream);
 int launch_wrap(const KParams &P, int view, int axis, void *stream);
 int launch_unwrap(const KParams &P, int view, int axis, void *stream);

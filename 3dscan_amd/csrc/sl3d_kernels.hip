@@ -225,6 +225,29 @@ int launch_cam_table(const KParams &P, const DevCal *d_cal, int kind, double *ou
     return (int)hipGetLastError();
 }
 
+// The radial table of a purely radial distortion model (RadEntry, sl3d_internal.h): node i sits at r0^2 = i * r2max / (NODES - 1);
+// its quadratic interpolates s = (last iteration's factor) - 1 at the node and at both cell boundaries (half a node spacing away),
+// each evaluated by the very iteration cvUndistortPoints runs (radial_factor_m1).
+__global__ __launch_bounds__(SL3D_RAD_NODES) void k_radial_table(const DevCal *__restrict__ C, int which, double node_spacing, RadEntry *__restrict__ out)
+{
+    const int i = (int)threadIdx.x;
+    const Intr &I = which == 0 ? C->cam : C->proj;
+    const double r2 = (double)i * node_spacing;
+    const double s0 = radial_factor_m1(r2, I), sm = radial_factor_m1(r2 - 0.5 * node_spacing, I), sp = radial_factor_m1(r2 + 0.5 * node_spacing, I);
+    RadEntry e;
+    e.c0 = s0;
+    e.c1 = (float)(sp - sm);                    // s(w) = s0 + w*(s+ - s-) + 2*w^2*(s+ + s- - 2*s0),  w in [-1/2, 1/2]
+    e.c2 = (float)(2.0 * (sp + sm - 2.0 * s0));
+    out[(size_t)blockIdx.x * SL3D_RAD_STRIDE + i] = e;
+}
+
+int launch_radial_table(const DevCal *d_cal, int which, double r2max, RadEntry *out, void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_radial_table, dim3(SL3D_RAD_COPIES), dim3(SL3D_RAD_NODES), 0, (hipStream_t)stream, d_cal, which, r2max / (double)(SL3D_RAD_NODES - 1), out);
+    return (int)hipGetLastError();
+}
+
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream)
 {
     hipLaunchKernelGGL(k_proj_table, dim3((PW + 255) / 256, PH), dim3(256), 0, (hipStream_t)stream, d_cal, PW, PH, out);

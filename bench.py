@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--precondition-ms", type=float, default=400.0,
                     help="part of the SETUP, before the W warm-up steps: run the kernel for this long so that the clocks have "
                          "left the idle state whatever W is (the package is power-managed; see profiles/README.md). 0 disables")
-    ap.add_argument("--rig", default="reference", choices=["reference", "distorted", "general"],
+    ap.add_argument("--rig", default="reference", choices=["reference", "distorted", "radial", "general"],
                     help="reference = the reference's calibration rescaled (BASELINE workload); distorted = the same rig with "
                          "projector distortion and camera tangential terms (table path); general = skewed camera matrix as well "
                          "(everything evaluated in the kernel) -- the other two are sweeps / side figures only")
@@ -179,6 +179,8 @@ def rig_calibration(syn, np, rig, W, H, PW, PH):
     if rig in ("distorted", "general"):
         cal_d["dp"] = np.array([-0.05, 0.02, 0.001, -0.0005, 0.0])
         cal_d["dc"] = np.array(cal_d["dc"], dtype=np.float64) + np.array([0.0, 0.0, 0.0008, -0.0006, 0.0])
+    if rig == "radial":   # a projector with k1, k2 only, as both of the reference's OpenCV projector calibrations are (RIG 3)
+        cal_d["dp"] = np.array([-0.05, 0.02, 0.0, 0.0, 0.0])
     if rig == "general":
         Kc = np.array(cal_d["Kc"], dtype=np.float64).reshape(3, 3).copy()
         Kc[0, 1] = 0.35   # skew: the camera matrix is no longer "plain", so the camera-frame solve does not apply (RIG 0)
@@ -245,7 +247,7 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
         alg = 20 + 4 * N
         # what this launch really moves: the camera-side table (8 B/px for the radial model of the reference rig, 16 with tangential
         # terms) is read once per LAUNCH, and nothing amortises it when a launch is one view
-        tab = 8 if args.rig == "reference" else 16
+        tab = 8 if args.rig in ("reference", "radial") else 16
         moved = alg + tab
         return {"value": round(W * H / ms / 1e3, 1), "unit": "Mpixels/s", "launch_us": round(ms * 1e3, 2), "kernel": sc.fused_kernel_name(1, clouds=clouds),
                 "frac": round(alg * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": alg,
@@ -282,7 +284,7 @@ def side_figures(args, scm, syn, np, dev_index):
         out["one_view_cold_clouds"] = one_view_cold(args, scm, syn, np, dev_index, launches=1000, clouds=True)
         # (distorted: projector k1,k2,p1,p2 + camera tangential terms; general: a skewed camera matrix as well -- since round 3 both
         # take the pipelined table kernel, RIG 2; the un-pipelined general kernel is left with perspective rows in K)
-        for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig2_general_skewed_camera")):
+        for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig2_general_skewed_camera"), ("radial", "rig3_radial_projector")):
             with ctx(rig, N, args.views) as sc:
                 v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 400)
                 out[key] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms}

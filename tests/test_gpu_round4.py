@@ -166,8 +166,8 @@ def _alt_projector_cal(name, W, H, PW, PH):
 def test_reference_distorted_projector_calibrations(name):
     """Projector_calibration/Matrices/OPencv calib/{Sharp,Viewsonic}: k1 = -1.01 / -1.16, k2 = 8.28 / 2.60 -- an order of magnitude
     stronger than the synthetic distortions of the other tests, and radial only.  1080p camera, 1280x720 projector (the files'
-    own size), two views (full mask; holes): the timed mode (camera-frame solve + the projector's undistortion table,
-    7/triangulation.cpp:352-378) and the parity mode (the 5 iterations evaluated per pixel) against the oracle on the frames the
+    own size), two views (full mask; holes): the timed mode (camera-frame solve + the projector's radial table in LDS, the rig
+    class 3 kernels; 7/triangulation.cpp:352-378) and the parity mode (the 5 iterations evaluated per pixel) against the oracle on the frames the
     context processed -- valid map and correspondences bit exact, points within 1e-5; the observed error of the table path is
     printed (pytest -s) and bounded well below the bar."""
     from oracle.oracle import Oracle
@@ -179,7 +179,7 @@ def test_reference_distorted_projector_calibrations(name):
     worst = 0.0
     with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=2) as sc:
         sc.set_calibration(*cal)
-        assert ", 1, 0, " not in sc.fused_kernel_name(2)        # not the undistorted-projector instantiation
+        assert ", 3, 0, " in sc.fused_kernel_name(2)            # radial only: the LDS-table instantiation (rig class 3)
         for v, m in enumerate(masks):
             sc.set_mask(m, view=v)
             sc.synth_view(v, plane=(2.0 * v, 0.05, 0.04), view_id=v, noise=2)
@@ -225,3 +225,45 @@ def test_reference_distorted_projector_calibrations(name):
     assert np.array_equal(cpm[ov], o.c_p_map()[ov])
     assert_points_close(ip, o.intersection_points(), ov)
     assert_points_close(xyz, o.intersection_points(), ov)
+
+
+# ---- a context larger than 4 GiB: results do not depend on where in the address space a view lies -------------------------------
+def test_views_across_4gib_boundaries():
+    """The kernels address a view's planes and results as (wave-uniform 64-bit base) + (32-bit lane offset).  400 views of 1 Mpx keep
+    5 GB of points and 20 GB of frames in single allocations, so the bases of the views picked here differ in every one of the address
+    bits 31..34 (a base whose low half has bit 31 set once came back sign-extended from a scalar read: intermittent faults, caught
+    by the A/B runs, not by a test -- hence this one).  Dense results and ordered clouds of views spread over the allocation, each
+    launched alone (small-launch kernels) and in a batch of 6 (the large-launch kernels), against the oracle."""
+    from oracle.oracle import Oracle
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, PW, PH, N, fw = 1024, 1024, 1024, 768, 9, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
+    mask = syn.default_mask(W, H)
+    picks = [0, 97, 171, 172, 255, 342, 394]
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=400) as sc:
+        sc.set_calibration(*cal)
+        for v in picks + list(range(394, 400)):
+            sc.set_mask(mask, view=v)
+            sc.synth_view(v, plane=(0.01 * v, 0.04, 0.03), view_id=v, noise=2)
+        got = {}
+        for v in picks:
+            sc.run(v, 1)
+            got[v] = sc.points(v)
+            cl = sc.fused_clouds(v, 1)[0]
+            assert np.array_equal(cl, got[v][0][got[v][1] == 1]), v
+        sc.run(394, 6)
+        batch = [sc.points(v) for v in range(394, 400)]
+        clouds = sc.fused_clouds(394, 6)
+        assert np.array_equal(batch[0][1], got[394][1]) and np.array_equal(batch[0][0], got[394][0], equal_nan=True)
+        for i in range(6):
+            assert np.array_equal(clouds[i], batch[i][0][batch[i][1] == 1]), i
+        frames = {v: (sc.frames(0, v), sc.frames(1, v)) for v in picks + [399]}
+        got[399] = batch[5]
+    for v in picks + [399]:
+        o = Oracle(W, H, PW, PH, N, N, fw, fw)
+        o.set_mask(mask)
+        o.set_calibration(*cal)
+        oxyz, ovalid, _ = o.run_scan_rowmajor(*frames[v])
+        assert int(ovalid.sum()) > 100_000
+        assert np.array_equal(got[v][1], ovalid), v
+        assert_points_close(got[v][0], oxyz, ovalid == 1)
