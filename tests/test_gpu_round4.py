@@ -267,3 +267,54 @@ def test_views_across_4gib_boundaries():
         assert int(ovalid.sum()) > 100_000
         assert np.array_equal(got[v][1], ovalid), v
         assert_points_close(got[v][0], oxyz, ovalid == 1)
+
+
+# ---- small launches of 1..4 views, every pipelined rig class, a window whose last tile is partial, masks with whole waves off ------
+@pytest.mark.parametrize("n_views", [1, 2, 3, 4])
+@pytest.mark.parametrize("rig", ["reference", "radial", "distorted"])
+def test_small_launches_partial_tile_and_masked_waves(n_views, rig):
+    """The small-launch instantiations (at most 4 views per launch: the reference's one scan per call) of the three pipelined rig
+    classes.  1912 x 1083: 2,023 tiles, the last one owns only 183 of its 256 quads (lanes past the last row leave at once; the wave
+    that straddles the end stores 16-byte pieces); masks with per-pixel holes AND whole rows / a block without a valid pixel (the
+    plane requests of every view but a lane's first are masked: waves that skip them).  With 3 views a launch is a group of two
+    views per lane and a group of one.  Dense results and ordered clouds against the oracle, view by view.
+    (Written for a schedule with two tiles per block that was measured and rejected -- profiles/r04_two_tiles_per_block_ab.txt;
+    the case stays.)"""
+    from oracle.oracle import Oracle
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, PW, PH, N, fw = 1912, 1083, 1920, 1080, 10, 2
+    cal_d = syn.synth_rig(W, H, PW, PH)
+    if rig == "radial":
+        cal_d["dp"] = np.array([-0.05, 0.02, 0.0, 0.0, 0.0])
+    if rig == "distorted":
+        cal_d["dp"] = np.array([-0.05, 0.02, 0.001, -0.0005, 0.0])
+        cal_d["dc"] = np.array(cal_d["dc"], dtype=np.float64) + np.array([0.0, 0.0, 0.0008, -0.0006, 0.0])
+    cal = syn.cal_tuple(cal_d)
+    rng = np.random.default_rng(100 + n_views)
+    masks = [_random_mask(rng, W, H, p=0.3 if v % 2 else 0.02) for v in range(n_views)]
+    for v, m in enumerate(masks):          # whole waves without a valid pixel: rows of the first tiles, a block in the middle, the last rows
+        m[: 3 + 5 * v, :] = 0
+        m[300 + 40 * v:520, 250:1500] = 0
+        if v % 2 == 0:
+            m[H - 4:, :] = 0
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=n_views) as sc:
+        sc.set_calibration(*cal)
+        want = {"reference": ", 1, 0, false>", "radial": ", 3, 0, false>", "distorted": ", 2, 0, false>"}[rig]
+        assert sc.fused_kernel_name(n_views).endswith(want), sc.fused_kernel_name(n_views)
+        for v in range(n_views):
+            sc.set_mask(masks[v], view=v)
+            sc.synth_view(v, plane=(1.5 * v, 0.05, 0.04 - 0.01 * v), view_id=v, noise=2)
+        sc.run(0, n_views)
+        got = [sc.points(v) for v in range(n_views)]
+        clouds = sc.fused_clouds(0, n_views)
+        frames = [(sc.frames(0, v), sc.frames(1, v)) for v in range(n_views)]
+    for v in range(n_views):
+        o = Oracle(W, H, PW, PH, N, N, fw, fw)
+        o.set_mask(masks[v])
+        o.set_calibration(*cal)
+        oxyz, ovalid, _ = o.run_scan_rowmajor(*frames[v])
+        assert int(ovalid.sum()) > 100_000
+        assert np.array_equal(got[v][1], ovalid), v
+        assert_points_close(got[v][0], oxyz, ovalid == 1)
+        assert np.isnan(got[v][0][ovalid == 0]).all()
+        assert np.array_equal(clouds[v], got[v][0][ovalid == 1]), v
