@@ -1,0 +1,16 @@
+# on the GPU box (round 4, session r): the camera's radial factor from 2 KB of LDS (cam_tab_kind 3: no per-pixel camera table in the
+# timed kernels of the camera-frame rigs; 128-node tables) against the build before it (base).  Parity first.
+set -u
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+T=gpurun_out/r4r
+mkdir -p $T
+timeout 2400 python -m pytest tests -q -m gpu -x > $T/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $T/summary.txt
+ONEVIEW=1 bash tools/ab.sh alt 3 > $T/ab_oneview_cold.txt 2>&1
+CLOUDS=1 bash tools/ab.sh alt 3 > $T/ab_dense_clouds.txt 2>&1
+bash tools/ab.sh alt 2 --views 2 --steps 6000 --warmup 1000 > $T/ab_views2.txt 2>&1
+bash tools/ab.sh alt 2 --views 4 --steps 4000 --warmup 600 > $T/ab_views4.txt 2>&1
+bash tools/ab.sh alt 2 --width 4096 --height 3000 --fringe-width 4 --views 3 --steps 1200 --warmup 200 > $T/ab_c2.txt 2>&1
+ONEVIEW=1 bash tools/ab.sh alt 2 --rig radial > $T/ab_oneview_radial.txt 2>&1
+bash tools/ab.sh alt 2 --rig radial > $T/ab_rig_radial.txt 2>&1
+cat $T/summary.txt; tail -3 $T/pytest_gpu.log; for f in ab_oneview_cold ab_dense_clouds ab_views2 ab_views4 ab_c2 ab_oneview_radial ab_rig_radial; do echo "== $f"; cat $T/$f.txt; done
