@@ -869,6 +869,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             phase_B<RIG, UNROLL>(P, Cglobal, PR, proj_table, vout, d, my_cam, my_cp, my_xyz, s_rad);
         }
         if (DEFER) {
+            if (view == it.v_begin) SL3D_STAMP(6);
             pvout = vout;
             continue;
         }
@@ -880,7 +881,10 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         store_quad<KEEP>(P, s_xyz, my_xyz, px, vout);
         if (view == it.v_begin) SL3D_STAMP(7);
     }
-    if (DEFER) store_view(it.v_end - 1, pvout);
+    if (DEFER) {
+        store_view(it.v_end - 1, pvout);
+        SL3D_STAMP(7);  // (trace builds: with deferred stores, the LAST view's)
+    }
 }
 
 // ---- launch plumbing -------------------------------------------------------------------------------------------------------------

@@ -131,7 +131,11 @@ void sl3d_destroy(sl3d_ctx *ctx);
 /* ---- inputs ------------------------------------------------------------------------------- */
 /* The 8 calibration files read by read_parameters() 7/triangulation.cpp:149-180 and
  * compute_A() :1061-1126: intrinsics K (3x3 row-major), distortion (k1,k2,p1,p2,k3),
- * Rodrigues rotation vector and translation vector (world -> device) for camera and projector. */
+ * Rodrigues rotation vector and translation vector (world -> device) for camera and projector.
+ * In the timed mode the call also builds, on the device, what the reference tabulates per scan (assign_3d_coordinates,
+ * 7/triangulation.cpp:252-307, :352-378): the camera-side undistortion per window pixel and, for a distorted projector, either a
+ * displacement per projector pixel or -- purely radial model, plain K: both projector calibrations the reference ships -- a 4-KB
+ * table of the radial factor.  It synchronises the context's stream. */
 int sl3d_set_calibration(sl3d_ctx *ctx,
                          const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
                          const double Kp[9], const double dp[5], const double rp[3], const double tp[3]);
