@@ -340,9 +340,19 @@ __device__ __forceinline__ void issue_fringe(const KParams &P, int view, unsigne
     }
 }
 
-// NMAX is the compile-time unroll bound of the Gray planes; EXACT = both axes have exactly NMAX planes (the plane clamps and the
-// per-plane tests fold away); otherwise an axis with fewer planes skips the surplus loads through a wave-uniform test
-template <int NMAX, bool EXACT>
+// NMAX is the compile-time unroll bound of the Gray planes.  PLANES (how an axis with N planes maps onto it):
+//   1  exact: both axes have exactly NMAX planes -- clamps and per-plane tests fold away (the benchmarked kernels)
+//   2  padded: straight-line code for NMAX planes per axis whatever the axes really have (N <= NMAX).  An axis with fewer planes is
+//      padded IN FRONT with NMAX - N virtual planes that decode to G = 0 -- the binary code sum B_i 2^(N-1-i) is unchanged by
+//      leading zero bits -- and that cost nothing but scalar arithmetic: logical plane i reads physical plane max(i - pad, 0) (the
+//      padded ones re-read plane 0: an L2 hit, never used), and the decode xors them in with an all-zero mask (decode_gray).  No
+//      per-plane test, no branch, one instruction stream for every (N_v, N_h) with max(N_v, N_h) <= NMAX.  The reference's own
+//      capture set is N_v = 6, N_h = 5 (global_cv.h:49-62); until round 4 unequal axes took the per-plane tests below, whose code
+//      spills kilobytes: 3.8 x slower at 6 / 5, 40 x at 10 / 9 (tools/nvnh.py, profiles/r04_unequal_axes.txt).  With equal axes it is
+//      1 % behind the exact form (the plane offsets are no longer compile-time multiples), which therefore stays.
+//   0  per-plane tests (parity mode, 4-/5-step fringes, more than 12 planes): an axis with fewer planes skips the surplus loads
+//      through a wave-uniform test
+template <int NMAX, int PLANES>
 __device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned lane_off, int F, int Nv, int Nh, unsigned (&g)[2][NMAX], unsigned (&iv)[2][NMAX])
 {
     const GLOBAL_AS uint8_t *vb = opaque(P.frames + (size_t)view * P.view_stride);
@@ -353,10 +363,20 @@ __device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned 
     for (int a = 0; a < 2; a++) {
         const int N = a == 0 ? Nv : Nh;
         const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
+        // (behind an empty asm: everything derived from it is loop-invariant, and 40 hoisted plane offsets + 20 masks are more
+        // SGPRs than there are)
+        int pad = NMAX - N;
+        if (PLANES == 2) asm volatile("" : "+s"(pad));
 #pragma unroll
         for (int i = 0; i < NMAX; i++) {
+            if (PLANES == 2) {
+                const unsigned idx = (unsigned)max(i - pad, 0);
+                g[a][i] = ldg32(vb + (size_t)(pg + idx * psv), lo);
+                iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + idx) * psv), lo);
+                continue;
+            }
             g[a][i] = iv[a][i] = 0u;
-            if (EXACT || i < N) {
+            if (PLANES == 1 || i < N) {
                 g[a][i] = ldg32(vb + (size_t)(pg + (unsigned)i * psv), lo);
                 iv[a][i] = ldg32(vb + (size_t)(pg + (unsigned)(N + i) * psv), lo);
             }
@@ -370,7 +390,9 @@ __device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned 
 // B_0 = G_0, B_i = B_{i-1} xor G_i (:187-191) is a running xor of the masks; the code sum B_i 2^(N-1-i) (:193) is
 // accumulated per byte, the LAST 8 planes in `lo`, the ones before them in `hi`, so that the 16-bit code of a pixel
 // is (hi byte, lo byte) and one v_perm per pixel pair builds it: code[a][j] = codes of pixels 2j (low half), 2j+1.
-template <int NMAX>
+// PLANES == 2 (padded, see issue_gray): NMAX positions; the NMAX - N padded planes in front are xored in with a zero mask (a scalar
+// select feeds the third operand of the v_bitop3 that the plain decode feeds with the constant).
+template <int NMAX, int PLANES>
 __device__ __forceinline__ void decode_gray(const unsigned (&g)[2][NMAX], const unsigned (&iv)[2][NMAX], int Nv, int Nh, unsigned (&code)[2][2])
 {
 #pragma unroll
@@ -379,6 +401,23 @@ __device__ __forceinline__ void decode_gray(const unsigned (&g)[2][NMAX], const 
         const unsigned H = 0x80808080u;
         unsigned bacc = 0;  // running binary bit of pixel k at bit 8k+7
         unsigned hi = 0, lo = 0;
+        if (PLANES == 2) {
+            int pad = NMAX - N;
+            asm volatile("" : "+s"(pad));
+#pragma unroll
+            for (int i = 0; i < NMAX; i++) {
+                const unsigned x = g[a][i], y = iv[a][i];
+                const unsigned t = (x | H) - (y & ~H);
+                const unsigned ge = __builtin_amdgcn_bitop3_b32(x, y, t, 0xB2);
+                const unsigned Hm = i >= pad ? H : 0u;  // (wave-uniform: an SGPR operand)
+                bacc = __builtin_amdgcn_bitop3_b32(bacc, ge, Hm, 0x78);
+                if (i < NMAX - 8) hi = (hi << 1) | (bacc >> 7);
+                else lo = (lo << 1) | (bacc >> 7);
+            }
+            code[a][0] = __builtin_amdgcn_perm(hi, lo, 0x05010400u);
+            code[a][1] = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NMAX; i++) {
             if (i < N) {
@@ -770,6 +809,8 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
 #endif
 
     // EXACT: both axes have exactly NMAX Gray planes (the usual case)
+    // how the axes map onto the NMAX unrolled planes (issue_gray): exact; padded (the timed 3-step kernels up to 12 planes); tests
+    constexpr int PLANES = EXACT ? 1 : (!KEEP && !FGEN && NMAX <= 12) ? 2 : 0;
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
     const bool proj_table = RIG == 2 || (RIG == 0 && !KEEP && P.proj_disp != nullptr);
 
@@ -782,7 +823,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     if (!item_begin<RIG, SEG, EARLY, BLK>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
     if (EARLY) {  // planes of the first view right behind the set-up requests; then the set-up results are consumed
         issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
-        issue_gray<NMAX, EXACT>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
+        issue_gray<NMAX, PLANES>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
         if (P.use_cam_table) cam_table_finish<RIG>(P, Cglobal, it, camt, my_cam);
     }
     SL3D_STAMP(2);
@@ -796,7 +837,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         if (it.v_begin + 1 < it.v_end) mq = load_mask_quad(P, it.v_begin + 1, it.lane_off);
         if (!EARLY && vb_next != 0) {  // (EARLY: they are in flight already)
             issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
-            issue_gray<NMAX, EXACT>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
+            issue_gray<NMAX, PLANES>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
         }
     }
     const PinnedRows PR = pinned_rows<RIG>(Cglobal);  // (stage 7 needs them; by now the item's first memory requests are on their way)
@@ -827,7 +868,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         if (!DEFER && !SEG && (KEEP || vbits == 0)) fill_nan(my_xyz);
         if (!PIPE && vbits != 0) {  // every load of the view is issued before the first one is consumed
             issue_fringe<FGEN>(P, view, it.lane_off, F, Nv, f);
-            issue_gray<NMAX, EXACT>(P, view, it.lane_off, F, Nv, Nh, g, iv);
+            issue_gray<NMAX, PLANES>(P, view, it.lane_off, F, Nv, Nh, g, iv);
         }
         if (view == it.v_begin) SL3D_STAMP(3);
         float w[2][4];
@@ -835,7 +876,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             wrapped_quad<RCPT>(F, f, s_rcp, w);          // waits for the 6 fringe planes
             __builtin_amdgcn_sched_barrier(0);           // (the decode below is not to be scheduled up in front of this arithmetic)
         }
-        if (vbits != 0) decode_gray<NMAX>(g, iv, Nv, Nh, code);  // waits for the planes of this view
+        if (vbits != 0) decode_gray<NMAX, PLANES>(g, iv, Nv, Nh, code);  // waits for the planes of this view
         if (view == it.v_begin) SL3D_STAMP(4);
         if (DEFER) {
             if (view > it.v_begin) store_view(view - 1, pvout);
@@ -860,7 +901,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             mq = load_mask_quad(P, min(view + 2, it.v_end - 1), it.lane_off);
             if (vb_next != 0) {
                 issue_fringe<FGEN>(P, view + 1, it.lane_off, F, Nv, f);
-                issue_gray<NMAX, EXACT>(P, view + 1, it.lane_off, F, Nv, Nh, g, iv);
+                issue_gray<NMAX, PLANES>(P, view + 1, it.lane_off, F, Nv, Nh, g, iv);
             }
         }
         if (!KEEP && vbits != 0) {
@@ -888,21 +929,24 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
 }
 
 // ---- launch plumbing -------------------------------------------------------------------------------------------------------------
-// Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT: plane tests fold away) and for
-// the unroll bounds 8 / 12 / 16 otherwise; the parity mode and the 4-/5-step fringes use the bounds only.  Dense 3-step launches
+// Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT), as padded straight-line code for
+// every NMAX = 6..12 (any other pair of axes up to NMAX planes -- issue_gray) and with the unroll bound 16 beyond; the parity mode
+// and the 4-/5-step fringes use the bounds 8 / 12 / 16 with per-plane tests.  Dense 3-step launches
 // of at most SL3D_SMALL_LAUNCH_VIEWS views take the instantiation without the LDS reciprocal table (re-measured with the streaming
 // stores: 8 views 185.6-187.5 us through it against 183.8-184.7, 16 views +-0: stays at 4).
 #define SL3D_SMALL_LAUNCH_VIEWS 4
 struct FusedChoice {
     int nmax;
-    bool exact, small;
+    bool exact, small;  // exact: both axes have exactly nmax planes.  (!exact, timed 3-step, nmax <= 12: the padded form, issue_gray)
 };
 inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh, int n_views)
 {
     FusedChoice c;
     const int m = nv > nh ? nv : nh;
     c.exact = !keep && !fgen && nv == nh && nv >= 6 && nv <= 12;
-    c.nmax = c.exact ? nv : (m <= 8 ? 8 : (m <= 12 ? 12 : SL3D_MAX_GRAY));
+    if (c.exact) c.nmax = nv;
+    else if (!keep && !fgen && m <= 12) c.nmax = m < 6 ? 6 : m;  // padded
+    else c.nmax = m <= 8 ? 8 : (m <= 12 ? 12 : SL3D_MAX_GRAY);
     c.small = !keep && !fgen && n_views <= SL3D_SMALL_LAUNCH_VIEWS;
     return c;
 }
@@ -938,10 +982,21 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
             }
             return;
         }
+        switch (c.nmax) {  // padded (unequal axes, or fewer than 6 planes); more than 12 planes: the per-plane tests
+        case 6: SL3D_LAUNCH(6, false); break;
+        case 7: SL3D_LAUNCH(7, false); break;
+        case 8: SL3D_LAUNCH(8, false); break;
+        case 9: SL3D_LAUNCH(9, false); break;
+        case 10: SL3D_LAUNCH(10, false); break;
+        case 11: SL3D_LAUNCH(11, false); break;
+        case 12: SL3D_LAUNCH(12, false); break;
+        default: SL3D_LAUNCH(SL3D_MAX_GRAY, false); break;
+        }
+    } else {
+        if (c.nmax == 8) SL3D_LAUNCH(8, false);
+        else if (c.nmax == 12) SL3D_LAUNCH(12, false);
+        else SL3D_LAUNCH(SL3D_MAX_GRAY, false);
     }
-    if (c.nmax == 8) SL3D_LAUNCH(8, false);
-    else if (c.nmax == 12) SL3D_LAUNCH(12, false);
-    else SL3D_LAUNCH(SL3D_MAX_GRAY, false);
 #undef SL3D_LAUNCH
 }
 

@@ -1,4 +1,4 @@
-// the 3-step timed dense kernels of rig class 0 (sl3d_fused.h): N = 6..12 exact + the unroll bounds 8 / 12 / 16, each with and
+// the 3-step timed dense kernels of rig class 0 (sl3d_fused.h): N = 6..12 exact, NMAX = 6..12 padded (unequal axes) + the unroll bound 16, each with and
 // without the LDS reciprocal table
 #include "sl3d_fused.h"
 namespace sl3d {

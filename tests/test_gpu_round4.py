@@ -318,3 +318,52 @@ def test_small_launches_partial_tile_and_masked_waves(n_views, rig):
         assert_points_close(got[v][0], oxyz, ovalid == 1)
         assert np.isnan(got[v][0][ovalid == 0]).all()
         assert np.array_equal(clouds[v], got[v][0][ovalid == 1]), v
+
+
+# ---- unequal Gray depths on the two axes: the straight-line kernels with the shorter axis padded in front --------------------------
+@pytest.mark.parametrize("Nv,Nh,fwv,fwh,PW,PH", [(6, 5, 32, 32, 1280, 720), (12, 3, 1, 64, 600, 400), (7, 11, 4, 1, 500, 333), (10, 4, 2, 32, 1024, 500),
+                                                (5, 5, 16, 16, 500, 400), (2, 12, 64, 1, 200, 1000), (9, 10, 2, 2, 1000, 1000), (1, 1, 64, 64, 100, 100)])
+def test_padded_gray_axes_take_the_straight_line_kernels(Nv, Nh, fwv, fwh, PW, PH):
+    """Any pair of axes with max(N_v, N_h) <= 12 that is not an exact instantiation (N_v = N_h in 6..12) takes the PADDED straight-line
+    instantiation for NMAX = max(6, N_v, N_h): the shorter axis is padded IN FRONT with virtual planes that decode to G = 0
+    (issue_gray / decode_gray in sl3d_fused.h) -- the reference's own capture set is 6 / 5.  Random frame bytes (every code value, ties, out-of-range correspondences), 6 views in one launch (the
+    large-launch kernels), each view alone (the small-launch kernels), ordered clouds: valid maps and point counts bit exact against
+    the oracle, points within 1e-5, and one launch equal to the other bit for bit."""
+    from oracle.oracle import Oracle
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, V = 168, 60, 6
+    cal_d = syn.synth_rig(W, H, PW, PH)
+    cal = syn.cal_tuple(cal_d)
+    rng = np.random.default_rng(1000 * Nv + Nh)
+    planes = [([rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(3 + 2 * Nv)],
+               [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(3 + 2 * Nh)]) for _ in range(V)]
+    masks = [(rng.random((H, W)) < 0.85).astype(np.uint8) for _ in range(V)]
+    with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, max_views=V) as sc:
+        sc.set_calibration(*cal)
+        nmax = max(6, Nv, Nh)
+        exact = "true" if Nv == Nh and Nv >= 6 else "false"   # (equal axes of 6..12 planes keep the exact form; "false" with nmax <= 12 = padded)
+        for n in (V, 1):
+            assert sc.fused_kernel_name(n).startswith(f"sl3d::k_fused<false, {nmax}, false, {exact}, "), sc.fused_kernel_name(n)
+        for v in range(V):
+            sc.set_mask(masks[v], view=v)
+            sc.set_frames(0, planes[v][0], view=v)
+            sc.set_frames(1, planes[v][1], view=v)
+        sc.run(0, V)
+        batch = [sc.points(v) for v in range(V)]
+        clouds = sc.fused_clouds(0, V)
+        for v in range(V):
+            sc.run(v, 1)
+            one = sc.points(v)
+            assert np.array_equal(one[1], batch[v][1]) and np.array_equal(one[0], batch[v][0], equal_nan=True), v
+            assert np.array_equal(sc.fused_clouds(v, 1)[0], clouds[v]), v
+    n_valid = 0
+    for v in range(V):
+        o = Oracle(W, H, PW, PH, Nv, Nh, fwv, fwh)
+        o.set_mask(masks[v])
+        o.set_calibration(*cal)
+        oxyz, ovalid, _ = o.run_scan_rowmajor(*planes[v])
+        assert np.array_equal(batch[v][1], ovalid), v
+        assert_points_close(batch[v][0], oxyz, ovalid == 1)
+        assert np.array_equal(clouds[v], batch[v][0][ovalid == 1]), v
+        n_valid += int(ovalid.sum())
+    assert n_valid > 0 or min(Nv, Nh) <= 2
