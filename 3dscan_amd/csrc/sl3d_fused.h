@@ -350,8 +350,8 @@ __device__ __forceinline__ void issue_fringe(const KParams &P, int view, unsigne
 //      capture set is N_v = 6, N_h = 5 (global_cv.h:49-62); until round 4 unequal axes took the per-plane tests below, whose code
 //      spills kilobytes: 3.8 x slower at 6 / 5, 40 x at 10 / 9 (tools/nvnh.py, profiles/r04_unequal_axes.txt).  With equal axes it is
 //      1 % behind the exact form (the plane offsets are no longer compile-time multiples), which therefore stays.
-//   0  per-plane tests (parity mode, 4-/5-step fringes, more than 12 planes): an axis with fewer planes skips the surplus loads
-//      through a wave-uniform test
+//   0  per-plane tests (parity mode, more than 12 planes): an axis with fewer planes skips the surplus loads through a wave-uniform
+//      test
 template <int NMAX, int PLANES>
 __device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned lane_off, int F, int Nv, int Nh, unsigned (&g)[2][NMAX], unsigned (&iv)[2][NMAX])
 {
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
 
     // EXACT: both axes have exactly NMAX Gray planes (the usual case)
     // how the axes map onto the NMAX unrolled planes (issue_gray): exact; padded (the timed 3-step kernels up to 12 planes); tests
-    constexpr int PLANES = EXACT ? 1 : (!KEEP && !FGEN && NMAX <= 12) ? 2 : 0;
+    constexpr int PLANES = EXACT ? 1 : (!KEEP && NMAX <= 12) ? 2 : 0;
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
     const bool proj_table = RIG == 2 || (RIG == 0 && !KEEP && P.proj_disp != nullptr);
 
@@ -930,14 +930,14 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
 
 // ---- launch plumbing -------------------------------------------------------------------------------------------------------------
 // Instantiations: the timed 3-step kernel exists for every N = 6..12 with both axes equal (EXACT), as padded straight-line code for
-// every NMAX = 6..12 (any other pair of axes up to NMAX planes -- issue_gray) and with the unroll bound 16 beyond; the parity mode
-// and the 4-/5-step fringes use the bounds 8 / 12 / 16 with per-plane tests.  Dense 3-step launches
+// every NMAX = 6..12 (any other pair of axes up to NMAX planes -- issue_gray; the 4-/5-step fringes have this form only) and with
+// the unroll bound 16 beyond; the parity mode uses the bounds 8 / 12 / 16 with per-plane tests.  Dense 3-step launches
 // of at most SL3D_SMALL_LAUNCH_VIEWS views take the instantiation without the LDS reciprocal table (re-measured with the streaming
 // stores: 8 views 185.6-187.5 us through it against 183.8-184.7, 16 views +-0: stays at 4).
 #define SL3D_SMALL_LAUNCH_VIEWS 4
 struct FusedChoice {
     int nmax;
-    bool exact, small;  // exact: both axes have exactly nmax planes.  (!exact, timed 3-step, nmax <= 12: the padded form, issue_gray)
+    bool exact, small;  // exact: both axes have exactly nmax planes.  (!exact, timed kernels, nmax <= 12: the padded form, issue_gray)
 };
 inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh, int n_views)
 {
@@ -945,7 +945,7 @@ inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh,
     const int m = nv > nh ? nv : nh;
     c.exact = !keep && !fgen && nv == nh && nv >= 6 && nv <= 12;
     if (c.exact) c.nmax = nv;
-    else if (!keep && !fgen && m <= 12) c.nmax = m < 6 ? 6 : m;  // padded
+    else if (!keep && m <= 12) c.nmax = m < 6 ? 6 : m;  // padded (4-/5-step fringes: always)
     else c.nmax = m <= 8 ? 8 : (m <= 12 ? 12 : SL3D_MAX_GRAY);
     c.small = !keep && !fgen && n_views <= SL3D_SMALL_LAUNCH_VIEWS;
     return c;
@@ -969,18 +969,20 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
         }                                                                                                                                  \
         hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE>), grid, block, 0, st, P, C, first_view, n_views, vpt);                  \
     } while (0)
-    if constexpr (!KEEP && !FGEN) {
-        if (c.exact) {
-            switch (c.nmax) {
-            case 6: SL3D_LAUNCH(6, true); break;
-            case 7: SL3D_LAUNCH(7, true); break;
-            case 8: SL3D_LAUNCH(8, true); break;
-            case 9: SL3D_LAUNCH(9, true); break;
-            case 10: SL3D_LAUNCH(10, true); break;
-            case 11: SL3D_LAUNCH(11, true); break;
-            default: SL3D_LAUNCH(12, true); break;
+    if constexpr (!KEEP) {
+        if constexpr (!FGEN) {
+            if (c.exact) {
+                switch (c.nmax) {
+                case 6: SL3D_LAUNCH(6, true); break;
+                case 7: SL3D_LAUNCH(7, true); break;
+                case 8: SL3D_LAUNCH(8, true); break;
+                case 9: SL3D_LAUNCH(9, true); break;
+                case 10: SL3D_LAUNCH(10, true); break;
+                case 11: SL3D_LAUNCH(11, true); break;
+                default: SL3D_LAUNCH(12, true); break;
+                }
+                return;
             }
-            return;
         }
         switch (c.nmax) {  // padded (unequal axes, or fewer than 6 planes); more than 12 planes: the per-plane tests
         case 6: SL3D_LAUNCH(6, false); break;
