@@ -992,7 +992,11 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
         case 10: SL3D_LAUNCH(10, false); break;
         case 11: SL3D_LAUNCH(11, false); break;
         case 12: SL3D_LAUNCH(12, false); break;
-        default: SL3D_LAUNCH(SL3D_MAX_GRAY, false); break;
+        default:
+            // 13..16 planes: per-plane tests, un-pipelined general kernel only (launch_fused routes every rig class there: the
+            // pipelined kernels with per-plane tests spill 3.5 KB per lane -- 21 ms per 16-view launch, tools/corners.py)
+            if constexpr (RIG == 0) SL3D_LAUNCH(SL3D_MAX_GRAY, false);
+            break;
         }
     } else {
         if (c.nmax == 8) SL3D_LAUNCH(8, false);

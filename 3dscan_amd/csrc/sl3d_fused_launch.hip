@@ -32,7 +32,13 @@ static int views_per_lane(unsigned bx, int n_views, int cam_table_kind)
     return vpt;
 }
 
-static int timed_rig(const KParams &P, int rig) { return rig == 1 ? 1 : (rig == 2 && P.proj_disp) ? 2 : (rig == 3 && P.proj_rad && P.F == 3) ? 3 : 0; }
+// (more than 12 Gray planes on an axis: the general kernel whatever the calibration is -- it evaluates any rig, and it is the only
+// one whose per-plane-test form does not spill)
+static int timed_rig(const KParams &P, int rig)
+{
+    if (P.Nv > 12 || P.Nh > 12) return 0;
+    return rig == 1 ? 1 : (rig == 2 && P.proj_disp) ? 2 : (rig == 3 && P.proj_rad && P.F == 3) ? 3 : 0;
+}
 
 // rig: 0 / 1 / 2 / 3 (sl3d_fused.h; the host knows the calibration, the timed kernels fold it at compile time).
 // cmode: 0 = dense xyz + valid planes, 2 = segmented clouds (KParams::clouds / seg_counts must be set).
