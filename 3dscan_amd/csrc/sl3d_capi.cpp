@@ -91,6 +91,8 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
         return fail(nullptr, SL3D_E_INVALID_ARG, "window does not fit the frame");
     if (c.proj_width < 1 || c.proj_height < 1 || c.fringe_width_v < 1 || c.fringe_width_h < 1)
         return fail(nullptr, SL3D_E_INVALID_ARG, "projector size / fringe width must be positive");
+    if ((long long)c.proj_width * c.proj_height >= (1ll << 29))  // (the projector table of rig class 2 is addressed with 32-bit byte offsets)
+        return fail(nullptr, SL3D_E_UNSUPPORTED, "projector too large: fewer than 2^29 pixels");
     if (c.n_fringe < 3 || c.n_fringe > 5) return fail(nullptr, SL3D_E_UNSUPPORTED, "n_fringe must be 3, 4 or 5");
     if (c.n_gray_v < 0 || c.n_gray_v > SL3D_MAX_GRAY || c.n_gray_h < 0 || c.n_gray_h > SL3D_MAX_GRAY)
         return fail(nullptr, SL3D_E_UNSUPPORTED, "n_gray out of range");

@@ -486,6 +486,15 @@ __device__ __forceinline__ GLOBAL_AS uint8_t *opaque_out(T *p)
     return (GLOBAL_AS uint8_t *)u;
 }
 
+// a float2 at (wave-uniform base) + (32-bit byte offset), cached (the projector table of rig class 2: neighbouring lanes share lines)
+__device__ __forceinline__ float2 ldg_f2(const GLOBAL_AS uint8_t *base, unsigned off)
+{
+    asm volatile("" : "+s"(base));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = *(const GLOBAL_AS f32x2 *)(base + (size_t)off);
+    return make_float2(v.x, v.y);
+}
+
 // the valid-map dword of the lane's quad (lane_off = byte offset of the quad inside any plane of a view)
 __device__ __forceinline__ MaskQuad load_mask_quad(const KParams &P, int view, unsigned lane_off)
 {

@@ -534,8 +534,11 @@ __device__ __forceinline__ void gather_B(const KParams &P, bool proj_table, cons
 #pragma unroll
     for (int k = 0; k < 4; k++) d[k] = make_float2(0.f, 0.f);
     if (proj_table) {
+        // (SGPR base + 32-bit byte offset: a projector has fewer than 2^29 pixels -- sl3d_create checks it)
+        const GLOBAL_AS uint8_t *tab = opaque((const uint8_t *)P.proj_disp);
+        const unsigned pw = (unsigned)P.PW;
 #pragma unroll
-        for (int k = 0; k < 4; k++) d[k] = P.proj_disp[(size_t)my_cp[3 * k + 1] * (size_t)P.PW + (size_t)my_cp[3 * k]];
+        for (int k = 0; k < 4; k++) d[k] = ldg_f2(tab, ((unsigned)my_cp[3 * k + 1] * pw + (unsigned)my_cp[3 * k]) * 8u);
     }
 }
 
