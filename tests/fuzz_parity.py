@@ -42,11 +42,15 @@ def main():
         if rng.random() < 0.3:
             full_mask[:] = rng.integers(0, 3, size=full_mask.shape)  # values other than 0/1 count as unselected
         cal = {k: np.array(v, dtype=np.float64).copy() for k, v in cap["cal"].items()}
-        rig = int(rng.integers(0, 3))
+        rig = int(rng.integers(0, 5))
         if rig >= 1:
             cal["dp"] = np.array([0.05, -0.02, 0.001, -0.0005, 0.01]) * rng.uniform(0, 1)
         if rig == 2:
-            cal["Kc"][1] = rng.uniform(-0.5, 0.5)  # skew: the general path
+            cal["Kc"][1] = rng.uniform(-0.5, 0.5)  # skew (camera-frame solve with a skew term)
+        if rig == 3:
+            cal["dp"][2] = cal["dp"][3] = 0.0      # purely radial projector model: the LDS radial table (rig class 3)
+        if rig == 4:
+            cal["Kc"][3] = rng.uniform(-1e-3, 1e-3)  # K[1][0] != 0: the general, un-pipelined kernel (rig class 0)
         ct = syn.cal_tuple(cal)
         o = Oracle(W, H, PW, PH, Nv, Nh, fwv, fwh, F=F, col0=col0, row0=row0)
         # the oracle sees the window as its own image: give it the window of the mask, compare away from the window's edge
