@@ -77,10 +77,11 @@ typedef struct sl3d_config {
     int32_t width, height;            /* window processed by this context (pixels)                 */
     int32_t full_width, full_height;  /* Camera_imagewidth/height of the frame; 0 = same as window */
     int32_t col0, row0;               /* window origin inside the frame                            */
-    int32_t proj_width, proj_height;  /* Projector_imagewidth / Projector_imageheight              */
+    int32_t proj_width, proj_height;  /* Projector_imagewidth / Projector_imageheight (fewer than 2^29 pixels) */
     int32_t n_fringe;                 /* number_of_patterns_fringe: 3 (or 4; 5 yields no valid pixel,
                                          exactly as 3/wrapped_phase.cpp:106-129 does)              */
-    int32_t n_gray_v, n_gray_h;       /* number_of_patterns_binary_{vertical,horizontal}           */
+    int32_t n_gray_v, n_gray_h;       /* number_of_patterns_binary_{vertical,horizontal}: 0..16; they need
+                                         not be equal (the reference's own capture set is 6 / 5)   */
     int32_t fringe_width_v, fringe_width_h; /* fringe_width_pixels_{vertical,horizontal}           */
     int32_t n_codes_v, n_codes_h;     /* number_of_codes_* (stage-4 debug image only); 0 = ceil(P/fw) */
     int32_t max_views;                /* batch capacity: views resident in HBM at once (>= 1)      */
