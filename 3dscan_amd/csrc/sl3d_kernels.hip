@@ -580,80 +580,80 @@ int launch_compact_views(const KParams &P, int first_view, int n_views, unsigned
 // its segments' first `count` points.  One wave per segment, one point (12 bytes) per lane and step.
 // ------------------------------------------------------------------------------------------------
 // Exclusive scan of one view's segment counts (1024-thread blocks), behind every segmented launch: it is on the critical path of
-// sl3d_run_clouds, so it is written for latency.  The counts are taken through LDS in chunks of SL3D_SCAN_RUN x 1024: coalesced
-// loads into a padded LDS array (rows of RUN + 1 words: the per-thread runs below are conflict-free), every thread scans its RUN
-// consecutive entries, the 1024 run totals are scanned by wave shuffles + 16 wave totals, and the offsets leave coalesced again;
-// a running carry links the chunks (any frame size).  The view's total goes straight into the mapped host word
-// sl3d_get_cloud_counts reads.  (k_compact_scan -- 32 strided dwords per thread straight from global memory -- took 14.3 us for
-// 16 x 32,400 counts; this scan with ONE block per view and runs of 32: 10.2 us.)
-// Since the end of round 3 a view's segments are scanned by SL3D_SCAN_PARTS blocks instead of one (16 blocks on a 256-CU machine were
-// a latency chain of ~10 us behind every sl3d_run_clouds): block (view, part) first SUMS the counts of the parts in front of it --
-// the same coalesced reads every one of them does anyway, at most n dwords from the L2 -- and then scans its own part from that
-// carry; no block waits for another.  The last part's block leaves the view's total.
+// sl3d_run_clouds, so it is written for latency.  A view's segments are scanned by SL3D_SCAN_PARTS blocks (one block per view was a
+// latency chain of ~10 us on a 256-CU machine): block (view, part) SUMS the counts of the parts in front of it -- the same
+// coalesced reads every one of them does anyway, at most n dwords from the L2 -- and scans its own part from that carry; no block
+// waits for another.  The last part's block leaves the view's total in the mapped host word sl3d_get_cloud_counts reads.
+// ONE memory round trip per block (round 4): it requests its own counts -- 4 consecutive ones per thread, one 16-byte load, a wave
+// reads 1 KB contiguous -- AND the counts in front of its part in the same breath, sums the latter, scans the former in registers
+// (the 4 entries, 6 wave shuffles, the 16 wave totals through LDS: one block barrier per chunk) and writes 4 offsets per thread
+// (32 contiguous bytes); the next chunk of a long part travels while the current one is scanned.  (Until then: the carry first,
+// then the chunk through a padded LDS array with five barriers -- 6.1 us for the 8,100 counts of one 1080p view;
+// profiles/r04_seg_scan_ab.txt.  Rounds 2-3: k_compact_scan, 32 strided dwords per thread, 14.3 us for 16 x 32,400 counts; one
+// block per view with runs of 32: 10.2 us.)
 #define SL3D_SCAN_RUN 4
 #define SL3D_SCAN_PARTS 8
 __global__ __launch_bounds__(1024) void k_seg_scan(const unsigned *__restrict__ counts, unsigned long long *__restrict__ offsets, int n,
                                                    unsigned long long *total)
 {
     const int view = (int)blockIdx.y, part = (int)blockIdx.x;
-    counts += (size_t)view * n;
+    counts += (size_t)view * n;   // (n = 4 * tiles: every row of counts is 16-byte aligned, every row of offsets 32-byte aligned)
     offsets += (size_t)view * n;
     constexpr int CHUNK = 1024 * SL3D_SCAN_RUN;
     // parts are whole chunks, so that every chunk of a part is scanned by the same code path
     const int part_len = (((n + SL3D_SCAN_PARTS - 1) / SL3D_SCAN_PARTS + CHUNK - 1) / CHUNK) * CHUNK;
     const int begin = min(part * part_len, n), end = min(begin + part_len, n);
-    __shared__ unsigned s_val[1024 * (SL3D_SCAN_RUN + 1)];
-    __shared__ unsigned s_wave[16];
-    __shared__ unsigned long long s_carry;
+    __shared__ unsigned long long s_part[16];
+    __shared__ unsigned s_wave[2][16];
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
-    {   // the carry into this part: the sum of everything in front of it
+    const uint4 zero = {0u, 0u, 0u, 0u};
+    auto mine = [&](int base) { return base + SL3D_SCAN_RUN * t < end ? *(const uint4 *)(counts + base + SL3D_SCAN_RUN * t) : zero; };
+    uint4 c = mine(begin);
+    unsigned long long carry;
+    {   // the carry into this part: the sum of everything in front of it (requested together with the part's first chunk)
         unsigned long long acc = 0ull;
-        for (int i = t; i < begin; i += 1024) acc += counts[i];
+        for (int i = SL3D_SCAN_RUN * t; i < begin; i += CHUNK) {
+            const uint4 f = *(const uint4 *)(counts + i);
+            acc += (unsigned long long)f.x + f.y + f.z + f.w;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        __shared__ unsigned long long s_part[16];
         if (lane == 0) s_part[wave] = acc;
         __syncthreads();
-        if (t == 0) {
-            unsigned long long c = 0ull;
-            for (int w = 0; w < 16; w++) c += s_part[w];
-            s_carry = c;
-        }
-    }
-    for (int base = begin; base < end; base += CHUNK) {
-        const int m = min(end - base, CHUNK);
-        __syncthreads();  // the previous chunk's LDS values have been written out; s_carry is up to date
-        for (int i = t; i < CHUNK; i += 1024) s_val[i + i / SL3D_SCAN_RUN] = i < m ? counts[base + i] : 0u;
-        __syncthreads();
-        unsigned *mine = s_val + t * (SL3D_SCAN_RUN + 1);
-        unsigned run = 0;
+        carry = 0ull;
 #pragma unroll
-        for (int j = 0; j < SL3D_SCAN_RUN; j++) {  // in place: each entry becomes the exclusive prefix inside the thread's run
-            const unsigned c = mine[j];
-            mine[j] = run;
-            run += c;
-        }
+        for (int w = 0; w < 16; w++) carry += s_part[w];
+    }
+    int buf = 0;
+    for (int base = begin;; base += CHUNK, buf ^= 1) {
+        const uint4 next = base + CHUNK < end ? mine(base + CHUNK) : zero;  // (the next chunk travels while this one is scanned)
+        const unsigned e1 = c.x, e2 = e1 + c.y, e3 = e2 + c.z, run = e3 + c.w;
         unsigned incl = run;  // inclusive scan of the run totals over the wave, then over the 16 waves
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned v = __shfl_up(incl, off, 64);
             if (lane >= off) incl += v;
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        unsigned wbase = 0;
-        for (int w = 0; w < wave; w++) wbase += s_wave[w];
-        const unsigned long long carry = s_carry;
-        mine[SL3D_SCAN_RUN] = wbase + (incl - run);  // the run's exclusive prefix inside the chunk, parked in the row's padding word
-        __syncthreads();
-        for (int i = t; i < m; i += 1024) {
-            const int r = i / SL3D_SCAN_RUN;
-            offsets[base + i] = carry + (unsigned long long)(s_val[r * (SL3D_SCAN_RUN + 1) + SL3D_SCAN_RUN] + s_val[i + r]);
+        if (lane == 63) s_wave[buf][wave] = incl;
+        __syncthreads();  // (two buffers: the next chunk's totals do not overwrite what a slower wave still reads)
+        unsigned wbase = 0, chunk_total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const unsigned v = s_wave[buf][w];
+            wbase += w < wave ? v : 0u;
+            chunk_total += v;
         }
-        if (t == 1023) s_carry = carry + (unsigned long long)(wbase + incl);
+        if (base + SL3D_SCAN_RUN * t < end) {
+            const unsigned long long o = carry + (unsigned long long)(wbase + (incl - run));
+            ulonglong2 *dst = (ulonglong2 *)(offsets + base + SL3D_SCAN_RUN * t);
+            dst[0] = make_ulonglong2(o, o + e1);
+            dst[1] = make_ulonglong2(o + e2, o + e3);
+        }
+        carry += (unsigned long long)chunk_total;
+        if (base + CHUNK >= end) break;
+        c = next;
     }
-    __syncthreads();
-    if (t == 0 && part == SL3D_SCAN_PARTS - 1) total[view] = s_carry;
+    if (t == 0 && part == SL3D_SCAN_PARTS - 1) total[view] = carry;
 }
 
 int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream)
