@@ -15,8 +15,9 @@ int fused_tiles(const KParams &P)
 }
 
 // views per lane: as many as possible up to SL3D_VPT_MAX (amortises the set-up of a block and the camera table entries) while
-// the grid still has >= ~8 blocks per CU to balance the tail.  (Rounds 1-2: 8.  With the stores streaming past the L2 the
-// optimum moved: 16 views per launch 354.5 us at 4 against 359.6 at 8 and 359.3 at 2, 372.7 at 16; 32 views 700 against 708,
+// the grid still has >= ~16 blocks per CU to balance the tail (8 until the end of round 4: with the repaired pipeline 3 / 4 views of
+// 1080p run 1 % / 0.4 % faster at one view per lane than at two, 8 views the same at two as at four -- profiles/r04_vpt_final.txt).
+// (Rounds 1-2: at most 8 views per lane.  With the stores streaming past the L2 the optimum moved: 16 views per launch 354.5 us at 4 against 359.6 at 8 and 359.3 at 2, 372.7 at 16; 32 views 700 against 708,
 // profiles/r03_vpt_sweep4.txt; configs[2], 3 views of 12 Mpx: 1 / 2 / 3 views per lane 0.670 / 0.681 / 0.685,
 // profiles/c2_r04_views_vpt_sweep.txt.)
 #define SL3D_VPT_MAX 4
@@ -25,7 +26,7 @@ static int views_per_lane(unsigned bx, int n_views, int cam_table_kind)
     int vpt = 1;
     // (a two-double camera table -- tangential terms -- costs a block 16 B/px: those rigs keep 8 views per lane, measured -0.6 % at 4)
     const int cap = cam_table_kind == 2 ? 8 : SL3D_VPT_MAX;
-    while (vpt < cap && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 2048) vpt *= 2;
+    while (vpt < cap && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 4096) vpt *= 2;
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_VPT") && atoi(getenv("SL3D_VPT")) >= 1) vpt = atoi(getenv("SL3D_VPT"));
 #endif

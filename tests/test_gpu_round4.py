@@ -276,8 +276,7 @@ def test_small_launches_partial_tile_and_masked_waves(n_views, rig):
     """The small-launch instantiations (at most 4 views per launch: the reference's one scan per call) of the three pipelined rig
     classes.  1912 x 1083: 2,023 tiles, the last one owns only 183 of its 256 quads (lanes past the last row leave at once; the wave
     that straddles the end stores 16-byte pieces); masks with per-pixel holes AND whole rows / a block without a valid pixel (the
-    plane requests of every view but a lane's first are masked: waves that skip them).  With 3 views a launch is a group of two
-    views per lane and a group of one.  Dense results and ordered clouds against the oracle, view by view.
+    plane requests of every view but a lane's first are masked: waves that skip them).  Dense results and ordered clouds against the oracle, view by view.
     (Written for a schedule with two tiles per block that was measured and rejected -- profiles/r04_two_tiles_per_block_ab.txt;
     the case stays.)"""
     from oracle.oracle import Oracle
