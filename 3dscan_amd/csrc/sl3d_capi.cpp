@@ -174,6 +174,11 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     }
     ALLOC(x->d_band, V * P.px_view_stride);
     ALLOC(x->d_mask_raw, P.mask_view_stride);
+    ALLOC(x->d_valid_quads, V);
+    CREATE_CHK(hipMemsetAsync(x->d_valid_quads, 0, V * sizeof(unsigned), x->stream));
+    CREATE_CHK(hipHostMalloc((void **)&x->h_valid_quads, V * sizeof(unsigned), hipHostMallocDefault));
+    for (size_t v = 0; v < V; v++) x->h_valid_quads[v] = 0xffffffffu;
+    P.valid_quads = x->d_valid_quads;
     CREATE_CHK(hipMemsetAsync(x->d_mask, 0, V * P.mask_view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_frames, 0, V * P.view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_valid, 0, V * P.px_view_stride, x->stream));
@@ -247,6 +252,7 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     for (void *p : x->allocs) (void)hipFree(p);
     if (x->h_counts) (void)hipHostFree(x->h_counts);
+    if (x->h_valid_quads) (void)hipHostFree((void *)x->h_valid_quads);
     for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_done) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_down) (void)hipEventDestroy(e);
@@ -419,6 +425,29 @@ extern "C" int sl3d_get_projection_matrices(sl3d_ctx *x, double A_cam[12], doubl
 static int launched(sl3d_ctx *x, int hip_err);
 static int need_keep(sl3d_ctx *x);
 
+// k_mask_prepare has counted the quads of `view` that hold a valid pixel; the count follows it to the host on the same stream (4
+// bytes into pinned memory, no event, no wait: until it lands the slot holds 0xffffffff = unknown)
+static int mask_count_to_host(sl3d_ctx *x, int view)
+{
+    x->h_valid_quads[view] = 0xffffffffu;
+    HIPCHK(x, hipMemcpyAsync((void *)(x->h_valid_quads + view), x->d_valid_quads + view, sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
+    return SL3D_OK;
+}
+
+// true if every view of [first, first + n) is KNOWN to be sparsely selected (fewer than 65 % of its quads hold a valid pixel): a
+// small launch over such views takes the large-launch instantiation (choose_fused).  Unknown (the count has not landed, or no
+// mask was ever set) counts as dense: that is the default this library was tuned on.
+static bool sparse_views(const sl3d_ctx *x, int first, int n)
+{
+    if (n > SL3D_SMALL_LAUNCH_VIEWS) return false;  // (only small launches have the choice)
+    const double quads = (double)(x->P.pitch >> 2) * (double)x->P.H;
+    for (int v = first; v < first + n; v++) {
+        const unsigned c = x->h_valid_quads[v];
+        if (c == 0xffffffffu || (double)c >= 0.65 * quads) return false;
+    }
+    return true;
+}
+
 static int check_view(sl3d_ctx *x, int view, int n = 1)
 {
     if (!x) return SL3D_E_INVALID_ARG;
@@ -455,6 +484,8 @@ extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t str
     HIPCHK(x, hipMemcpy2DAsync(dst, P.mpitch, m + (size_t)gy0 * stride + gx0, stride, (size_t)(gx1 - gx0), (size_t)(gy1 - gy0),
                                hipMemcpyHostToDevice, x->stream));
     rc = launched(x, launch_mask_prepare(P, view, x->d_mask_raw, x->stream));
+    if (rc) return rc;
+    rc = mask_count_to_host(x, view);
     if (rc) return rc;
     if (!is_pinned_host(m)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
@@ -496,6 +527,8 @@ extern "C" int sl3d_set_mask_colrow(sl3d_ctx *x, int view, const int32_t *sel)
     rc = launched(x, launch_mask_from_colrow(P, (const int *)x->d_colrow, gx0, gy0, ncols, nrows, x->d_mask_raw, x->stream));
     if (rc) return rc;
     rc = launched(x, launch_mask_prepare(P, view, x->d_mask_raw, x->stream));
+    if (rc) return rc;
+    rc = mask_count_to_host(x, view);
     if (rc) return rc;
     if (!is_pinned_host(sel)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
@@ -713,7 +746,7 @@ extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE(x);
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream));
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream, sparse_views(x, first_view, n_views)));
 }
 
 // the k_fused instantiation sl3d_run / sl3d_run_clouds launches for a batch of n_views views of this context, as rocprofv3 spells it
@@ -721,7 +754,7 @@ extern "C" int sl3d_fused_kernel_name(sl3d_ctx *x, int n_views, int clouds, char
 {
     if (!x || !buf || capacity == 0 || n_views < 1) return fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: null argument");
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called (the rig class is part of the name)");
-    const int n = fused_kernel_name(x->P, x->rig, n_views, x->keep, clouds ? 2 : 0, buf, capacity);
+    const int n = fused_kernel_name(x->P, x->rig, n_views, x->keep, clouds ? 2 : 0, buf, capacity, n_views <= x->cfg.max_views && sparse_views(x, 0, n_views));
     return n > 0 && (size_t)n < capacity ? SL3D_OK : fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: buffer too small");
 }
 
@@ -732,7 +765,7 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE(x);
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
-    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream));
+    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream, sparse_views(x, first_view, n_views)));
     if (rc) return rc;
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));
@@ -910,7 +943,7 @@ int sl3d_process_views_enqueue(sl3d_ctx *x, int n_views, const uint8_t *const *p
         }
         HIPCHK(x, hipEventRecord(x->ev_up[(size_t)slot], x->s_h2d));
         HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_up[(size_t)slot], 0));
-        const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, 0, x->stream));
+        const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, 0, x->stream, sparse_views(x, slot, 1)));
         if (rc) return rc;
         HIPCHK(x, hipEventRecord(x->ev_done[(size_t)slot], x->stream));
         HIPCHK(x, hipStreamWaitEvent(x->s_d2h, x->ev_done[(size_t)slot], 0));
@@ -1005,7 +1038,7 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
     ON_DEVICE(x);
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
-    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 2, x->stream));
+    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 2, x->stream, sparse_views(x, first_view, n_views)));
     if (rc) return rc;
     return launched(x, launch_seg_scan(x->P, first_view, n_views, x->stream));
 }

@@ -26,6 +26,8 @@ struct sl3d_ctx {
     std::string err;
     uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
     uint8_t *d_mask_raw = nullptr;            // sl3d_set_mask: the caller's bytes of one view (window + halo), staged for k_mask_prepare
+    unsigned *d_valid_quads = nullptr;        // [max_views] quads with a valid pixel, counted by k_mask_prepare ...
+    volatile unsigned *h_valid_quads = nullptr;  // ... and copied here (pinned) behind it; 0xffffffff = not (yet) known
     float *d_points = nullptr;
     unsigned *d_blk_cnt = nullptr;            // compaction scratch: per-1024-pixel block counts,
     unsigned long long *d_blk_off = nullptr;  // their exclusive scan, and the total

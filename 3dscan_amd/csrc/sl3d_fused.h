@@ -18,6 +18,7 @@
 // start stagger, un-split pixel loop, the single-pass look-back compaction, other block sizes / occupancies) is recorded in
 // DESIGN.md section 4 and profiles/README.md; git history has the code.
 #pragma once
+#include <stdlib.h>
 #include "sl3d_device.h"
 
 #define SL3D_BLOCK 256 /* threads per block: a block is a 1024-pixel tile of the scan, 4 waves = 4 segments of 256 pixels */
@@ -937,12 +938,14 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
 // the unroll bound 16 beyond; the parity mode uses the bounds 8 / 12 / 16 with per-plane tests.  Dense 3-step launches
 // of at most SL3D_SMALL_LAUNCH_VIEWS views take the instantiation without the LDS reciprocal table (re-measured with the streaming
 // stores: 8 views 185.6-187.5 us through it against 183.8-184.7, 16 views +-0: stays at 4).
-#define SL3D_SMALL_LAUNCH_VIEWS 4
 struct FusedChoice {
     int nmax;
     bool exact, small;  // exact: both axes have exactly nmax planes.  (!exact, timed kernels, nmax <= 12: the padded form, issue_gray)
 };
-inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh, int n_views)
+// prefer_gated: the views of the launch are sparsely selected -- a small launch then takes the large-launch instantiation, whose
+// plane requests wait for the valid bits instead of going out first (one view of 1080p with 19 % of the frame selected, as in the
+// reference's real captures: 15.8 us against 22.2; a full frame: 26.9 against 24.6 -- profiles/r04_sparse_mask.txt)
+inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh, int n_views, bool prefer_gated = false)
 {
     FusedChoice c;
     const int m = nv > nh ? nv : nh;
@@ -950,7 +953,10 @@ inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh,
     if (c.exact) c.nmax = nv;
     else if (!keep && m <= 12) c.nmax = m < 6 ? 6 : m;  // padded (4-/5-step fringes: always)
     else c.nmax = m <= 8 ? 8 : (m <= 12 ? 12 : SL3D_MAX_GRAY);
-    c.small = !keep && !fgen && n_views <= SL3D_SMALL_LAUNCH_VIEWS;
+    c.small = !keep && !fgen && n_views <= SL3D_SMALL_LAUNCH_VIEWS && !prefer_gated;
+#ifdef SL3D_MEASURE
+    if (getenv("SL3D_NO_SMALL")) c.small = false;
+#endif
     return c;
 }
 
@@ -958,7 +964,7 @@ template <bool KEEP, bool FGEN, int RIG, int CMODE>
 static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     const dim3 block(SL3D_BLOCK, 1, 1);
-    const FusedChoice c = choose_fused(KEEP, FGEN, CMODE, nv, nh, n_views);
+    const FusedChoice c = choose_fused(KEEP, FGEN, CMODE, nv, nh, n_views, P.prefer_gated != 0);
     constexpr bool HAS_SMALL = !KEEP && !FGEN;  // (the 3-step timed families have the second instantiation, dense and clouds)
     const long quads_ = (long)(P.pitch >> 2) * P.H;
     const dim3 small_grid((((unsigned)((quads_ + SL3D_SMALL_BLOCK - 1) / SL3D_SMALL_BLOCK)) + 7u) & ~7u, grid.y, 1);

@@ -44,9 +44,10 @@ static int timed_rig(const KParams &P, int rig)
 // rig: 0 / 1 / 2 / 3 (sl3d_fused.h; the host knows the calibration, the timed kernels fold it at compile time).
 // cmode: 0 = dense xyz + valid planes, 2 = segmented clouds (KParams::clouds / seg_counts must be set).
 // Returns the hipError_t of THIS launch.
-int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream)
+int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream, bool prefer_gated)
 {
     KParams P = P_;
+    P.prefer_gated = prefer_gated ? 1 : 0;
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: consecutive tiles go round the 8 XCDs
     const int vpt = views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0);
@@ -75,10 +76,10 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
 
 // the instantiation launch_fused picks for such a launch, spelled as rocprofv3 prints it (bench.py names the kernel its roofline
 // figure is about; derived from the same choose_fused / timed_rig the launch uses, so it cannot go stale)
-int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap)
+int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap, bool prefer_gated)
 {
     const bool fgen = P.F != 3;
-    const FusedChoice c = choose_fused(keep, fgen, cmode, P.Nv, P.Nh, n_views);
+    const FusedChoice c = choose_fused(keep, fgen, cmode, P.Nv, P.Nh, n_views, prefer_gated);
     auto b = [](bool v) { return v ? "true" : "false"; };
     return snprintf(buf, cap, "sl3d::k_fused<%s, %d, %s, %s, %d, %d, %s>", b(keep), c.nmax, b(fgen), b(c.exact), keep ? 0 : timed_rig(P, rig), keep ? 0 : cmode,
                     b(!c.small));

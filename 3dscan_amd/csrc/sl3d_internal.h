@@ -100,6 +100,9 @@ struct KParams {
     unsigned long long *cloud_totals;  // [view] number of valid points -- HOST memory mapped into the device: k_seg_scan stores the
                                        // count where sl3d_get_cloud_counts reads it after the stream has drained (no copy)
     int n_tiles;               // 1024-pixel tiles per view = blocks of the fused kernel along x that own pixels
+    unsigned *valid_quads;     // [view]: quads of the view with at least one valid pixel, counted by k_mask_prepare (how sparse a mask is
+                               // decides which instantiation a SMALL launch takes: launch_fused)
+    int prefer_gated;          // set per launch (host only): small launch over sparsely selected views -> the large-launch kernel
     // a segment's first seg_counts[view][seg] slots are its valid points in scan order
     unsigned *seg_counts;              // [view][n_segs]
     unsigned long long *seg_offsets;   // [view][n_segs] exclusive scan of the counts (k_seg_scan)
@@ -118,9 +121,11 @@ struct KParams {
 
 // launchers (sl3d_fused_launch.hip, sl3d_kernels.hip); `stream` is a hipStream_t
 // cmode: 0 = dense xyz + valid planes, 2 = segmented clouds
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream);
+#define SL3D_SMALL_LAUNCH_VIEWS 4  // launches of at most this many views take the small-launch instantiation (sl3d_fused.h)
+// prefer_gated: the views of a small launch are sparsely selected (sl3d_capi.cpp: sparse_views)
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream, bool prefer_gated = false);
 // the k_fused instantiation such a launch runs, as rocprofv3 spells it; returns snprintf's value
-int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap);
+int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap, bool prefer_gated = false);
 // segmented clouds: offsets / totals of views [first_view, first_view + n_views) from the counts the fused kernel stored
 int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream);
 // segments -> contiguous: view first_view+k's points to dst + 3*k*dst_view_stride_points (dst: device memory or mapped host memory)

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int view,
     m.mpitch = P.mpitch;
     m.col0 = P.col0; m.row0 = P.row0; m.fullW = P.fullW; m.fullH = P.fullH;
     const int c0 = x * 4 - SL3D_MASK_LPAD, wr = r - SL3D_MASK_HALO;  // window column of byte 0, window row
+    unsigned has = 0u;
     const int gy = P.row0 + wr;
     unsigned norm = 0;
 #pragma unroll
@@ -47,13 +48,19 @@ __global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int view,
         for (int k = 0; k < 4; k++)
             if (c0 + k < P.W && m.valid(P.col0 + c0 + k, gy)) band |= 1u << (8 * k);
         *(unsigned *)((uint8_t *)P.band + (size_t)view * P.px_view_stride + (size_t)wr * P.pitch + (size_t)c0) = band;
+        has = band != 0u ? 1u : 0u;
     }
+    // how many quads of the view hold a valid pixel: one atomic per wave (the host reads the sum when it picks the instantiation
+    // of a small launch -- a launch that asks for its planes before it knows the mask is the wrong one for a sparse selection)
+    const unsigned long long b = __ballot(has != 0u);
+    if (b != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(true))) atomicAdd(P.valid_quads + view, (unsigned)__popcll(b));
 }
 
 int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream)
 {
     const long n = (long)(P.mpitch >> 2) * (P.H + 2 * SL3D_MASK_HALO);
     (void)hipGetLastError();
+    (void)hipMemsetAsync(P.valid_quads + view, 0, sizeof(unsigned), (hipStream_t)stream);
     hipLaunchKernelGGL(k_mask_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, view, raw);
     return (int)hipGetLastError();
 }

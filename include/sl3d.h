@@ -150,8 +150,8 @@ int sl3d_get_projection_matrices(sl3d_ctx *ctx, double A_cam[12], double A_proj[
 /* selected_region of image_scissor() m_tech_project_console.cpp:146-238, handed over as a
  * FULL-FRAME row-major u8 plane (full_width x full_height); a pixel is selected iff byte == 1
  * (every consumer in the reference tests `== 1`).  The context copies its window plus a 2-pixel halo in ONE 2-D copy and
- * prepares it on the device (bytes normalised to 0/1, border band of the boundary removal evaluated by a kernel): no host
- * pass over the mask.  Pageable memory is consumed before the call returns; PINNED memory (sl3d_host_alloc) is read by
+ * prepares it on the device (bytes normalised to 0/1, border band of the boundary removal evaluated by a kernel, the selected
+ * quads counted -- a launch of a few sparsely selected views picks its kernel by that count): no host pass over the mask.  Pageable memory is consumed before the call returns; PINNED memory (sl3d_host_alloc) is read by
  * asynchronous DMA on the context's stream, so it must stay unchanged until the next synchronising call on the context
  * (any getter, sl3d_synchronize) -- the call then costs a copy and a launch (tens of microseconds at 1080p). */
 int sl3d_set_mask(sl3d_ctx *ctx, int view, const uint8_t *full_frame_mask, size_t stride);

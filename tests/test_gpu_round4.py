@@ -366,3 +366,52 @@ def test_padded_gray_axes_take_the_straight_line_kernels(Nv, Nh, fwv, fwh, PW, P
         assert np.array_equal(clouds[v], batch[v][0][ovalid == 1]), v
         n_valid += int(ovalid.sum())
     assert n_valid > 0 or min(Nv, Nh) <= 2
+
+
+# ---- sparse selections: a small launch asks the mask first ------------------------------------------------------------------------
+def test_small_launch_over_sparse_masks_takes_the_gated_kernel():
+    """k_mask_prepare counts the quads of a view that hold a valid pixel; a launch of at most 4 views whose views are ALL known to be
+    sparsely selected (< 65 % of the quads; the reference's real captures select 19 % of the frame) takes the large-launch
+    instantiation, which requests a view's planes only for quads its valid bits leave standing, instead of the small-launch one,
+    which requests them first (one 1080p view at 19 %: 15.8 us against 22.2, profiles/r04_sparse_mask.txt).  Which kernel runs must
+    not change a bit of the result: one view alone and in launches of 2 and 4, sparse and dense views mixed, dense results and
+    ordered clouds, against the oracle."""
+    from oracle.oracle import Oracle
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, PW, PH, N, fw = 960, 540, 1024, 768, 9, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
+    dense = syn.default_mask(W, H)
+    sparse = np.zeros((H, W), np.uint8)
+    sparse[150:390, 300:700] = 1                       # 18.5 % of the frame
+    rng = np.random.default_rng(3)
+    sparse[rng.random((H, W)) < 0.02] = 0
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=5) as sc:
+        sc.set_calibration(*cal)
+        for v in range(5):
+            sc.set_mask(sparse if v < 4 else dense, view=v)     # (pageable source: the call returns after the count has landed)
+            sc.synth_view(v, plane=(1.5 * v, 0.05, 0.04), view_id=v, noise=2)
+        for n in (1, 2, 4):
+            assert sc.fused_kernel_name(n).endswith(", 1, 0, true>"), sc.fused_kernel_name(n)                 # views 0..n-1: all sparse
+            assert sc.fused_kernel_name(n, clouds=True).endswith(", 1, 2, true>")
+        sc.run(0, 4)
+        batch = [sc.points(v) for v in range(4)]
+        clouds = sc.fused_clouds(0, 4)
+        sc.run(3, 2)                                            # views 3 (sparse) + 4 (dense): the small-launch kernel
+        mixed = [sc.points(3), sc.points(4)]
+        assert np.array_equal(mixed[0][1], batch[3][1]) and np.array_equal(mixed[0][0], batch[3][0], equal_nan=True)
+        for v in range(4):
+            sc.run(v, 1)
+            one = sc.points(v)
+            assert np.array_equal(one[1], batch[v][1]) and np.array_equal(one[0], batch[v][0], equal_nan=True), v
+            assert np.array_equal(sc.fused_clouds(v, 1)[0], clouds[v]), v
+        frames = [(sc.frames(0, v), sc.frames(1, v)) for v in (0, 3, 4)]
+        sc.set_mask(dense, view=0)
+        assert sc.fused_kernel_name(1).endswith(", 1, 0, false>")                                              # view 0 is dense now
+    for (v, m, got), fr in zip(((0, sparse, batch[0]), (3, sparse, batch[3]), (4, dense, mixed[1])), frames):
+        o = Oracle(W, H, PW, PH, N, N, fw, fw)
+        o.set_mask(m)
+        o.set_calibration(*cal)
+        oxyz, ovalid, _ = o.run_scan_rowmajor(*fr)
+        assert int(ovalid.sum()) > 50_000
+        assert np.array_equal(got[1], ovalid), v
+        assert_points_close(got[0], oxyz, ovalid == 1)
