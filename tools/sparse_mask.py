@@ -32,8 +32,11 @@ with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=R) as sc:
         for v in range(R):
             sc.set_mask(m, view=v)
         sc.synchronize()
-        for n_views in (1, 8):
-            run = (lambda i: sc.run(i % R, 1)) if n_views == 1 else (lambda i: sc.run(0, 8))
+        for n_views, clouds in ((1, False), (8, False), (1, True), (8, True)):
+            if clouds:
+                run = (lambda i: sc.run_clouds(i % R, 1)) if n_views == 1 else (lambda i: sc.run_clouds(0, 8))
+            else:
+                run = (lambda i: sc.run(i % R, 1)) if n_views == 1 else (lambda i: sc.run(0, 8))
             reps = 3000 if n_views == 1 else 600
             for i in range(reps // 3):
                 run(i)
@@ -42,4 +45,5 @@ with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=R) as sc:
             for i in range(reps):
                 run(i)
             ms = sc.timer_stop() / reps
-            print(f"mask covers {frac * 100:5.1f} %: {n_views} view(s) per launch {ms * 1e3 / n_views:7.2f} us per view   {sc.fused_kernel_name(n_views)}")
+            what = "ordered clouds (sl3d_run_clouds)" if clouds else "dense planes   (sl3d_run)       "
+            print(f"mask covers {frac * 100:5.1f} %: {what} {n_views} view(s) per launch {ms * 1e3 / n_views:7.2f} us per view   {sc.fused_kernel_name(n_views, clouds=clouds)}")
