@@ -444,7 +444,7 @@ __device__ __forceinline__ void decode_gray(const unsigned (&g)[2][NMAX], const 
 // instead of shifts by a loop counter); k = 2*pair + i only addresses LDS and the frame.
 template <bool RCP_TAB>
 __device__ __forceinline__ unsigned pixel_A(const KParams &P, const Item &it, int F, int i, int k, unsigned vbits, const unsigned (&f)[2][4],
-                                            const unsigned (&code)[2][2], const double *s_rcp, int *my_cp)
+                                            const unsigned (&code)[2][2], const double *s_rcp, int *pair_cp)
 {
     const int sh = 8 * i;
     const int code_v = (int)((code[0][0] >> (16 * i)) & 0xffffu);
@@ -458,8 +458,8 @@ __device__ __forceinline__ unsigned pixel_A(const KParams &P, const Item &it, in
     wh = shift_pi(wh);
     int cx, cy;
     const bool ok = correspond_px(P, it.gx0 + k, it.gy, wv, wh, code_v, code_h, cx, cy) && ((vbits >> i) & 1u);
-    my_cp[3 * k] = ok ? cx : 0;  // a rejected pixel keeps a harmless table index
-    my_cp[3 * k + 1] = ok ? cy : 0;
+    pair_cp[3 * i] = ok ? cx : 0;  // (the pair's 6 staging words) a rejected pixel keeps a harmless table index
+    pair_cp[3 * i + 1] = ok ? cy : 0;
     return ok ? 1u : 0u;
 }
 
@@ -470,9 +470,9 @@ __device__ __forceinline__ unsigned pixel_A(const KParams &P, const Item &it, in
 // the last waves of the launch compute alone -- and there a wave's own latency is what the launch waits for.
 template <bool RCP_TAB>
 __device__ __forceinline__ void phase_A_pair(const KParams &P, const Item &it, int F, int j, unsigned &vbits, unsigned (&f)[2][4], unsigned (&code)[2][2],
-                                             const double *s_rcp, int *my_cp, unsigned &vout)
+                                             const double *s_rcp, int *pair_cp, unsigned &vout)
 {
-    const unsigned ok0 = pixel_A<RCP_TAB>(P, it, F, 0, 2 * j, vbits, f, code, s_rcp, my_cp), ok1 = pixel_A<RCP_TAB>(P, it, F, 1, 2 * j + 1, vbits, f, code, s_rcp, my_cp);
+    const unsigned ok0 = pixel_A<RCP_TAB>(P, it, F, 0, 2 * j, vbits, f, code, s_rcp, pair_cp), ok1 = pixel_A<RCP_TAB>(P, it, F, 1, 2 * j + 1, vbits, f, code, s_rcp, pair_cp);
     vout = (vout >> 16) | (ok0 << 16) | (ok1 << 24);  // after two pairs: valid byte of pixel k at byte k
 #pragma unroll
     for (int a = 0; a < 2; a++) {
@@ -489,7 +489,15 @@ __device__ __forceinline__ unsigned phase_A(const KParams &P, const Item &it, in
 {
     unsigned vout = 0;
 #pragma unroll(UNROLL ? 2 : 1)
-    for (int j = 0; j < 2; j++) phase_A_pair<RCP_TAB>(P, it, F, j, vbits, f, code, s_rcp, my_cp, vout);
+    for (int j = 0; j < 2; j++) {
+        // the pair's 6 staging words (24 bytes): in the rolled loop the offset is built from shifts of a VGPR copy of j, as in
+        // phase_B -- `base + 24 * j` became a v_mad_u64_u32 whose addend pair is (LDS base, the NEXT register: the mask dword of the
+        // view after next, still in flight) and put an s_waitcnt vmcnt(0) in the middle of stage 5: the wave waited for the
+        // acknowledgement of the stores it had just issued (read in the ISA at the end of round 4)
+        int j8 = j * 8;
+        if (!UNROLL) asm volatile("" : "+v"(j8));
+        phase_A_pair<RCP_TAB>(P, it, F, j, vbits, f, code, s_rcp, my_cp + (UNROLL ? 6 * j : ((j8 << 1) + j8) >> 2), vout);
+    }
     return vout;
 }
 
@@ -882,6 +890,14 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         }
         if (vbits != 0) decode_gray<NMAX, PLANES>(g, iv, Nv, Nh, code);  // waits for the planes of this view
         if (view == it.v_begin) SL3D_STAMP(4);
+        // the NEXT view's valid bits, taken here -- its mask dword is older than the planes just decoded, so it has landed, and no
+        // store of this view has been issued yet.  Taken at the pipeline point (where they are needed) they cost an s_waitcnt
+        // vmcnt(0) there: one in-order counter, and by then the deferred stores are in it
+        unsigned vb_pre = 0;
+        if (PIPE) {
+            vb_pre = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+            asm volatile("" : "+v"(vb_pre));  // (here, not sunk to its use)
+        }
         if (DEFER) {
             if (view > it.v_begin) store_view(view - 1, pvout);
             if (!SEG && vbits == 0) fill_nan(my_xyz);
@@ -896,7 +912,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         // loads, so -- vmcnt counts in issue order -- phase B starts only once those planes have landed.  Requesting them first was
         // built and measured: distorted rig 77.8-78.2 Gpx/s against 79.0-79.5 for this order, profiles/r03_gather_first_ab.txt.)
         if (PIPE && view + 1 < it.v_end) {
-            vb_next = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+            vb_next = vb_pre;
             // UNCONDITIONAL (the index is clamped; the last view's dword is asked for once more): with `if (view + 2 < v_end)` the
             // new value meets the old one in a phi, whose copy the compiler places behind the plane loads below -- and a copy of a
             // loaded value is a use: s_waitcnt vmcnt(0), i.e. stage 7 of this view waited for ALL of the next view's planes to land
