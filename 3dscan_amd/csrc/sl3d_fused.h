@@ -840,9 +840,9 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     }
     SL3D_STAMP(2);
     // The mask dword of the NEXT view is requested a view ahead, so a wave never waits a full memory round trip for it before it
-    // can ask for its 11.5 KB of planes.  (Round 3 read the ISA of this loop: the wait-count pass puts an s_waitcnt vmcnt(0) at the
-    // pipeline point and at the loop latch -- one in-order counter for loads and stores; a schedule without either was built and
-    // measured at +-0.3 %, profiles/r03_mask_early_ab.txt.  The simpler code stays.)
+    // can ask for its 11.5 KB of planes.  (gfx950 has one in-order vmcnt for loads and stores, and the wait-count pass is
+    // conservative wherever a register a load is still writing is touched: round 4 removed, one by one, every s_waitcnt vmcnt(0)
+    // of this loop except the decode's -- see the comments at the pipeline point, in phase_A / phase_B and at vb_pre.)
     unsigned vb_next = 0;
     if (PIPE) {
         vb_next = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
