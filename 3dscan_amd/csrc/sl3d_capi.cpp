@@ -435,11 +435,11 @@ static int mask_count_to_host(sl3d_ctx *x, int view)
 }
 
 // true if every view of [first, first + n) is KNOWN to be sparsely selected (fewer than 65 % of its quads hold a valid pixel): a
-// small launch over such views takes the large-launch instantiation (choose_fused).  Unknown (the count has not landed, or no
-// mask was ever set) counts as dense: that is the default this library was tuned on.
+// launch over such views takes the instantiation whose every plane request waits for the valid bits (choose_fused: the large-launch
+// kernel without early requests, also for a small launch).  Unknown (the count has not landed, or no mask was ever set) counts as
+// dense: that is the default this library was tuned on.
 static bool sparse_views(const sl3d_ctx *x, int first, int n)
 {
-    if (n > SL3D_SMALL_LAUNCH_VIEWS) return false;  // (only small launches have the choice)
     const double quads = (double)(x->P.pitch >> 2) * (double)x->P.H;
     for (int v = first; v < first + n; v++) {
         const unsigned c = x->h_valid_quads[v];

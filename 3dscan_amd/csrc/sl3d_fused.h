@@ -781,7 +781,12 @@ struct RadialLds<3> {
 //       view's planes requested before the mask is known (EARLY).  Both quotients are proven equal to the host's libm on the whole
 //       lattice by the device self-check.  Round 3, alternating on one box: 1 view 30.3 against 31.6 us, 2 views -2.7 %, 4 views
 //       -1 %; at 16 views per launch the table is as fast (dense) or 1.4 % faster (clouds) -- profiles/r03_rcp_table_ab*.txt.
-template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE = 0, bool RCPT = true>
+// EARLY the first view's planes of an item are requested before its mask is known (pipelined kernels only).  Always in the
+//       small-launch instantiation.  In the large-launch one: when the launch's views are not known to be sparsely selected
+//       (launch_fused) -- a block's prologue is one memory round trip shorter: 16 views +1.4 %, 8 views +1.7 %, clouds +0.8 %
+//       (profiles/r04_early_large_ab.txt); EARLY = false is the large-launch kernel for sparse selections, whose every request
+//       waits for the valid bits.
+template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE, bool RCPT, bool EARLY_>
 __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
     constexpr bool SEG = CMODE == 2;
@@ -812,7 +817,8 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     // EARLY (the small-launch instantiation of the pipelined dense kernels): the first view's planes are requested
     // UNCONDITIONALLY, right behind the item's mask / camera-table requests and before any of those is waited for, at the price of
     // plane loads for quads that turn out to be masked off (profiles/r03_early_planes_ab.txt)
-    constexpr bool EARLY = !RCPT && PIPE;
+    static_assert(RCPT || EARLY_ == PIPE, "the small-launch instantiation: early requests iff pipelined");
+    constexpr bool EARLY = EARLY_ && PIPE;
     constexpr bool UNROLL = !RCPT;  // the small-launch instantiation: both pixel pairs of phases A and B in one basic block (see phase_A)
 #ifdef SL3D_NO_SPLIT
     constexpr bool SPLIT = false;
@@ -957,11 +963,13 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
 struct FusedChoice {
     int nmax;
     bool exact, small;  // exact: both axes have exactly nmax planes.  (!exact, timed kernels, nmax <= 12: the padded form, issue_gray)
+    bool early;         // the last template argument (EARLY): see k_fused
 };
 // prefer_gated: the views of the launch are sparsely selected -- a small launch then takes the large-launch instantiation, whose
 // plane requests wait for the valid bits instead of going out first (one view of 1080p with 19 % of the frame selected, as in the
 // reference's real captures: 15.8 us against 22.2; a full frame: 26.9 against 24.6 -- profiles/r04_sparse_mask.txt)
-inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh, int n_views, bool prefer_gated = false)
+// rig: the rig class the launch runs (0 = the un-pipelined general kernel: no early requests there)
+inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh, int n_views, bool prefer_gated, int rig)
 {
     FusedChoice c;
     const int m = nv > nh ? nv : nh;
@@ -973,6 +981,8 @@ inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh,
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_NO_SMALL")) c.small = false;
 #endif
+    const bool pipelined = !keep && rig != 0 && m <= 12;
+    c.early = c.small ? pipelined : (pipelined && !fgen && !prefer_gated);
     return c;
 }
 
@@ -980,7 +990,7 @@ template <bool KEEP, bool FGEN, int RIG, int CMODE>
 static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     const dim3 block(SL3D_BLOCK, 1, 1);
-    const FusedChoice c = choose_fused(KEEP, FGEN, CMODE, nv, nh, n_views, P.prefer_gated != 0);
+    const FusedChoice c = choose_fused(KEEP, FGEN, CMODE, nv, nh, n_views, P.prefer_gated != 0, RIG);
     constexpr bool HAS_SMALL = !KEEP && !FGEN;  // (the 3-step timed families have the second instantiation, dense and clouds)
     const long quads_ = (long)(P.pitch >> 2) * P.H;
     const dim3 small_grid((((unsigned)((quads_ + SL3D_SMALL_BLOCK - 1) / SL3D_SMALL_BLOCK)) + 7u) & ~7u, grid.y, 1);
@@ -988,11 +998,17 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
     do {                                                                                                                                   \
         if constexpr (HAS_SMALL) {                                                                                                         \
             if (c.small) {                                                                                                                 \
-                hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE, false>), small_grid, dim3(SL3D_SMALL_BLOCK), 0, st, P, C, first_view, n_views, vpt); \
+                hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE, false, RIG != 0>), small_grid, dim3(SL3D_SMALL_BLOCK), 0, st, P, C, first_view, n_views, vpt); \
                 break;                                                                                                                     \
             }                                                                                                                              \
         }                                                                                                                                  \
-        hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE>), grid, block, 0, st, P, C, first_view, n_views, vpt);                  \
+        if constexpr (HAS_SMALL && RIG != 0 && (NM) <= 12) {                                                                               \
+            if (c.early) {                                                                                                                 \
+                hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE, true, true>), grid, block, 0, st, P, C, first_view, n_views, vpt); \
+                break;                                                                                                                     \
+            }                                                                                                                              \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((k_fused<KEEP, NM, FGEN, EX, RIG, CMODE, true, false>), grid, block, 0, st, P, C, first_view, n_views, vpt);     \
     } while (0)
     if constexpr (!KEEP) {
         if constexpr (!FGEN) {

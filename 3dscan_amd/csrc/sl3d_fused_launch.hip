@@ -79,10 +79,10 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
 int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap, bool prefer_gated)
 {
     const bool fgen = P.F != 3;
-    const FusedChoice c = choose_fused(keep, fgen, cmode, P.Nv, P.Nh, n_views, prefer_gated);
+    const int r = keep ? 0 : timed_rig(P, rig);
+    const FusedChoice c = choose_fused(keep, fgen, cmode, P.Nv, P.Nh, n_views, prefer_gated, r);
     auto b = [](bool v) { return v ? "true" : "false"; };
-    return snprintf(buf, cap, "sl3d::k_fused<%s, %d, %s, %s, %d, %d, %s>", b(keep), c.nmax, b(fgen), b(c.exact), keep ? 0 : timed_rig(P, rig), keep ? 0 : cmode,
-                    b(!c.small));
+    return snprintf(buf, cap, "sl3d::k_fused<%s, %d, %s, %s, %d, %d, %s, %s>", b(keep), c.nmax, b(fgen), b(c.exact), r, keep ? 0 : cmode, b(!c.small), b(c.early));
 }
 
 }  // namespace sl3d

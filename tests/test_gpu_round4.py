@@ -298,7 +298,7 @@ def test_small_launches_partial_tile_and_masked_waves(n_views, rig):
             m[H - 4:, :] = 0
     with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=n_views) as sc:
         sc.set_calibration(*cal)
-        want = {"reference": ", 1, 0, false>", "radial": ", 3, 0, false>", "distorted": ", 2, 0, false>"}[rig]
+        want = {"reference": ", 1, 0, false, true>", "radial": ", 3, 0, false, true>", "distorted": ", 2, 0, false, true>"}[rig]   # small launch
         assert sc.fused_kernel_name(n_views).endswith(want), sc.fused_kernel_name(n_views)
         for v in range(n_views):
             sc.set_mask(masks[v], view=v)
@@ -391,8 +391,8 @@ def test_small_launch_over_sparse_masks_takes_the_gated_kernel():
             sc.set_mask(sparse if v < 4 else dense, view=v)     # (pageable source: the call returns after the count has landed)
             sc.synth_view(v, plane=(1.5 * v, 0.05, 0.04), view_id=v, noise=2)
         for n in (1, 2, 4):
-            assert sc.fused_kernel_name(n).endswith(", 1, 0, true>"), sc.fused_kernel_name(n)                 # views 0..n-1: all sparse
-            assert sc.fused_kernel_name(n, clouds=True).endswith(", 1, 2, true>")
+            assert sc.fused_kernel_name(n).endswith(", 1, 0, true, false>"), sc.fused_kernel_name(n)          # views 0..n-1: all sparse
+            assert sc.fused_kernel_name(n, clouds=True).endswith(", 1, 2, true, false>")
         sc.run(0, 4)
         batch = [sc.points(v) for v in range(4)]
         clouds = sc.fused_clouds(0, 4)
@@ -406,7 +406,8 @@ def test_small_launch_over_sparse_masks_takes_the_gated_kernel():
             assert np.array_equal(sc.fused_clouds(v, 1)[0], clouds[v]), v
         frames = [(sc.frames(0, v), sc.frames(1, v)) for v in (0, 3, 4)]
         sc.set_mask(dense, view=0)
-        assert sc.fused_kernel_name(1).endswith(", 1, 0, false>")                                              # view 0 is dense now
+        assert sc.fused_kernel_name(1).endswith(", 1, 0, false, true>")                                        # view 0 is dense now
+        assert sc.fused_kernel_name(5).endswith(", 1, 0, true, true>")                                         # a large launch, not all sparse: early requests
     for (v, m, got), fr in zip(((0, sparse, batch[0]), (3, sparse, batch[3]), (4, dense, mixed[1])), frames):
         o = Oracle(W, H, PW, PH, N, N, fw, fw)
         o.set_mask(m)

@@ -43,7 +43,7 @@ def dense_name():
     try:
         return json.loads(open(f"{src}/stats_bench.json").read())["roofline"]["kernel"].replace("sl3d::", "")
     except Exception:
-        return "k_fused<false, 10, false, true, 1, 0, true>"
+        return "k_fused<false, 10, false, true, 1, 0, true, true>"
 
 
 dense = dense_name()
@@ -54,7 +54,7 @@ def clouds_name():
     try:
         return json.loads(open(f"{src}/stats_bench.json").read())["to_compacted_clouds"]["roofline"]["kernel"].replace("sl3d::", "")
     except Exception:
-        return dense.rsplit(", 0, ", 1)[0] + ", 2, true>"
+        return dense.rsplit(", 0, ", 1)[0] + ", 2, true, true>"
 
 
 compact_kernel = clouds_name()
