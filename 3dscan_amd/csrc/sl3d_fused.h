@@ -260,10 +260,11 @@ __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglob
     it.cq = (int)(q - (unsigned)row_q * qpr);
     // SEG: a wave stores its segment with all 64 lanes (whole 16-byte chunks, lane after lane), so the lanes past the last row
     // stay, without a valid pixel; only the blocks the grid was padded with leave (they own no segment)
+    // EARLY keeps them too, until the block's barrier (their requests go to the last row: one code path, one wait count)
     if (SEG && tile_ >= (unsigned)P.n_tiles) return false;
-    if (!SEG && row_q >= P.H) return false;
+    if (!SEG && !EARLY && row_q >= P.H) return false;
     it.alive = row_q < P.H;
-    it.row = SEG ? min(row_q, P.H - 1) : row_q;
+    it.row = (SEG || EARLY) ? min(row_q, P.H - 1) : row_q;
     it.gx0 = P.col0 + it.cq * 4;
     it.gy = P.row0 + it.row;
     it.lane_off = (unsigned)it.row * (unsigned)P.pitch + (unsigned)it.cq * 4u;
@@ -800,11 +801,21 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     RadEntry *const s_rad = RadialLds<RIG>::get();                                  // rig 3: the projector's radial table
     static_assert(RIG != 3 || SL3D_BLOCK == SL3D_RAD_NODES, "one table node per thread");
     SL3D_STAMP(0);
+    constexpr bool PIPE = !KEEP && RIG != 0;  // (see below)
+    static_assert(RCPT || EARLY_ == PIPE, "the small-launch instantiation: early requests iff pipelined");
+    constexpr bool EARLY = EARLY_ && PIPE;
     // rig 3: one of the 8 copies of the table (one per XCD, as consecutive blocks go round the XCDs: all blocks of a launch would
-    // otherwise start on the same 32 cache lines of one L2 -- what cost the camera-side radial table 2 us per one-view launch)
-    if (RIG == 3) s_rad[threadIdx.x] = P.proj_rad[(blockIdx.x & 7u) * SL3D_RAD_STRIDE + threadIdx.x];
-    if (RCPT) fill_rcp_table(s_rcp);
-    if (RCPT || RIG == 3) __syncthreads();
+    // otherwise start on the same 32 cache lines of one L2 -- what cost the camera-side radial table 2 us per one-view launch).
+    // The block's LDS tables -- this one, the reciprocal table -- are filled UNDER its first memory requests where there are early
+    // ones (EARLY, below): the node is only requested here; without them, here and now.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // (a node travels as one 16-byte register quad)
+    u32x4 rad_node = {0u, 0u, 0u, 0u};
+    if (RIG == 3) rad_node = ((const u32x4 *)P.proj_rad)[(blockIdx.x & 7u) * SL3D_RAD_STRIDE + threadIdx.x];
+    if (!EARLY) {
+        if (RIG == 3) ((u32x4 *)s_rad)[threadIdx.x] = rad_node;
+        if (RCPT) fill_rcp_table(s_rcp);
+        if (RCPT || RIG == 3) __syncthreads();
+    }
     SL3D_STAMP(1);
     const int F = FGEN ? P.F : 3;
     float *my_xyz = s_xyz + threadIdx.x * 12;
@@ -813,12 +824,9 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     // PIPE (timed kernels): the planes of view v+1 are requested in the middle of view v -- after phase A, when the plane
     // registers of view v are dead, before stage 7 -- so a wave's own arithmetic runs under its own memory requests
     // (the general rig's stage 7 is too register-hungry for it: 44 bytes of scratch per lane, -9 %)
-    constexpr bool PIPE = !KEEP && RIG != 0;
-    // EARLY (the small-launch instantiation of the pipelined dense kernels): the first view's planes are requested
-    // UNCONDITIONALLY, right behind the item's mask / camera-table requests and before any of those is waited for, at the price of
-    // plane loads for quads that turn out to be masked off (profiles/r03_early_planes_ab.txt)
-    static_assert(RCPT || EARLY_ == PIPE, "the small-launch instantiation: early requests iff pipelined");
-    constexpr bool EARLY = EARLY_ && PIPE;
+    // EARLY: the first view's planes of an item are requested UNCONDITIONALLY, right behind the item's mask / camera-table requests
+    // and before any of those is waited for, at the price of plane loads for quads that turn out to be masked off
+    // (profiles/r03_early_planes_ab.txt, r04_early_large_ab.txt)
     constexpr bool UNROLL = !RCPT;  // the small-launch instantiation: both pixel pairs of phases A and B in one basic block (see phase_A)
 #ifdef SL3D_NO_SPLIT
     constexpr bool SPLIT = false;
@@ -838,10 +846,18 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     // gridDim.x is a multiple of 8 (launch_fused): consecutive tiles go round-robin over the 8 XCDs on purpose (the XCD-banded
     // order was measured at -4 %: DRAM locality across XCDs beats L2 locality for 2 % of shared bytes)
+    // (false: a lane past the last row, or a block the grid was padded with.  EARLY: block-uniform, only the latter -- a lane past the
+    // last row stays until the block's barrier, its requests go to the last row.)
     if (!item_begin<RIG, SEG, EARLY, BLK>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
-    if (EARLY) {  // planes of the first view right behind the set-up requests; then the set-up results are consumed
+    if (EARLY) {
+        // planes of the first view right behind the set-up requests; the block's LDS tables are filled while they travel (the radial
+        // node requested at the very top is the oldest request: its store waits for nothing else); then the set-up results are consumed
         issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
         issue_gray<NMAX, PLANES>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
+        if (RCPT) fill_rcp_table(s_rcp);
+        if (RIG == 3) ((u32x4 *)s_rad)[threadIdx.x] = rad_node;
+        if (RCPT || RIG == 3) __syncthreads();
+        if (!SEG && !it.alive) return;
         if (P.use_cam_table) cam_table_finish<RIG>(P, Cglobal, it, camt, my_cam);
     }
     SL3D_STAMP(2);

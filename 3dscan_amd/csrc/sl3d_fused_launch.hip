@@ -21,12 +21,16 @@ int fused_tiles(const KParams &P)
 // profiles/r03_vpt_sweep4.txt; configs[2], 3 views of 12 Mpx: 1 / 2 / 3 views per lane 0.670 / 0.681 / 0.685,
 // profiles/c2_r04_views_vpt_sweep.txt.)
 #define SL3D_VPT_MAX 4
-static int views_per_lane(unsigned bx, int n_views, int cam_table_kind)
+#define SL3D_BLOCK_SLOTS 1024 /* blocks of the fused kernel resident at once: 256 CUs x SL3D_OCC */
+static int views_per_lane(unsigned bx, int n_views, int cam_table_kind, bool small)
 {
     int vpt = 1;
     // (a two-double camera table -- tangential terms -- costs a block 16 B/px: those rigs keep 8 views per lane, measured -0.6 % at 4)
     const int cap = cam_table_kind == 2 ? 8 : SL3D_VPT_MAX;
-    while (vpt < cap && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= 4096) vpt *= 2;
+    // (large launches -- early requests, the block's LDS tables filled under them -- want their 4 views per lane as soon as one round
+    // of blocks is left: 5 / 6 / 8 / 12 views of 1080p +1.3...1.7 % at 4 views per lane against 2, profiles/r04_vpt_final.txt)
+    const long min_blocks = small ? 4096 : SL3D_BLOCK_SLOTS;
+    while (vpt < cap && vpt < n_views && (long)bx * ((n_views + 2 * vpt - 1) / (2 * vpt)) >= min_blocks) vpt *= 2;
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_VPT") && atoi(getenv("SL3D_VPT")) >= 1) vpt = atoi(getenv("SL3D_VPT"));
 #endif
@@ -50,7 +54,7 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     P.prefer_gated = prefer_gated ? 1 : 0;
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: consecutive tiles go round the 8 XCDs
-    const int vpt = views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0);
+    const int vpt = views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0, !keep && P.F == 3 && n_views <= SL3D_SMALL_LAUNCH_VIEWS);
     const dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1);
     // the timed kernels read the camera-side T1 from the per-calibration table whatever the batch is: with 8 views per lane it
     // costs nothing (1 B/px/view), with 1..4 it saves the iteration (+2..13 %), and a view's result does not depend on the

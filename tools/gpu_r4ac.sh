@@ -1,9 +1,9 @@
-# on the GPU box (round 4, session ac): early plane requests in the large-launch kernels too (a template argument; sparse selections
+# on the GPU box (round 4, sessions ac / ad): early plane requests in the large-launch kernels (ac); their LDS tables filled under those requests (ad)
 # keep the gated form) -- base = the build before (commit bc594e1)
 set -u
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-T=gpurun_out/r4ac
+T=gpurun_out/r4ad
 mkdir -p $T
 timeout 2400 python -m pytest tests -q -m gpu -x > $T/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $T/pytest.log
 CLOUDS=1 bash tools/ab.sh alt 3 > $T/ab_dense_clouds.txt 2>&1
