@@ -806,12 +806,14 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     constexpr bool EARLY = EARLY_ && PIPE;
     // rig 3: one of the 8 copies of the table (one per XCD, as consecutive blocks go round the XCDs: all blocks of a launch would
     // otherwise start on the same 32 cache lines of one L2 -- what cost the camera-side radial table 2 us per one-view launch).
-    // The block's LDS tables -- this one, the reciprocal table -- are filled UNDER its first memory requests where there are early
-    // ones (EARLY, below): the node is only requested here; without them, here and now.
+    // REQ_FIRST (every pipelined kernel): the block's LDS tables -- this one, the reciprocal table -- are filled UNDER the item's first
+    // memory requests (mask dword, camera-table entries and, with EARLY, the first view's planes): the node is only requested here.
+    // The un-pipelined kernels fill them here and now.
+    constexpr bool REQ_FIRST = PIPE;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // (a node travels as one 16-byte register quad)
     u32x4 rad_node = {0u, 0u, 0u, 0u};
     if (RIG == 3) rad_node = ((const u32x4 *)P.proj_rad)[(blockIdx.x & 7u) * SL3D_RAD_STRIDE + threadIdx.x];
-    if (!EARLY) {
+    if (!REQ_FIRST) {
         if (RIG == 3) ((u32x4 *)s_rad)[threadIdx.x] = rad_node;
         if (RCPT) fill_rcp_table(s_rcp);
         if (RCPT || RIG == 3) __syncthreads();
@@ -846,14 +848,17 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     // gridDim.x is a multiple of 8 (launch_fused): consecutive tiles go round-robin over the 8 XCDs on purpose (the XCD-banded
     // order was measured at -4 %: DRAM locality across XCDs beats L2 locality for 2 % of shared bytes)
-    // (false: a lane past the last row, or a block the grid was padded with.  EARLY: block-uniform, only the latter -- a lane past the
-    // last row stays until the block's barrier, its requests go to the last row.)
-    if (!item_begin<RIG, SEG, EARLY, BLK>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
-    if (EARLY) {
-        // planes of the first view right behind the set-up requests; the block's LDS tables are filled while they travel (the radial
-        // node requested at the very top is the oldest request: its store waits for nothing else); then the set-up results are consumed
-        issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
-        issue_gray<NMAX, PLANES>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
+    // (false: a lane past the last row, or a block the grid was padded with.  REQ_FIRST: block-uniform, only the latter -- a lane past
+    // the last row stays until the block's barrier, its requests go to the last row.)
+    if (!item_begin<RIG, SEG, REQ_FIRST, BLK>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
+    if (REQ_FIRST) {
+        // EARLY: planes of the first view right behind the set-up requests.  The block's LDS tables are filled while all of that
+        // travels (the radial node requested at the very top is the oldest request: its store waits for nothing else); then the
+        // set-up results are consumed
+        if (EARLY) {
+            issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
+            issue_gray<NMAX, PLANES>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
+        }
         if (RCPT) fill_rcp_table(s_rcp);
         if (RIG == 3) ((u32x4 *)s_rad)[threadIdx.x] = rad_node;
         if (RCPT || RIG == 3) __syncthreads();
