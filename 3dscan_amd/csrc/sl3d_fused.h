@@ -722,20 +722,24 @@ __device__ __forceinline__ void store_segment(const KParams &P, const Item &it, 
     const unsigned seg = first_lane_u32(it.tile) * 4u + wave_;
     if (lane_ == 0u) P.seg_counts[(size_t)view * (size_t)P.n_segs + seg] = total;
     float *slot = P.clouds + 3 * ((size_t)view * P.px_view_stride + (size_t)seg * SL3D_SEG_POINTS);
-    const float4 *sx = (const float4 *)my_xyz;
-    const float4 a = sx[0], b = sx[1], c = sx[2];
-    const float q[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-    wave_lds_handoff();  // every lane has read its own 12 floats before any lane overwrites a slot
     float *wbase = s_xyz + wave_ * (64u * 12u);
+    // (a wave whose 256 pixels are all valid -- the usual case away from the selection's edge -- has nothing to compact: every point
+    // already sits at its rank)
+    if (total != 4u * 64u) {
+        const float4 *sx = (const float4 *)my_xyz;
+        const float4 a = sx[0], b = sx[1], c = sx[2];
+        const float q[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        wave_lds_handoff();  // every lane has read its own 12 floats before any lane overwrites a slot
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        if ((vout >> (8 * k)) & 1u) {
-            wbase[3 * rank + 0] = q[3 * k + 0];
-            wbase[3 * rank + 1] = q[3 * k + 1];
-            wbase[3 * rank + 2] = q[3 * k + 2];
-            rank++;
-        }
-    wave_lds_handoff();  // the compacted points are in place before the chunks are read back across lanes
+        for (int k = 0; k < 4; k++)
+            if ((vout >> (8 * k)) & 1u) {
+                wbase[3 * rank + 0] = q[3 * k + 0];
+                wbase[3 * rank + 1] = q[3 * k + 1];
+                wbase[3 * rank + 2] = q[3 * k + 2];
+                rank++;
+            }
+    }
+    wave_lds_handoff();  // the (compacted) points are in place before the chunks are read back across lanes
     const unsigned chunks = (3u * total + 3u) >> 2;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 *wb4 = (const f32x4 *)wbase;
