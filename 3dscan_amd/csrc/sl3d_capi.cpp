@@ -174,11 +174,17 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     }
     ALLOC(x->d_band, V * P.px_view_stride);
     ALLOC(x->d_mask_raw, P.mask_view_stride);
-    ALLOC(x->d_valid_quads, V);
-    CREATE_CHK(hipMemsetAsync(x->d_valid_quads, 0, V * sizeof(unsigned), x->stream));
-    CREATE_CHK(hipHostMalloc((void **)&x->h_valid_quads, V * sizeof(unsigned), hipHostMallocDefault));
-    for (size_t v = 0; v < V; v++) x->h_valid_quads[v] = 0xffffffffu;
-    P.valid_quads = x->d_valid_quads;
+    x->mask_raw_slots = 1;
+    CREATE_CHK(hipMemsetAsync(x->d_mask_raw, 0, P.mask_view_stride, x->stream));
+    x->quad_blocks = mask_prepare_blocks(P);
+    CREATE_CHK(hipHostMalloc((void **)&x->h_quad_part, V * (size_t)x->quad_blocks * sizeof(unsigned long long), hipHostMallocMapped));
+    memset((void *)x->h_quad_part, 0, V * (size_t)x->quad_blocks * sizeof(unsigned long long));
+    CREATE_CHK(hipHostGetDevicePointer((void **)&x->d_quad_part, (void *)x->h_quad_part, 0));
+    x->quad_seq.assign(V, 0u);
+    x->quad_sum_seq.assign(V, 0u);
+    x->quad_sum.assign(V, 0u);
+    x->quad_src.resize(V);
+    for (size_t v = 0; v < V; v++) x->quad_src[v] = (int)v;
     CREATE_CHK(hipMemsetAsync(x->d_mask, 0, V * P.mask_view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_frames, 0, V * P.view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_valid, 0, V * P.px_view_stride, x->stream));
@@ -252,7 +258,7 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     for (void *p : x->allocs) (void)hipFree(p);
     if (x->h_counts) (void)hipHostFree(x->h_counts);
-    if (x->h_valid_quads) (void)hipHostFree((void *)x->h_valid_quads);
+    if (x->h_quad_part) (void)hipHostFree((void *)x->h_quad_part);
     for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_done) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_down) (void)hipEventDestroy(e);
@@ -425,13 +431,28 @@ extern "C" int sl3d_get_projection_matrices(sl3d_ctx *x, double A_cam[12], doubl
 static int launched(sl3d_ctx *x, int hip_err);
 static int need_keep(sl3d_ctx *x);
 
-// k_mask_prepare has counted the quads of `view` that hold a valid pixel; the count follows it to the host on the same stream (4
-// bytes into pinned memory, no event, no wait: until it lands the slot holds 0xffffffff = unknown)
-static int mask_count_to_host(sl3d_ctx *x, int view)
+// Quads of `view` that hold a valid pixel, as k_mask_prepare counted them: the sum of the view's per-block words, known only once
+// every block carries the sequence number of the view's last preparation (the blocks store straight into this host array: no copy
+// behind the kernel, no wait here; a word of an earlier preparation cannot pass for a current one).
+static bool quads_known(const sl3d_ctx *x, int view, unsigned *quads)
 {
-    x->h_valid_quads[view] = 0xffffffffu;
-    HIPCHK(x, hipMemcpyAsync((void *)(x->h_valid_quads + view), x->d_valid_quads + view, sizeof(unsigned), hipMemcpyDeviceToHost, x->stream));
-    return SL3D_OK;
+    const unsigned seq = x->quad_seq[view];
+    if (seq == 0u) return false;  // no mask was ever set
+    if (x->quad_sum_seq[view] == seq) {
+        *quads = x->quad_sum[view];
+        return true;
+    }
+    const volatile unsigned long long *p = x->h_quad_part + (size_t)x->quad_src[view] * x->quad_blocks;
+    unsigned sum = 0u;
+    for (int b = 0; b < x->quad_blocks; b++) {
+        const unsigned long long w = p[b];
+        if ((unsigned)(w >> 32) != seq) return false;
+        sum += (unsigned)w;
+    }
+    x->quad_sum_seq[view] = seq;
+    x->quad_sum[view] = sum;
+    *quads = sum;
+    return true;
 }
 
 // true if every view of [first, first + n) is KNOWN to be sparsely selected (fewer than 65 % of its quads hold a valid pixel): a
@@ -442,8 +463,8 @@ static bool sparse_views(const sl3d_ctx *x, int first, int n)
 {
     const double quads = (double)(x->P.pitch >> 2) * (double)x->P.H;
     for (int v = first; v < first + n; v++) {
-        const unsigned c = x->h_valid_quads[v];
-        if (c == 0xffffffffu || (double)c >= 0.65 * quads) return false;
+        unsigned c;
+        if (!quads_known(x, v, &c) || (double)c >= 0.65 * quads) return false;
     }
     return true;
 }
@@ -455,41 +476,111 @@ static int check_view(sl3d_ctx *x, int view, int n = 1)
     return SL3D_OK;
 }
 
-// true if `p` is pinned (hipHostMalloc / hipHostRegister) host memory: copies from it are asynchronous DMA, so the caller
-// owns the hand-over (see include/sl3d.h); pageable memory is consumed before the call returns
-static bool is_pinned_host(const void *p)
+// what kind of memory `p` is: 0 = pageable host memory (unknown to the runtime: a copy from it is consumed before the call returns),
+// 1 = pinned host memory (hipHostMalloc / hipHostRegister: copies from it are asynchronous DMA, the caller owns the hand-over, see
+// include/sl3d.h), 2 = device memory (*device = its ordinal)
+static int memory_kind(const void *p, int *device = nullptr)
 {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
         (void)hipGetLastError();  // pageable memory is not known to the runtime: not an error of ours
-        return false;
+        return 0;
     }
-    return a.type == hipMemoryTypeHost;
+    if (a.type == hipMemoryTypeHost) return 1;
+    if (a.type == hipMemoryTypeDevice) {
+        if (device) *device = a.device;
+        return 2;
+    }
+    return 0;
 }
+static bool is_pinned_host(const void *p) { return memory_kind(p) == 1; }
 
-// selected_region -> the context's mask plane, on the device: the caller's rows (window + 2-pixel halo, clipped to the
-// frame) go up as ONE 2-D copy into a staging plane, k_mask_prepare normalises them to 0/1 and evaluates the border band
-// (3/wrapped_phase.cpp:253-279 in closed form, MaskView::valid).  No host-side pass over the mask, no allocation, and no
-// stream synchronisation when the source is pinned memory.
-extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t stride)
+// the staging plane(s) of sl3d_set_mask(s): `slots` planes, zero outside the region the copies fill
+static int ensure_mask_staging(sl3d_ctx *x, int slots)
 {
-    int rc = check_view(x, view);
+    if (slots <= x->mask_raw_slots) return SL3D_OK;
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    (void)hipFree(x->d_mask_raw);
+    x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_mask_raw), x->allocs.end());
+    x->d_mask_raw = nullptr;
+    x->mask_raw_slots = 0;
+    const int rc = dev_alloc(x, &x->d_mask_raw, (size_t)slots * x->P.mask_view_stride);
     if (rc) return rc;
-    if (!m || stride < (size_t)x->cfg.full_width) return fail(x, SL3D_E_INVALID_ARG, "mask: null or stride < full_width");
-    const KParams &P = x->P;
-    ON_DEVICE(x);
-    const int gy0 = std::max(P.row0 - SL3D_MASK_HALO, 0), gy1 = std::min(P.row0 + P.H + SL3D_MASK_HALO, P.fullH);
-    const int gx0 = std::max(P.col0 - SL3D_MASK_HALO, 0), gx1 = std::min(P.col0 + P.W + SL3D_MASK_HALO, P.fullW);
-    uint8_t *dst = x->d_mask_raw + (size_t)(gy0 - P.row0 + SL3D_MASK_HALO) * P.mpitch + SL3D_MASK_LPAD + (gx0 - P.col0);
-    HIPCHK(x, hipMemcpy2DAsync(dst, P.mpitch, m + (size_t)gy0 * stride + gx0, stride, (size_t)(gx1 - gx0), (size_t)(gy1 - gy0),
-                               hipMemcpyHostToDevice, x->stream));
-    rc = launched(x, launch_mask_prepare(P, view, x->d_mask_raw, x->stream));
-    if (rc) return rc;
-    rc = mask_count_to_host(x, view);
-    if (rc) return rc;
-    if (!is_pinned_host(m)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
+    HIPCHK(x, hipMemsetAsync(x->d_mask_raw, 0, (size_t)slots * x->P.mask_view_stride, x->stream));
+    x->mask_raw_slots = slots;
     return SL3D_OK;
 }
+
+// the part of the mask plane that holds source pixels: the window + 2-pixel halo, clipped to the frame
+struct MaskRegion {
+    int gx0, gx1, gy0, gy1;
+};
+static MaskRegion mask_region(const KParams &P, MaskSrc &S)
+{
+    MaskRegion g;
+    g.gy0 = std::max(P.row0 - SL3D_MASK_HALO, 0), g.gy1 = std::min(P.row0 + P.H + SL3D_MASK_HALO, P.fullH);
+    g.gx0 = std::max(P.col0 - SL3D_MASK_HALO, 0), g.gx1 = std::min(P.col0 + P.W + SL3D_MASK_HALO, P.fullW);
+    S.bx0 = SL3D_MASK_LPAD + g.gx0 - P.col0, S.bx1 = SL3D_MASK_LPAD + g.gx1 - P.col0;
+    S.r0 = g.gy0 - P.row0 + SL3D_MASK_HALO, S.r1 = g.gy1 - P.row0 + SL3D_MASK_HALO;
+    return g;
+}
+
+// k_mask_prepare over the views of one call; the views' counts become known under a new sequence number
+static int prepare_masks(sl3d_ctx *x, int first_view, int n_views, const MaskSrc &S)
+{
+    const unsigned seq = ++x->mask_seq;
+    for (int v = first_view; v < first_view + n_views; v++) {
+        x->quad_seq[v] = seq;
+        x->quad_src[v] = v;
+    }
+    return launched(x, launch_mask_prepare(x->P, first_view, n_views, S, x->d_quad_part, seq, x->stream));
+}
+
+// selected_region -> the context's mask planes, on the device (H0, S3b, S3d: m_tech_project_console.cpp:366, 3/wrapped_phase.cpp:
+// 106-115, :253-279).  Host memory: the rows of the window + 2-pixel halo (clipped to the frame) go up as ONE 2-D copy per distinct
+// mask into a staging plane.  Device memory of this context's GPU (4-byte aligned rows): no copy at all -- the kernel reads the
+// caller's buffer.  ONE launch of k_mask_prepare then serves every view of the call.  No host pass over a mask, no allocation
+// after the first call of a given shape, no stream synchronisation unless the source is pageable host memory.
+extern "C" int sl3d_set_masks(sl3d_ctx *x, int first_view, int n_views, const uint8_t *m, size_t stride, size_t view_stride)
+{
+    int rc = check_view(x, first_view, n_views);
+    if (rc) return rc;
+    if (!m || stride < (size_t)x->cfg.full_width) return fail(x, SL3D_E_INVALID_ARG, "mask: null or stride < full_width");
+    if (view_stride != 0 && view_stride < stride * (size_t)(x->cfg.full_height - 1) + (size_t)x->cfg.full_width)
+        return fail(x, SL3D_E_INVALID_ARG, "masks: view_stride is smaller than one mask (0 = the same mask for every view)");
+    const KParams &P = x->P;
+    ON_DEVICE(x);
+    MaskSrc S;
+    const MaskRegion g = mask_region(P, S);
+    int dev = -1;
+    const int kind = memory_kind(m, &dev);
+    const int distinct = view_stride ? n_views : 1;
+    // dwords of a row must neither straddle the row's end nor start off a 4-byte boundary
+    const bool direct = kind == 2 && dev == x->cfg.device && ((uintptr_t)m & 3u) == 0 && (stride & 3u) == 0 && (view_stride & 3u) == 0 && (P.col0 & 3) == 0 &&
+                        (P.fullW & 3) == 0;
+    if (direct) {
+        S.origin = (uintptr_t)((intptr_t)m + ((intptr_t)P.row0 - SL3D_MASK_HALO) * (intptr_t)stride + P.col0 - SL3D_MASK_LPAD);
+        S.stride = stride;
+        S.view_stride = view_stride;
+    } else {
+        rc = ensure_mask_staging(x, distinct);
+        if (rc) return rc;
+        for (int k = 0; k < distinct; k++) {
+            uint8_t *dst = x->d_mask_raw + (size_t)k * P.mask_view_stride + (size_t)S.r0 * P.mpitch + S.bx0;
+            HIPCHK_DRAIN(x, hipMemcpy2DAsync(dst, P.mpitch, m + (size_t)k * view_stride + (size_t)g.gy0 * stride + g.gx0, stride, (size_t)(g.gx1 - g.gx0),
+                                             (size_t)(g.gy1 - g.gy0), hipMemcpyDefault, x->stream));
+        }
+        S.origin = (uintptr_t)x->d_mask_raw;
+        S.stride = (size_t)P.mpitch;
+        S.view_stride = distinct > 1 ? P.mask_view_stride : 0;
+    }
+    rc = prepare_masks(x, first_view, n_views, S);
+    if (rc) return rc;
+    if (kind == 0) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
+    return SL3D_OK;
+}
+
+extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t stride) { return sl3d_set_masks(x, view, 1, m, stride, 0); }
 
 static int ensure_colrow(sl3d_ctx *x, size_t bytes)
 {
@@ -517,18 +608,19 @@ extern "C" int sl3d_set_mask_colrow(sl3d_ctx *x, int view, const int32_t *sel)
     if (!sel) return fail(x, SL3D_E_INVALID_ARG, "mask: null");
     const KParams &P = x->P;
     ON_DEVICE(x);
-    const int gy0 = std::max(P.row0 - SL3D_MASK_HALO, 0), gy1 = std::min(P.row0 + P.H + SL3D_MASK_HALO, P.fullH);
-    const int gx0 = std::max(P.col0 - SL3D_MASK_HALO, 0), gx1 = std::min(P.col0 + P.W + SL3D_MASK_HALO, P.fullW);
-    const int ncols = gx1 - gx0, nrows = gy1 - gy0;
+    MaskSrc S;
+    const MaskRegion g = mask_region(P, S);
+    const int gx0 = g.gx0, gy0 = g.gy0, ncols = g.gx1 - g.gx0, nrows = g.gy1 - g.gy0;
+    S.origin = (uintptr_t)x->d_mask_raw;
+    S.stride = (size_t)P.mpitch;
+    S.view_stride = 0;
     rc = ensure_colrow(x, std::max((size_t)ncols * nrows * sizeof(int), (size_t)P.W * P.H * 24));
     if (rc) return rc;
     HIPCHK(x, hipMemcpy2DAsync(x->d_colrow, (size_t)nrows * sizeof(int), sel + (size_t)gx0 * P.fullH + gy0, (size_t)P.fullH * sizeof(int),
                                (size_t)nrows * sizeof(int), (size_t)ncols, hipMemcpyHostToDevice, x->stream));
     rc = launched(x, launch_mask_from_colrow(P, (const int *)x->d_colrow, gx0, gy0, ncols, nrows, x->d_mask_raw, x->stream));
     if (rc) return rc;
-    rc = launched(x, launch_mask_prepare(P, view, x->d_mask_raw, x->stream));
-    if (rc) return rc;
-    rc = mask_count_to_host(x, view);
+    rc = prepare_masks(x, view, 1, S);
     if (rc) return rc;
     if (!is_pinned_host(sel)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
@@ -652,6 +744,8 @@ extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
                              P.mask_view_stride, hipMemcpyDeviceToDevice, x->stream));
     HIPCHK(x, hipMemcpyAsync(x->d_band + (size_t)dst * P.px_view_stride, x->d_band + (size_t)src * P.px_view_stride, P.px_view_stride,
                              hipMemcpyDeviceToDevice, x->stream));
+    x->quad_seq[dst] = x->quad_seq[src];  // the duplicate's count of selected quads is the source's (until either mask is set again)
+    x->quad_src[dst] = x->quad_src[src];
     return SL3D_OK;
 }
 
@@ -740,13 +834,33 @@ extern "C" int sl3d_triangulate(sl3d_ctx *x, int view)
     return launched(x, launch_tri(x->P, x->C, view, x->stream));
 }
 
+// every fused launch of the library goes through here: the kernel is chosen by what is known about the views' masks NOW, and the
+// choice is recorded (sl3d_last_fused_kernel_name reports the instantiation that ran, not a later prediction)
+static int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode)
+{
+    const bool prefer_gated = sparse_views(x, first_view, n_views);
+    x->last_fused.n_views = n_views;
+    x->last_fused.cmode = cmode;
+    x->last_fused.keep = keep;
+    x->last_fused.prefer_gated = prefer_gated;
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, prefer_gated));
+}
+
+extern "C" int sl3d_last_fused_kernel_name(sl3d_ctx *x, char *buf, size_t capacity)
+{
+    if (!x || !buf || capacity == 0) return fail(x, SL3D_E_INVALID_ARG, "last_fused_kernel_name: null argument");
+    if (x->last_fused.n_views < 1) return fail(x, SL3D_E_STATE, "no fused launch has been made on this context");
+    const int n = fused_kernel_name(x->P, x->rig, x->last_fused.n_views, x->last_fused.keep, x->last_fused.cmode, buf, capacity, x->last_fused.prefer_gated);
+    return n > 0 && (size_t)n < capacity ? SL3D_OK : fail(x, SL3D_E_INVALID_ARG, "last_fused_kernel_name: buffer too small");
+}
+
 extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
 {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE(x);
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream, sparse_views(x, first_view, n_views)));
+    return run_fused(x, first_view, n_views, x->keep, 0);
 }
 
 // the k_fused instantiation sl3d_run / sl3d_run_clouds launches for a batch of n_views views of this context, as rocprofv3 spells it
@@ -765,7 +879,7 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE(x);
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
-    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, x->keep, false, x->stream, sparse_views(x, first_view, n_views)));
+    rc = run_fused(x, first_view, n_views, x->keep, 0);
     if (rc) return rc;
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
     HIPCHK(x, hipEventSynchronize(x->ev1));
@@ -943,7 +1057,7 @@ int sl3d_process_views_enqueue(sl3d_ctx *x, int n_views, const uint8_t *const *p
         }
         HIPCHK(x, hipEventRecord(x->ev_up[(size_t)slot], x->s_h2d));
         HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_up[(size_t)slot], 0));
-        const int rc = launched(x, launch_fused(P, x->d_cal, x->rig, slot, 1, x->keep, 0, x->stream, sparse_views(x, slot, 1)));
+        const int rc = run_fused(x, slot, 1, x->keep, 0);
         if (rc) return rc;
         HIPCHK(x, hipEventRecord(x->ev_done[(size_t)slot], x->stream));
         HIPCHK(x, hipStreamWaitEvent(x->s_d2h, x->ev_done[(size_t)slot], 0));
@@ -1038,7 +1152,7 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
     ON_DEVICE(x);
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
-    rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, false, 2, x->stream, sparse_views(x, first_view, n_views)));
+    rc = run_fused(x, first_view, n_views, false, 2);
     if (rc) return rc;
     return launched(x, launch_seg_scan(x->P, first_view, n_views, x->stream));
 }

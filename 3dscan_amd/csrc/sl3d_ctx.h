@@ -25,9 +25,20 @@ struct sl3d_ctx {
     std::vector<void *> allocs;
     std::string err;
     uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
-    uint8_t *d_mask_raw = nullptr;            // sl3d_set_mask: the caller's bytes of one view (window + halo), staged for k_mask_prepare
-    unsigned *d_valid_quads = nullptr;        // [max_views] quads with a valid pixel, counted by k_mask_prepare ...
-    volatile unsigned *h_valid_quads = nullptr;  // ... and copied here (pinned) behind it; 0xffffffff = not (yet) known
+    uint8_t *d_mask_raw = nullptr;            // sl3d_set_mask(s): the caller's bytes (window + halo) of mask_raw_slots views, staged for
+    int mask_raw_slots = 0;                   // k_mask_prepare; zero outside the copied region (the kernel relies on that)
+    // quads with a valid pixel, per view: every block of k_mask_prepare stores {seq, count} into this host array (mapped into the
+    // device: d_quad_part is the same memory as the kernels address it); the host adds a view's blocks up on demand and treats the
+    // view as unknown until every block carries the sequence number of the view's last preparation (quads_known, sl3d_capi.cpp)
+    volatile unsigned long long *h_quad_part = nullptr;
+    unsigned long long *d_quad_part = nullptr;
+    int quad_blocks = 0;                      // blocks per view
+    std::vector<unsigned> quad_seq;           // [max_views] sequence number of the view's last preparation (0 = never set)
+    std::vector<int> quad_src;                // [max_views] the view whose blocks hold this view's count (sl3d_copy_view duplicates masks)
+    mutable std::vector<unsigned> quad_sum_seq, quad_sum;  // [max_views] the sum once it was complete, and the preparation it belongs to
+    unsigned mask_seq = 0;
+    // the fused launch made last on this context (sl3d_last_fused_kernel_name: the instantiation that RAN, not a prediction)
+    struct { int n_views = 0, cmode = 0; bool keep = false, prefer_gated = false; } last_fused;
     float *d_points = nullptr;
     unsigned *d_blk_cnt = nullptr;            // compaction scratch: per-1024-pixel block counts,
     unsigned long long *d_blk_off = nullptr;  // their exclusive scan, and the total

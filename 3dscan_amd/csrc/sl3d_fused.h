@@ -364,7 +364,10 @@ __device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned 
 #pragma unroll
     for (int a = 0; a < 2; a++) {
         const int N = a == 0 ? Nv : Nh;
-        const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
+        // (an axis WITHOUT Gray planes -- sl3d_config allows 0 -- has no plane of its own to pad with: its padded loads, all of them
+        // masked out by the decode, read plane 0 of the view instead of whatever follows the axis, which for the last axis of the last
+        // resident view would be the first bytes past the frame stack)
+        const unsigned pg = (PLANES == 2 && N == 0) ? 0u : (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
         // (behind an empty asm: everything derived from it is loop-invariant, and 40 hoisted plane offsets + 20 masks are more
         // SGPRs than there are)
         int pad = NMAX - N;

@@ -65,6 +65,14 @@ struct SynthParams {
     int view_id;                        // enters the noise hash
 };
 
+// Where k_mask_prepare reads a selection mask from: the staging plane behind sl3d_set_mask's copy, or the caller's device memory.
+struct MaskSrc {
+    uintptr_t origin;      // address of plane row 0, byte 0 (= window row -2, window column -16); only bytes inside the region below are read
+    size_t stride;         // bytes between rows
+    size_t view_stride;    // bytes between the masks of consecutive views of one call (0: every view gets the same mask)
+    int bx0, bx1, r0, r1;  // plane bytes [bx0, bx1) x plane rows [r0, r1) hold source pixels: window + 2-pixel halo, clipped to the frame
+};
+
 // Everything a kernel needs to address one context's buffers.
 struct KParams {
     int W, H;                  // window
@@ -100,8 +108,6 @@ struct KParams {
     unsigned long long *cloud_totals;  // [view] number of valid points -- HOST memory mapped into the device: k_seg_scan stores the
                                        // count where sl3d_get_cloud_counts reads it after the stream has drained (no copy)
     int n_tiles;               // 1024-pixel tiles per view = blocks of the fused kernel along x that own pixels
-    unsigned *valid_quads;     // [view]: quads of the view with at least one valid pixel, counted by k_mask_prepare (how sparse a mask is
-                               // decides which instantiation a SMALL launch takes: launch_fused)
     int prefer_gated;          // set per launch (host only): small launch over sparsely selected views -> the large-launch kernel
     // a segment's first seg_counts[view][seg] slots are its valid points in scan order
     unsigned *seg_counts;              // [view][n_segs]
@@ -133,7 +139,10 @@ int launch_seg_close(const KParams &P, int first_view, int n_views, float *dst, 
 // register_point_clouds on segmented input: view first_view+k rotated by R4[4*k..], written at out + 3*(out_base[k] + offset)
 int launch_seg_register(const KParams &P, int view, float *out, const float R4[4], float tx, float ty, float tz, void *stream);
 int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)
-int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream);  // raw: staged bytes in the layout of one mask plane
+// k_mask_prepare over views [first_view, first_view + n_views): view k reads S.origin + k * S.view_stride; block b of view v stores
+// {seq, quads with a valid pixel} at partials[v * mask_prepare_blocks(P) + b] (host memory mapped into the device)
+int launch_mask_prepare(const KParams &P, int first_view, int n_views, const MaskSrc &S, unsigned long long *partials, unsigned seq, void *stream);
+int mask_prepare_blocks(const KParams &P);
 int launch_to_colrow(const KParams &P, int view, int which, void *dst, void *stream);  // a global in the reference's [col][row] layout
 int launch_mask_from_colrow(const KParams &P, const int *sel, int gx0, int gy0, int ncols, int nrows, uint8_t *raw, void *stream);
 int launch_proj_table(const DevCal *d_cal, int PW, int PH, float2 *out, void *stream);

@@ -13,55 +13,95 @@
 #include <stdlib.h>
 
 #include "sl3d_device.h"
+#include "sl3d_maskbits.h"
 
 namespace sl3d {
 
-// sl3d_set_mask on the device: `raw` holds the caller's bytes of the window + 2-pixel halo (clipped to the frame) in the
-// layout of the mask plane itself (row r of the plane = window row r - 2, byte SL3D_MASK_LPAD + c = window column c).
-// One lane per dword of the plane: normalises the bytes to 0/1 (selected iff byte == 1; outside the frame or the halo: 0; the
-// per-stage kernel k_wrap evaluates the boundary removal on this plane) and evaluates the generic closed form of the
-// boundary removal (MaskView::valid on the raw bytes) for EVERY pixel of the window into the band plane the fused kernel reads.
-__global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int view, const uint8_t *__restrict__ raw)
+// sl3d_set_mask(s) on the device (H0 / S3b / S3d).  The source is either the staging plane the host copy filled or the caller's
+// own device-resident mask (MaskSrc: address of plane row 0 / byte 0, row stride, and the part of the plane that holds source
+// bytes -- window + 2-pixel halo clipped to the frame; everything else counts as unselected and is never loaded).
+// One lane = one dword column of the plane x R rows: per row it loads its dword and both neighbours, turns `byte == 1` into 12 bits
+// and evaluates the closed form of the boundary removal (3/wrapped_phase.cpp:253-279) on those bits (sl3d_maskbits.h) -- no
+// per-pixel loads, no per-pixel branches.  It writes the 0/1 plane (what the per-stage kernel k_wrap reads) and the `band` plane
+// (final valid bytes of every window pixel: what the fused kernel reads), and counts the quads that hold a valid pixel: one LDS
+// add per wave, ONE 8-byte store per block {seq, count} into host memory mapped into the device -- no device atomics, no memset,
+// no copy behind the kernel; the host adds the blocks up when it needs the number (sparse_views, sl3d_capi.cpp) and knows by the
+// sequence number whether every block of THIS preparation has landed.
+template <int R>
+__global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int first_view, const MaskSrc S, unsigned long long *__restrict__ partials,
+                                                      unsigned seq)
 {
-    const int dwords_per_row = P.mpitch >> 2;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    const int r = (int)(t / dwords_per_row), x = (int)(t - (long)r * dwords_per_row);
-    if (r >= P.H + 2 * SL3D_MASK_HALO) return;
-    MaskView m;
-    m.base = raw + (size_t)SL3D_MASK_HALO * P.mpitch + SL3D_MASK_LPAD;
-    m.mpitch = P.mpitch;
-    m.col0 = P.col0; m.row0 = P.row0; m.fullW = P.fullW; m.fullH = P.fullH;
-    const int c0 = x * 4 - SL3D_MASK_LPAD, wr = r - SL3D_MASK_HALO;  // window column of byte 0, window row
-    unsigned has = 0u;
-    const int gy = P.row0 + wr;
-    unsigned norm = 0;
+    __shared__ unsigned s_quads;
+    if (threadIdx.x == 0) s_quads = 0u;
+    __syncthreads();
+    const int view = first_view + (int)blockIdx.y;
+    const int dwpr = P.mpitch >> 2, rows = P.H + 2 * SL3D_MASK_HALO;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const int strip = (int)(t / (unsigned)dwpr), x = (int)(t - (unsigned)strip * (unsigned)dwpr);
+    const int pr0 = strip * R;  // first plane row of the lane
+    unsigned wave_quads = 0u;
+    if (pr0 < rows) {
+        const MbCols c = mb_cols(x, P.col0, SL3D_MASK_LPAD, P.fullW, S.bx0, S.bx1);
+        const unsigned own_bytes = mb_expand_nibble(c.REG >> 4) * 0xffu;
+        const unsigned outw = (mb_range_bits(SL3D_MASK_LPAD, SL3D_MASK_LPAD + P.W, 4 * x - 4) >> 4) & 0xfu;  // the lane's pixels inside the window
+        const uintptr_t src = S.origin + (uintptr_t)blockIdx.y * S.view_stride;
+        MbRow row[R + 3];
+        unsigned own[R + 3];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int c = c0 + k;
-        if (c >= -SL3D_MASK_HALO && c < P.W + SL3D_MASK_HALO && m.V(P.col0 + c, gy)) norm |= 1u << (8 * k);
-    }
-    uint8_t *dst = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
-    *(unsigned *)(dst + (size_t)r * P.mpitch + (size_t)x * 4) = norm;
-    if (wr >= 0 && wr < P.H && c0 >= 0 && c0 < P.pitch) {
-        unsigned band = 0;
+        for (int a = 0; a < R + 3; a++) {
+            const int pr = pr0 + a - 2;
+            unsigned dl = 0u, dc = 0u, dr = 0u;
+            if (pr >= S.r0 && pr < S.r1) {
+                const uintptr_t p = src + (uintptr_t)pr * S.stride + (uintptr_t)(4 * x);
+                if (c.REG & 0x00fu) dl = *(const unsigned *)(p - 4);
+                if (c.REG & 0x0f0u) dc = *(const unsigned *)p;
+                if (c.REG & 0xf00u) dr = *(const unsigned *)(p + 4);
+            }
+            const unsigned bc = mb_eq1_bytes(dc);
+            const unsigned V = (mb_pack_nibble(mb_eq1_bytes(dl)) | (mb_pack_nibble(bc) << 4) | (mb_pack_nibble(mb_eq1_bytes(dr)) << 8)) & c.REG;
+            row[a] = mb_row(V, c, P.row0 + pr - SL3D_MASK_HALO, P.fullH);
+            own[a] = bc & own_bytes;
+        }
+        unsigned L[R + 3], OK[R + 3];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (c0 + k < P.W && m.valid(P.col0 + c0 + k, gy)) band |= 1u << (8 * k);
-        *(unsigned *)((uint8_t *)P.band + (size_t)view * P.px_view_stride + (size_t)wr * P.pitch + (size_t)c0) = band;
-        has = band != 0u ? 1u : 0u;
+        for (int a = 1; a < R + 2; a++) {
+            L[a] = mb_L(row[a], row[a + 1]);
+            OK[a] = mb_OK(row[a], L[a], row[a - 1]);
+        }
+        uint8_t *mask = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
+        uint8_t *band = (uint8_t *)P.band + (size_t)view * P.px_view_stride;
+        const int xb = x - (SL3D_MASK_LPAD >> 2);  // dword of the band row
+        const bool in_band = xb >= 0 && xb < (P.pitch >> 2);
+#pragma unroll
+        for (int a = 2; a < R + 2; a++) {
+            const int pr = pr0 + a - 2, wr = pr - SL3D_MASK_HALO;
+            if (pr < rows) *(unsigned *)(mask + (size_t)pr * P.mpitch + (size_t)x * 4) = own[a];
+            bool has = false;
+            if (in_band && wr >= 0 && wr < P.H) {
+                const unsigned v = (mb_valid(row[a], L[a], OK[a - 1], OK[a]) >> 4) & outw;
+                *(unsigned *)(band + (size_t)wr * P.pitch + (size_t)xb * 4) = mb_expand_nibble(v);
+                has = v != 0u;
+            }
+            wave_quads += (unsigned)__popcll(__ballot(has));
+        }
     }
-    // how many quads of the view hold a valid pixel: one atomic per wave (the host reads the sum when it picks the instantiation
-    // of a small launch -- a launch that asks for its planes before it knows the mask is the wrong one for a sparse selection)
-    const unsigned long long b = __ballot(has != 0u);
-    if (b != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(true))) atomicAdd(P.valid_quads + view, (unsigned)__popcll(b));
+    if ((threadIdx.x & 63u) == 0u && wave_quads) atomicAdd(&s_quads, wave_quads);  // LDS
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)view * gridDim.x + blockIdx.x] = ((unsigned long long)seq << 32) | s_quads;
 }
 
-int launch_mask_prepare(const KParams &P, int view, const uint8_t *raw, void *stream)
+#define SL3D_MASK_ROWS_PER_LANE 4
+int mask_prepare_blocks(const KParams &P)
 {
-    const long n = (long)(P.mpitch >> 2) * (P.H + 2 * SL3D_MASK_HALO);
+    const long strips = (P.H + 2 * SL3D_MASK_HALO + SL3D_MASK_ROWS_PER_LANE - 1) / SL3D_MASK_ROWS_PER_LANE;
+    return (int)(((long)(P.mpitch >> 2) * strips + 255) / 256);
+}
+
+int launch_mask_prepare(const KParams &P, int first_view, int n_views, const MaskSrc &S, unsigned long long *partials, unsigned seq, void *stream)
+{
     (void)hipGetLastError();
-    (void)hipMemsetAsync(P.valid_quads + view, 0, sizeof(unsigned), (hipStream_t)stream);
-    hipLaunchKernelGGL(k_mask_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, view, raw);
+    hipLaunchKernelGGL(k_mask_prepare<SL3D_MASK_ROWS_PER_LANE>, dim3((unsigned)mask_prepare_blocks(P), (unsigned)n_views), dim3(256), 0, (hipStream_t)stream, P,
+                       first_view, S, partials, seq);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,93 @@
+// sl3d_maskbits.h -- H0 / S3b / S3d as bit-plane arithmetic: the selection mask -> the valid map after stage 3's boundary
+// removal (3/wrapped_phase.cpp:106-115, then :253-279 / :306-318), 4 pixels per lane, R rows per lane, no per-pixel loads.
+//
+// Shared by k_mask_prepare (sl3d_kernels.hip) and by the CPU emulation the test suite compares with the literal scan of the reference's loop
+// (tests/native/mask_bits_emul.c): plain C, no HIP types.
+//
+// The closed form (sl3d_device.h, MaskView) written per ROW of 12 neighbouring pixels held as 12 bits of one register -- bit i of
+// a row word is the pixel at plane byte 4*x - 4 + i, i.e. the lane's own dword is bits 4..7 and its left / right neighbour
+// dwords are bits 0..3 / 8..11 (everything the 4 results depend on lies within 2 columns):
+//   V      selected (byte == 1), 0 outside the staged region (which never leaves the frame)
+//   nV3    = nV | nV<<1 | nV>>1          some pixel of the 3 columns around is unselected            (nV = ~V)
+//   L(r)   = nV(r)>>1 | nV3(r+1)         E, SW, S or SE neighbour unselected: those are scanned LATER than the pixel
+//   bu(r)  = ROWM(r) & nV(r)             frame-border pixel, unselected (never scanned, hence never `visited`)
+//   B(r)   = bu3(r-1) | bu(r)<<1         NW, N, NE or W neighbour is such a pixel
+//   OK(r)  = V | INT(r) & (L | B)        a neighbour that does not clear the pixels scanned after it
+//   valid(y) = V & ( ~INT(y) | ~L(y) & OK3(y-1) & OK(y)<<1 )
+// with INT(r) = the interior columns if row r is an interior row (else 0) and ROWM(r) = the frame's border columns on an interior
+// row, every in-frame column on the frame's first / last row, 0 outside the frame.
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define SL3D_MB_FN __host__ __device__ __forceinline__
+#else
+#define SL3D_MB_FN static inline
+#endif
+
+// bits i of a 12-bit row word whose coordinate base + i lies in [lo, hi)
+SL3D_MB_FN unsigned mb_range_bits(int lo, int hi, int base)
+{
+    int a = lo - base, b = hi - base;
+    a = a < 0 ? 0 : (a > 12 ? 12 : a);
+    b = b < 0 ? 0 : (b > 12 ? 12 : b);
+    return b > a ? ((1u << b) - (1u << a)) : 0u;
+}
+
+// 0x01 in every byte of d that equals 1 (exact: no borrow runs between the bytes)
+SL3D_MB_FN unsigned mb_eq1_bytes(unsigned d)
+{
+    const unsigned t = d ^ 0x01010101u;
+    return (~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u) >> 7;
+}
+// 0/1 bytes -> 4 bits (byte k -> bit k): the four partial products land on distinct bits, so nothing carries
+SL3D_MB_FN unsigned mb_pack_nibble(unsigned bytes01) { return (bytes01 * 0x01020408u) >> 24; }
+// 4 bits -> 0/1 bytes
+SL3D_MB_FN unsigned mb_expand_nibble(unsigned n) { return ((n & 0xfu) * 0x00204081u) & 0x01010101u; }
+
+// per-lane column constants
+typedef struct MbCols {
+    unsigned REG;   // bits inside the staged region's byte columns [bx0, bx1)
+    unsigned INF;   // in-frame columns
+    unsigned INTC;  // interior columns: 1 <= gx <= fullW - 2
+} MbCols;
+
+SL3D_MB_FN MbCols mb_cols(int x /* dword of the plane row */, int col0, int lpad, int fullW, int bx0, int bx1)
+{
+    MbCols c;
+    const int b0 = 4 * x - 4;            // plane byte of bit 0
+    const int gx0 = col0 - lpad + b0;    // its frame column
+    c.REG = mb_range_bits(bx0, bx1, b0);
+    c.INF = mb_range_bits(0, fullW, gx0);
+    c.INTC = mb_range_bits(1, fullW - 1, gx0);
+    return c;
+}
+
+// per-row derived words
+typedef struct MbRow {
+    unsigned V, nV, nV3, bu, bu3, INT;
+} MbRow;
+
+// V: the 12 selected bits of frame row gy (already limited to the staged region)
+SL3D_MB_FN MbRow mb_row(unsigned V, const MbCols c, int gy, int fullH)
+{
+    MbRow r;
+    const int inframe = gy >= 0 && gy < fullH, interior = gy >= 1 && gy <= fullH - 2;
+    const unsigned rowm = !inframe ? 0u : (interior ? (c.INF & ~c.INTC) : c.INF);
+    r.V = V;
+    r.nV = ~V;
+    r.nV3 = r.nV | (r.nV << 1) | (r.nV >> 1);
+    r.bu = rowm & r.nV;
+    r.bu3 = r.bu | (r.bu << 1) | (r.bu >> 1);
+    r.INT = interior ? c.INTC : 0u;
+    return r;
+}
+
+SL3D_MB_FN unsigned mb_L(const MbRow r, const MbRow below) { return (r.nV >> 1) | below.nV3; }
+SL3D_MB_FN unsigned mb_OK(const MbRow r, unsigned L, const MbRow above) { return r.V | (r.INT & (L | above.bu3 | (r.bu << 1))); }
+// valid bits of row y (bits 4..7 are the lane's own pixels) from OK of the row above and of the row itself
+SL3D_MB_FN unsigned mb_valid(const MbRow r, unsigned L, unsigned OK_above, unsigned OK_row)
+{
+    const unsigned ok3 = OK_above & (OK_above << 1) & (OK_above >> 1);
+    return r.V & (~r.INT | (~L & ok3 & (OK_row << 1)));
+}

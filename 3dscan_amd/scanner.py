@@ -20,9 +20,9 @@ VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
 # every symbol include/sl3d.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
-    "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_mask_colrow", "sl3d_set_frames_range", "sl3d_get_global_colrow", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
+    "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_masks", "sl3d_set_mask_colrow", "sl3d_set_frames_range", "sl3d_get_global_colrow", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
-    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
+    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_last_fused_kernel_name", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
     "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
@@ -86,6 +86,12 @@ def load_library(path=None):
     L.sl3d_get_projection_matrices.argtypes = [vp, vp, vp]
     L.sl3d_set_mask.argtypes = [vp, i, vp, C.c_size_t]
     L.sl3d_set_frames.argtypes = [vp, i, i, vp, i, C.c_size_t]
+    try:
+        L.sl3d_set_masks.argtypes = [vp, i, i, vp, C.c_size_t, C.c_size_t]
+        L.sl3d_last_fused_kernel_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    except AttributeError:   # an older build of the library under SL3D_LIB (A/B runs against a previous round)
+        if not os.environ.get("SL3D_LIB"):
+            raise
     L.sl3d_set_mask_colrow.argtypes = [vp, i, vp]
     L.sl3d_set_frames_range.argtypes = [vp, i, i, i, vp, i, C.c_size_t]
     L.sl3d_get_global_colrow.argtypes = [vp, i, i, vp, i, i]
@@ -230,6 +236,22 @@ class Scanner:
         m = np.ascontiguousarray(full_frame_mask, dtype=np.uint8)
         assert m.shape == (self.cfg.full_height, self.cfg.full_width), m.shape
         self._chk(self.L.sl3d_set_mask(self._h, view, m.ctypes.data, m.strides[0]), "sl3d_set_mask")
+
+    def set_masks(self, masks, first_view=0, n_views=None):
+        """One launch for several views.  masks: one full-frame mask (every view gets it) or an array [n][full_height][full_width]."""
+        m = np.ascontiguousarray(masks, dtype=np.uint8)
+        if m.ndim == 2:
+            assert m.shape == (self.cfg.full_height, self.cfg.full_width), m.shape
+            n, vs = (self.cfg.max_views - first_view if n_views is None else n_views), 0
+        else:
+            assert m.shape[1:] == (self.cfg.full_height, self.cfg.full_width), m.shape
+            n, vs = m.shape[0], m.strides[0]
+            assert n_views is None or n_views == n
+        self._chk(self.L.sl3d_set_masks(self._h, first_view, n, m.ctypes.data, m.strides[-2], vs), "sl3d_set_masks")
+
+    def set_masks_device(self, dev_ptr, stride, view_stride, first_view=0, n_views=1):
+        """Masks that already live in device memory (a raw address, e.g. torch.Tensor.data_ptr())."""
+        self._chk(self.L.sl3d_set_masks(self._h, first_view, n_views, C.c_void_p(dev_ptr), stride, view_stride), "sl3d_set_masks")
 
     def set_frames(self, axis, planes, view=0):
         arrs = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
@@ -376,6 +398,12 @@ class Scanner:
             return "(a build without sl3d_fused_kernel_name)"
         buf = C.create_string_buffer(256)
         self._chk(self.L.sl3d_fused_kernel_name(self._h, n_views, 1 if clouds else 0, buf, len(buf)), "sl3d_fused_kernel_name")
+        return buf.value.decode()
+
+    def last_fused_kernel_name(self):
+        """The k_fused instantiation the last fused launch of this context ran."""
+        buf = C.create_string_buffer(256)
+        self._chk(self.L.sl3d_last_fused_kernel_name(self._h, buf, len(buf)), "sl3d_last_fused_kernel_name")
         return buf.value.decode()
 
     def run_timed(self, first_view=0, n_views=1):

@@ -257,6 +257,66 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
                         f"> 256 MiB Infinity Cache): the frames come from HBM"}
 
 
+def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=False):
+    """What ONE iteration of the reference's scan loop costs on the device once the frames are resident (m_tech_project_console.cpp:
+    366-395): a NEW selection mask (image_scissor's result, here already in device memory: no PCIe in this figure) prepared by
+    k_mask_prepare (H0 / S3b / S3d: 3/wrapped_phase.cpp:106-115, :253-279) and then ONE one-view launch of the fused kernel, a
+    different resident view and a different mask every scan (frames from HBM, as in one_view_cold).  HIP events on the context's
+    stream around `scans` such pairs; mask_us = the same loop with the mask preparation alone."""
+    W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
+    V = max(2, args.cold_views)
+    rng = np.random.default_rng(5)
+    masks = np.stack([syn.default_mask(W, H) for _ in range(V)])
+    for v in range(V):   # every mask differs a little (a few holes), all of them dense: the small-launch kernel, like one_view_cold
+        ys, xs = rng.integers(8, H - 8, 12), rng.integers(8, W - 8, 12)
+        for y, x in zip(ys, xs):
+            masks[v, y:y + 3, x:x + 5] = 0
+    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index) as sc:
+        sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
+        d_masks = torch.from_numpy(masks).to(torch.device("cuda", dev_index))
+        torch.cuda.synchronize()
+        ptr, vs = d_masks.data_ptr(), W * H
+        sc.set_masks_device(ptr, W, vs, 0, V)
+        for v in range(V):
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=args.noise)
+        sc.synchronize()
+        run = (lambda v: sc.run_clouds(v, 1)) if clouds else (lambda v: sc.run(v, 1))
+
+        def scan(i):
+            v = i % V
+            sc.set_masks_device(ptr + ((i + 3) % V) * vs, W, 0, v, 1)   # view v gets another mask than last time
+            run(v)
+
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < 200.0:
+            for i in range(40):
+                scan(i)
+            sc.synchronize()
+        sc.timer_start()
+        for i in range(scans):
+            scan(i)
+        us = sc.timer_stop() / scans * 1e3
+        kernel = sc.last_fused_kernel_name()
+        sc.timer_start()
+        for i in range(scans):
+            sc.set_masks_device(ptr + ((i + 3) % V) * vs, W, 0, i % V, 1)
+        mask_us = sc.timer_stop() / scans * 1e3
+        sc.timer_start()
+        for i in range(scans // 8):
+            sc.set_masks_device(ptr, W, vs, 0, V)
+        batch_us = sc.timer_stop() / (scans // 8) * 1e3
+        alg = 20 + 4 * N
+        mask_bytes = W * H + (W + 32) * (H + 4) + W * H      # read the mask, write the 0/1 plane with its halo and the valid-byte plane
+        return {"scan_us": round(us, 2), "mask_us": round(mask_us, 2), "masks_of_%d_views_one_launch_us" % V: round(batch_us, 2),
+                "value": round(W * H / us, 1), "unit": "Mpixels/s", "frac": round(alg * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "mask_kernel": {"kernel": "sl3d::k_mask_prepare<4>", "algorithmic_bytes": mask_bytes,
+                                "frac": round(mask_bytes / (mask_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                "kernel": kernel, "resident_views": V, "scans": scans,
+                "note": "per scan: sl3d_set_masks on a device-resident mask (no copy: the kernel reads the caller's buffer) + sl3d_run"
+                        + ("_clouds" if clouds else "") + " of ONE view, a different view and mask each scan; frac = the fused kernel's algorithmic "
+                        "bytes over the time of BOTH kernels"}
+
+
 def side_figures(args, scm, syn, np, dev_index):
     """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
@@ -282,6 +342,9 @@ def side_figures(args, scm, syn, np, dev_index):
                                                       "not an HBM figure (round 3 reported it as one_view_latency); one_view_cold is"}
         out["one_view_cold"] = one_view_cold(args, scm, syn, np, dev_index)
         out["one_view_cold_clouds"] = one_view_cold(args, scm, syn, np, dev_index, launches=1000, clouds=True)
+        import torch
+        out["per_scan_device"] = per_scan_device(args, scm, syn, np, torch, dev_index)
+        out["per_scan_device_clouds"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, clouds=True)
         # (distorted: projector k1,k2,p1,p2 + camera tangential terms; general: a skewed camera matrix as well -- since round 3 both
         # take the pipelined table kernel, RIG 2; the un-pipelined general kernel is left with perspective rows in K)
         for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig2_general_skewed_camera"), ("radial", "rig3_radial_projector")):
@@ -401,8 +464,8 @@ def main():
                      stream=compute_stream.cuda_stream)
     sc.set_calibration(*cal)
     full_mask = syn.default_mask(W, H)
+    sc.set_masks(full_mask, 0, n_views)     # one copy, ONE launch of k_mask_prepare for every view
     for v in range(n_views):
-        sc.set_mask(full_mask, view=v)
         sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=args.noise)
     sc.synchronize()
 
@@ -436,6 +499,7 @@ def main():
     for _ in range(args.steps):
         sc.run(0, n_views)
     ev_ms = sc.timer_stop()                # second event, waited for
+    kernel_name = sc.last_fused_kernel_name()   # the instantiation the timed launches RAN (recorded by the library at the launch)
     barrier()
     dt = time.perf_counter() - t0
     dt = dmod.max_over_ranks(dt, red_dev)
@@ -448,7 +512,6 @@ def main():
     launch_s = ev_ms / 1e3 / args.steps
     achieved = alg_bytes_px * px_per_launch / launch_s / 1e9
 
-    kernel_name = sc.fused_kernel_name(n_views)            # the instantiation this launch ran, from the library's own dispatch rules
     kernel_name_clouds = sc.fused_kernel_name(n_views, clouds=True)
     traffic, traffic_src = measured_traffic(px_per_launch) if alg_bytes_px == 60 else (None, None)
 

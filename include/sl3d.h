@@ -156,6 +156,15 @@ int sl3d_get_projection_matrices(sl3d_ctx *ctx, double A_cam[12], double A_proj[
  * (any getter, sl3d_synchronize) -- the call then costs a copy and a launch (tens of microseconds at 1080p). */
 int sl3d_set_mask(sl3d_ctx *ctx, int view, const uint8_t *full_frame_mask, size_t stride);
 
+/* The same for n_views views [first_view, first_view + n_views) with ONE kernel launch: the mask of view first_view + k starts at
+ * full_frame_masks + k * view_stride; view_stride == 0 hands every view the same mask (one copy, one launch).
+ * The masks may also live in DEVICE memory of the context's GPU (an acquisition stage that segments on the GPU, a benchmark): with
+ * 4-byte aligned rows (pointer, stride, view_stride, col0 and full_width multiples of 4) nothing is copied -- the kernel reads the
+ * caller's buffer, which must stay unchanged until the stream has passed the call; otherwise the rows go through the staging
+ * plane by a device copy.  This is the per-scan device cost of image_scissor()'s result (m_tech_project_console.cpp:366) + stage
+ * 3's boundary removal (3/wrapped_phase.cpp:253-279): bench.py `side.per_scan_device`. */
+int sl3d_set_masks(sl3d_ctx *ctx, int first_view, int n_views, const uint8_t *full_frame_masks, size_t stride, size_t view_stride);
+
 /* The captured frames of one axis of one view, window-sized planes in host memory: what
  * read_image() 3/wrapped_phase.cpp:29-58 (n_fringe planes) and read_captured_images()
  * 4/phase_unwrap.cpp:51-131 (n_gray planes + n_gray inverse planes) load.
@@ -245,6 +254,10 @@ int sl3d_register_clouds(sl3d_ctx *ctx, int first_view, int n_views, float tx, f
  * with this context's configuration and calibration, spelled as rocprofv3 --kernel-trace prints it: benchmarks name the kernel
  * their roofline figure is about without restating the library's dispatch rules. */
 int sl3d_fused_kernel_name(sl3d_ctx *ctx, int n_views, int clouds, char *buf, size_t capacity);
+/* The instantiation the LAST fused launch of this context ran (sl3d_run, sl3d_run_clouds, sl3d_run_timed, sl3d_process_views): the
+ * choice is recorded when the launch is made -- it depends on what was known about the views' masks at that moment (a small
+ * launch over sparsely selected views takes another kernel), so a later prediction could name a different one. */
+int sl3d_last_fused_kernel_name(sl3d_ctx *ctx, char *buf, size_t capacity);
 /* sl3d_run bracketed by HIP events on the context's stream; returns the kernel time of this launch */
 int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);
 int sl3d_synchronize(sl3d_ctx *ctx);

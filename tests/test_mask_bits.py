@@ -1,0 +1,98 @@
+"""k_mask_prepare's arithmetic on the CPU: the bit-plane closed form of stage 3's boundary removal (3dscan_amd/csrc/sl3d_maskbits.h,
+the header the HIP kernel is compiled from) driven by the kernel's own lane / strip indexing (tests/native/mask_bits_emul.c),
+against the oracle's literal scan of 3/wrapped_phase.cpp:253-279 -- full frames, windows touching every border, 1- and 2-pixel
+frames' worth of edge cases, arbitrary mask bytes.  The GPU run of the same comparison is tests/test_gpu_round5.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle.oracle import Oracle
+
+
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("maskbits") / "libmask_bits_emul.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "3dscan_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "mask_bits_emul.c"), "-o", out])
+    L = C.CDLL(out)
+    L.emul_mask_prepare.restype = C.c_long
+    L.emul_mask_prepare.argtypes = [C.c_void_p, C.c_size_t] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
+    return L
+
+
+def run_emul(L, mask, win, R):
+    FH, FW = mask.shape
+    x0, y0, w, h = win
+    pitch = (w + 15) & ~15
+    norm = np.full((h + 4, pitch + 32), 0xEE, np.uint8)
+    band = np.full((h, pitch), 0xEE, np.uint8)
+    q = L.emul_mask_prepare(mask.ctypes.data, mask.strides[0], FW, FH, x0, y0, w, h, R, norm.ctypes.data, band.ctypes.data)
+    return norm, band, q
+
+
+def oracle_valid(mask):
+    FH, FW = mask.shape
+    o = Oracle(FW, FH, 64, 64, 3, 3, 8, 8)
+    o.set_mask(mask)
+    o.compute_wrapped_phase(0, [np.zeros((FH, FW), np.uint8)] * 3)
+    return o.valid_map(0).astype(np.uint8)
+
+
+def random_mask(rng, FW, FH, trial):
+    p = rng.choice([0.02, 0.3, 0.5, 0.8, 0.95, 1.0])
+    S = (rng.random((FH, FW)) < p).astype(np.uint8)
+    if trial % 3 == 0:
+        S[:] = 0
+        for _ in range(4):
+            y, x, h, w = rng.integers(0, FH), rng.integers(0, FW), rng.integers(1, 30), rng.integers(1, 30)
+            S[y:y + h, x:x + w] = 1
+        S ^= (rng.random((FH, FW)) < 0.02).astype(np.uint8)
+    if trial % 4 == 1:
+        S[S == 0] = rng.integers(2, 256, size=int((S == 0).sum()), dtype=np.uint8)  # only the value 1 selects a pixel
+    if trial % 5 == 2:
+        S[:] = 1
+    return S
+
+
+def test_byte_helpers_exhaustive(emul):
+    assert emul.emul_check_byte_helpers() == 0
+
+
+@pytest.mark.parametrize("R", [1, 4, 8])
+def test_bit_plane_boundary_removal_equals_literal_scan(emul, R):
+    rng = np.random.default_rng(100 + R)
+    for trial in range(40):
+        FW, FH = int(rng.integers(3, 90)), int(rng.integers(3, 70))
+        mask = random_mask(rng, FW, FH, trial)
+        ref = oracle_valid(mask)
+        wins = [(0, 0, FW, FH)]
+        for _ in range(5):
+            w, h = int(rng.integers(1, FW + 1)), int(rng.integers(1, FH + 1))
+            wins.append((int(rng.integers(0, FW - w + 1)), int(rng.integers(0, FH - h + 1)), w, h))
+        for win in wins:
+            x0, y0, w, h = win
+            norm, band, q = run_emul(emul, mask, win, R)
+            assert np.array_equal(band[:, :w], ref[y0:y0 + h, x0:x0 + w]), (trial, win)
+            assert not band[:, w:].any(), (trial, win)  # the pitch padding stays 0
+            # the 0/1 plane: selected bytes of window + halo inside the frame, 0 elsewhere
+            expect = np.zeros_like(norm)
+            ys, xs = slice(max(y0 - 2, 0), min(y0 + h + 2, FH)), slice(max(x0 - 2, 0), min(x0 + w + 2, FW))
+            expect[ys.start - y0 + 2:ys.stop - y0 + 2, 16 + xs.start - x0:16 + xs.stop - x0] = mask[ys, xs] == 1
+            assert np.array_equal(norm, expect), (trial, win)
+            quads = band.reshape(h, -1, 4).any(axis=2).sum()
+            assert q == quads, (trial, win)
+
+
+def test_degenerate_frames(emul):
+    """Frames of 1 or 2 rows / columns have no interior at all: valid == selected."""
+    rng = np.random.default_rng(5)
+    for FW, FH in ((1, 1), (1, 9), (9, 1), (2, 2), (2, 17), (17, 2), (3, 3)):
+        for trial in range(6):
+            mask = random_mask(rng, FW, FH, trial)
+            ref = oracle_valid(mask) if FW >= 3 and FH >= 3 else (mask == 1).astype(np.uint8)
+            norm, band, q = run_emul(emul, mask, (0, 0, FW, FH), 4)
+            assert np.array_equal(band[:, :FW], ref), (FW, FH, trial)

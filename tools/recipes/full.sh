@@ -1,7 +1,7 @@
 # on the GPU box: the whole -m gpu suite, smoke, the default bench line; logs under gpurun_out/<tag>/
 set -u
-cd $GRAFT_REPO_ROOT
-TAG=${1:-full}
+
+TAG=full
 mkdir -p gpurun_out/$TAG
 timeout 3000 python -m pytest tests -q -m gpu -x --durations=15 > gpurun_out/$TAG/pytest_gpu.log 2>&1
 echo "pytest rc=$?" > gpurun_out/$TAG/summary.txt
