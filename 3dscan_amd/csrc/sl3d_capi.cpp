@@ -631,10 +631,10 @@ extern "C" int sl3d_get_global_colrow(sl3d_ctx *x, int view, int which, void *ou
     int rc = check_view(x, view);
     if (rc) return rc;
     const KParams &P = x->P;
-    if (!out || which < SL3D_G_VALID_V || which > SL3D_G_INTERSECTION_POINTS || out_row0 < 0 || out_row0 + P.H > out_height)
+    if (!out || which < SL3D_G_VALID_V || which > SL3D_G_POINTS_F64 || out_row0 < 0 || out_row0 + P.H > out_height)
         return fail(x, SL3D_E_INVALID_ARG, "get_global_colrow: null output, unknown global, or the window's rows do not fit out_height");
-    if (which != SL3D_G_VALID && (rc = need_keep(x))) return rc;
-    const size_t elem = which == SL3D_G_INTERSECTION_POINTS ? 24 : 4;
+    if (which != SL3D_G_VALID && which != SL3D_G_POINTS_F64 && (rc = need_keep(x))) return rc;
+    const size_t elem = (which == SL3D_G_INTERSECTION_POINTS || which == SL3D_G_POINTS_F64) ? 24 : 4;
     ON_DEVICE(x);
     rc = ensure_colrow(x, (size_t)P.W * P.H * 24);
     if (rc) return rc;
@@ -668,16 +668,17 @@ extern "C" int sl3d_set_frames_range(sl3d_ctx *x, int view, int axis, int first_
     uint8_t *dst0 = x->d_frames + (size_t)view * P.view_stride + (size_t)base * P.plane_stride;
     if (back_to_back) {
         // the device planes of an axis are back to back too (plane_stride = pitch * H): the whole range is ONE 2-D copy
-        HIPCHK(x, hipMemcpy2DAsync(dst0, P.pitch, planes[0], stride, P.W, (size_t)P.H * n_planes, hipMemcpyHostToDevice, x->stream));
+        HIPCHK(x, hipMemcpy2DAsync(dst0, P.pitch, planes[0], stride, P.W, (size_t)P.H * n_planes, hipMemcpyDefault, x->stream));
     } else {
         for (int i = 0; i < n_planes; i++)
-            HIPCHK_DRAIN(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyHostToDevice, x->stream));
+            HIPCHK_DRAIN(x, hipMemcpy2DAsync(dst0 + (size_t)i * P.plane_stride, P.pitch, planes[i], stride, P.W, P.H, hipMemcpyDefault, x->stream));
     }
-    // a pageable source is consumed before we return; the hand-over is asynchronous only if EVERY plane of the call is pinned
-    // (callers mix sources: a pinned image next to file-decoded pageable frames)
+    // a pageable source is consumed before we return; the hand-over is asynchronous only if EVERY plane of the call is pinned host
+    // memory or device memory (callers mix sources: a pinned image next to file-decoded pageable frames; planes that already live
+    // on a GPU -- another context's frame stack, an acquisition stage on the device -- are copied device to device)
     bool all_pinned = true;
     for (int i = 0; i < n_planes && all_pinned; i++)
-        if ((i == 0 || !back_to_back) && !is_pinned_host(planes[i])) all_pinned = false;
+        if ((i == 0 || !back_to_back) && memory_kind(planes[i]) == 0) all_pinned = false;
     if (!all_pinned) HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
@@ -746,6 +747,7 @@ extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
                              hipMemcpyDeviceToDevice, x->stream));
     x->quad_seq[dst] = x->quad_seq[src];  // the duplicate's count of selected quads is the source's (until either mask is set again)
     x->quad_src[dst] = x->quad_src[src];
+    x->quad_sum_seq[dst] = 0u;  // (a sum cached for dst under the same sequence number -- one sl3d_set_masks call serves many views -- is not the source's)
     return SL3D_OK;
 }
 

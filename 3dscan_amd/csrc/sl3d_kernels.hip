@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void k_mask_prepare(const KParams P, int first
     if (threadIdx.x == 0) partials[(size_t)view * gridDim.x + blockIdx.x] = ((unsigned long long)seq << 32) | s_quads;
 }
 
+#ifndef SL3D_MASK_ROWS_PER_LANE
 #define SL3D_MASK_ROWS_PER_LANE 4
+#endif
 int mask_prepare_blocks(const KParams &P)
 {
     const long strips = (P.H + 2 * SL3D_MASK_HALO + SL3D_MASK_ROWS_PER_LANE - 1) / SL3D_MASK_ROWS_PER_LANE;
@@ -927,7 +929,7 @@ __global__ __launch_bounds__(256) void k_to_colrow(const TI *__restrict__ src, T
 }
 
 // which: 0..2 valid maps (vertical, horizontal, merged) -> int; 3,4 wrapped; 5,6 unwrapped -> float; 7,8 code -> int;
-// 9 intersection_points -> double[3].  dst: [W][H] elements of the window.
+// 9 intersection_points -> double[3]; 10 the dense f32 result widened -> double[3].  dst: [W][H] elements of the window.
 int launch_to_colrow(const KParams &P, int view, int which, void *dst, void *stream)
 {
     const dim3 grid((unsigned)((P.W + 31) / 32), (unsigned)((P.H + 31) / 32)), block(256);
@@ -941,6 +943,7 @@ int launch_to_colrow(const KParams &P, int view, int which, void *dst, void *str
     case 5: case 6: hipLaunchKernelGGL((k_to_colrow<float, float, 1>), grid, block, 0, st, P.unwrapped[which - 5] + off, (float *)dst, P.W, P.H, P.pitch); break;
     case 7: case 8: hipLaunchKernelGGL((k_to_colrow<int32_t, int, 1>), grid, block, 0, st, P.code[which - 7] + off, (int *)dst, P.W, P.H, P.pitch); break;
     case 9: hipLaunchKernelGGL((k_to_colrow<double, double, 3>), grid, block, 0, st, P.ipoints + 3 * off, (double *)dst, P.W, P.H, P.pitch); break;
+    case 10: hipLaunchKernelGGL((k_to_colrow<float, double, 3>), grid, block, 0, st, P.points + 3 * off, (double *)dst, P.W, P.H, P.pitch); break;
     default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();

@@ -169,7 +169,8 @@ int sl3d_set_masks(sl3d_ctx *ctx, int first_view, int n_views, const uint8_t *fu
  * read_image() 3/wrapped_phase.cpp:29-58 (n_fringe planes) and read_captured_images()
  * 4/phase_unwrap.cpp:51-131 (n_gray planes + n_gray inverse planes) load.
  * planes[] order: fringe[0..F), gray[0..N), inverse_gray[0..N).  Planes that follow each other in host memory (plane i+1
- * at plane i + stride*height) go up as ONE 2-D copy per axis.  Pageable / pinned memory: as for sl3d_set_mask. */
+ * at plane i + stride*height) go up as ONE 2-D copy per axis.  Pageable / pinned memory: as for sl3d_set_mask; planes in DEVICE
+ * memory (another context's frame stack, sl3d_get_device_buffers) are copied device to device, asynchronously. */
 int sl3d_set_frames(sl3d_ctx *ctx, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride);
 
 /* selected_region exactly as the reference holds it: int [full_width][full_height], indexed [col][row]
@@ -294,7 +295,11 @@ int sl3d_get_points(sl3d_ctx *ctx, int view, float *xyz, uint8_t *valid);
  *        writes only its rows of every column.  Needs SL3D_FLAG_KEEP_STAGES.  Synchronises. */
 enum sl3d_global {
     SL3D_G_VALID_V = 0, SL3D_G_VALID_H = 1, SL3D_G_VALID = 2, SL3D_G_WRAPPED_V = 3, SL3D_G_WRAPPED_H = 4,
-    SL3D_G_UNWRAPPED_V = 5, SL3D_G_UNWRAPPED_H = 6, SL3D_G_CODE_V = 7, SL3D_G_CODE_H = 8, SL3D_G_INTERSECTION_POINTS = 9
+    SL3D_G_UNWRAPPED_V = 5, SL3D_G_UNWRAPPED_H = 6, SL3D_G_CODE_V = 7, SL3D_G_CODE_H = 8, SL3D_G_INTERSECTION_POINTS = 9,
+    /* double [W][H][3] like SL3D_G_INTERSECTION_POINTS, but the dense f32 result of sl3d_run widened to double (NaN where invalid):
+     * what a context WITHOUT SL3D_FLAG_KEEP_STAGES has of intersection_points -- the very values 8/save_point_cloud.cpp:98-100
+     * casts them to, i.e. all that the reference's only reader of that global ever sees (like SL3D_G_VALID, no KEEP_STAGES needed) */
+    SL3D_G_POINTS_F64 = 10
 };
 int sl3d_get_global_colrow(sl3d_ctx *ctx, int view, int which, void *out, int out_height, int out_row0);
 

@@ -89,6 +89,36 @@ void sl3d_shim_provide_matrix(const char *relative_path, const double *values, i
 /* save_point_cloud() / register_point_clouds(): 0 = ASCII PCD / PLY like the reference (8/save_point_cloud.cpp:211-217), 1 = the
  * binary flavours of the same formats (PCD "DATA binary", PLY "binary_little_endian") */
 void sl3d_shim_cloud_format(int binary);
+/* Which of the reference's globals the stage functions fill.
+ *   SL3D_SHIM_G_ALL (default): every stage call runs its own kernel and fills its globals before it returns, exactly the hand-over
+ *     the reference's stages have among themselves (the contexts keep every stage plane; ~146 MB of [col][row] arrays come down per scan).
+ *   anything else = DEFERRED: main()'s own calls (m_tech_project_console.cpp:372-395) stay as they are, but compute_wrapped_phase /
+ *     unwrap_phase only bring the mask and their frames to the GPU (from pinned memory or files: asynchronously), compute_c_p_map
+ *     does nothing, and triangulate() runs the whole scan as ONE launch of the timed fused kernel -- the kernel behind sl3d_run, the
+ *     one bench.py measures -- and then fills the globals the mask names:
+ *       SL3D_SHIM_G_FINAL = valid_map + intersection_points: all that the rest of the reference reads (main() reads none of the
+ *         globals; 8/save_point_cloud.cpp:85-104 reads these two).  intersection_points then holds the kernel's f32 result widened to
+ *         double -- the values save_point_cloud.cpp:98-100 casts them to anyway; SL3D_SHIM_G_INTERSECTION_POINTS asks for the doubles
+ *       SL3D_SHIM_G_NONE: nothing (the shim's own save_point_cloud() follows: it reads the device-resident result)
+ *       any other bit: that global too, from a second, parity-mode launch on a context that keeps the stage planes (created on first
+ *         use; frames and mask are copied device to device) -- also available after the scan through sl3d_shim_materialize(which).
+ *     A deferred scan assumes what main() does: selected_region and the scalar globals do not change between the first stage call of
+ *     a scan and its triangulate().  Changing the mode drops the contexts. */
+enum {
+    SL3D_SHIM_G_NONE = 0u,
+    SL3D_SHIM_G_VALID_V = 1u << 0, SL3D_SHIM_G_VALID_H = 1u << 1, SL3D_SHIM_G_VALID = 1u << 2,
+    SL3D_SHIM_G_WRAPPED_V = 1u << 3, SL3D_SHIM_G_WRAPPED_H = 1u << 4, SL3D_SHIM_G_UNWRAPPED_V = 1u << 5, SL3D_SHIM_G_UNWRAPPED_H = 1u << 6,
+    SL3D_SHIM_G_CODE_V = 1u << 7, SL3D_SHIM_G_CODE_H = 1u << 8, SL3D_SHIM_G_C_P_MAP = 1u << 9,
+    SL3D_SHIM_G_INTERSECTION_POINTS = 1u << 10,      /* the fp64 solve's doubles (parity launch) */
+    SL3D_SHIM_G_INTERSECTION_POINTS_F32 = 1u << 11,  /* the timed kernel's f32 result widened to double */
+    SL3D_SHIM_G_FINAL = (1u << 2) | (1u << 11),
+    SL3D_SHIM_G_EVERY = (1u << 12) - 1u,             /* deferred, every global (intersection_points as doubles) */
+    SL3D_SHIM_G_ALL = 0xffffffffu                    /* stage by stage (default) */
+};
+void sl3d_shim_globals(unsigned mask);
+/* after a deferred scan: fill the named globals now (returns an sl3d_status, also in sl3d_shim_last_status); which = 0 fills
+ * nothing and only waits until the scan's launch has finished (triangulate() with SL3D_SHIM_G_NONE returns right after launching) */
+int sl3d_shim_materialize(unsigned which);
 /* measurement switch: 1 = fetch row-major planes and transpose them on the host (the shim's behaviour before the globals were
  * transposed on the device); the results are identical */
 void sl3d_shim_host_transpose(int enable);

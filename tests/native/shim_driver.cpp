@@ -4,6 +4,7 @@
 //   shim_driver <data_root> <out.bin> Nv Nh fwv fwh ncv nch
 //   shim_driver register <data_root> n tx ty tz rot_step : register_point_clouds() only (9/register_point_clouds.cpp:23)
 //   shim_driver patterns <data_root> F fwv fwh      : generate_pattern() only (1/pattern_generator.cpp:513); prints the counts
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -33,7 +34,7 @@ int main(int argc, char **argv)
     }
     if (argc < 9) return 2;
     sl3d_shim_set_data_root(argv[1]);
-    sl3d_shim_write_debug_images(1);
+    sl3d_shim_write_debug_images(getenv("SL3D_SHIM_NO_DEBUG") ? 0 : 1);
     // switches of the test: SL3D_SHIM_HOST_TRANSPOSE=1 (row-major download + host transposes), SL3D_SHIM_BINARY=1 (binary PCD / PLY),
     // SL3D_SHIM_MEMORY=1: the frames, the texture and the calibration are handed over in memory (frames.raw: per axis F fringe,
     // N gray, N inverse planes of W*H bytes; texture.raw: H*W*3 B,G,R; cal.raw: 40 doubles) -- no BMP / XML file exists then
@@ -95,6 +96,22 @@ int main(int argc, char **argv)
         for (int r = 0; r < Camera_imageheight; r++)
             for (int c = 0; c < Camera_imagewidth; c++) selected_region[c][r] = m[(size_t)r * Camera_imagewidth + c];
     }
+    // SL3D_SHIM_GLOBALS=<hex mask>: the deferred mode (sl3d_shim_globals); SL3D_SHIM_SCANS=n: main()'s scan loop n times -- every scan
+    // but the last one with ANOTHER selection (a block cleared), so that a stale mask or stale frames would show in the dump
+    const unsigned gmask = getenv("SL3D_SHIM_GLOBALS") ? (unsigned)strtoul(getenv("SL3D_SHIM_GLOBALS"), nullptr, 16) : (unsigned)SL3D_SHIM_G_ALL;
+    sl3d_shim_globals(gmask);
+    const int scans = getenv("SL3D_SHIM_SCANS") ? atoi(getenv("SL3D_SHIM_SCANS")) : 1;
+    for (int scan = 0; scan < scans; scan++) {
+    if (scans > 1) {
+        static std::vector<int> orig;
+        int *flat = &selected_region[0][0];
+        const size_t npx = (size_t)Camera_imagewidth * Camera_imageheight;
+        if (orig.empty()) orig.assign(flat, flat + npx);
+        std::copy(orig.begin(), orig.end(), flat);
+        if (scan != scans - 1)
+            for (int c = Camera_imagewidth / 4; c < Camera_imagewidth / 2; c++)
+                for (int r = Camera_imageheight / 4; r < Camera_imageheight / 2; r++) selected_region[c][r] = 0;
+    }
     compute_wrapped_phase(0);
     if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 10; }
     compute_wrapped_phase(1);
@@ -112,6 +129,14 @@ int main(int argc, char **argv)
         if (t) fclose(t);
         save_point_cloud(3);
         if (sl3d_shim_last_status()) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 16; }
+    }
+    }  // scan loop
+    // a deferred scan filled only the globals its mask names: the dump below wants them all, so the rest is asked for now
+    // (intersection_points stays what the mask made it: the f32 result widened with SL3D_SHIM_G_FINAL, the doubles otherwise)
+    if (gmask != (unsigned)SL3D_SHIM_G_ALL) {
+        unsigned rest = (unsigned)SL3D_SHIM_G_EVERY & ~gmask & ~(unsigned)SL3D_SHIM_G_INTERSECTION_POINTS_F32;
+        if (gmask & SL3D_SHIM_G_INTERSECTION_POINTS_F32) rest &= ~(unsigned)SL3D_SHIM_G_INTERSECTION_POINTS;
+        if (rest && sl3d_shim_materialize(rest)) { fprintf(stderr, "\n%s\n", sl3d_shim_last_error()); return 17; }
     }
 
     FILE *o = fopen(argv[2], "wb");

@@ -29,14 +29,32 @@ def _xml(path, name, rows, cols, vals):
                 % (name, rows, cols, " ".join("%.17e" % v for v in vals), name))
 
 
+# the deferred mode (sl3d_shim_globals): <inputs>+deferred_<mask>[x<scans>]
+DEFERRED = {"every": 0xfff, "final": 0x804, "none": 0x0, "phases": 0x804 | 0x78}
+
+
 @pytest.mark.parametrize("devices,mode", [(None, "files"), ("0,0,0", "files"), (None, "memory"), ("0,0,0", "memory"), (None, "host_transpose"),
-                                          ("0,0,0", "host_transpose"), (None, "binary")])
+                                          ("0,0,0", "host_transpose"), (None, "binary"),
+                                          (None, "files+deferred_every"), (None, "files+deferred_final"), (None, "memory+deferred_none"),
+                                          ("0,0,0", "files+deferred_final"), ("0,0,0", "memory+deferred_every"), (None, "files+deferred_phases"),
+                                          (None, "memory+deferred_final_x3"), (None, "files+deferred_none_x2"), (None, "files+stagewise_x2")])
 def test_shim_matches_oracle(tmp_path, devices, mode):
     """devices = "0,0,0": SL3D_DEVICES splits the scan into three row stripes (sl3d_group_*; here all on GPU 0): every
     reference-layout global and both cloud files must come out exactly as on one context.
     mode: files = the reference's BMP / XML inputs; memory = the same inputs handed over in memory (sl3d_shim_provide_image /
     _matrix; no input file exists); host_transpose = the pre-round-3 route (row-major planes transposed by the host) instead of
     the [col][row] globals produced on the device; binary = binary PCD / PLY cloud files."""
+    # deferred modes: main()'s six calls unchanged, but ONE launch of the timed fused kernel inside triangulate(); the globals the mask
+    # names are filled by triangulate(), the others afterwards by sl3d_shim_materialize (a parity-mode launch on the same frames) -- every
+    # global must still equal the oracle's; with `final` intersection_points holds the f32 result widened to double.  _xN: the scan loop
+    # N times with another selection in the earlier scans (stale masks / frames / staging slots would show).
+    mode, _, extra = mode.partition("+")
+    deferred, scans = None, 1
+    if extra:
+        parts = extra.split("_")
+        if parts[-1].startswith("x"):
+            scans = int(parts.pop()[1:])
+        deferred = DEFERRED[parts[1]] if parts[0] == "deferred" else None
     syn = pkg("synth")
     cap = syn.make_capture(W, H, PW, PH, NV, NH, FWV, FWH, noise=2)
     rng = np.random.default_rng(5)
@@ -99,6 +117,13 @@ def test_shim_matches_oracle(tmp_path, devices, mode):
     if devices:
         env["SL3D_DEVICES"] = devices
     env.update({"memory": {"SL3D_SHIM_MEMORY": "1"}, "host_transpose": {"SL3D_SHIM_HOST_TRANSPOSE": "1"}, "binary": {"SL3D_SHIM_BINARY": "1"}}.get(mode, {}))
+    if deferred is not None:
+        env["SL3D_SHIM_GLOBALS"] = "%x" % deferred
+    if scans > 1:
+        env["SL3D_SHIM_SCANS"] = str(scans)
+    no_debug = deferred == 0   # (without the debug images nothing touches the parity contexts before sl3d_shim_materialize does)
+    if no_debug:
+        env["SL3D_SHIM_NO_DEBUG"] = "1"
     r = subprocess.run([exe, root, out, str(NV), str(NH), str(FWV), str(FWH), str(ncv), str(nch)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
 
@@ -132,12 +157,19 @@ def test_shim_matches_oracle(tmp_path, devices, mode):
     assert np.array_equal(uh[o.valid_map(1) == 1], o.unwrapped_phi(1)[o.valid_map(1) == 1])
     assert np.array_equal(cp[v], o.c_p_map()[v])
     assert_points_close(ip, o.intersection_points(), v)
+    if deferred is not None and deferred & 0x800:   # the timed kernel's f32 points, widened: what save_point_cloud casts them to anyway
+        assert np.array_equal(ip[v], ip[v].astype(np.float32).astype(np.float64))
+    elif deferred is not None:                       # the fp64 solve's own doubles (parity launch)
+        assert not np.array_equal(ip[v], ip[v].astype(np.float32).astype(np.float64))
     # the debug images written next to the inputs are the reference's stage-3/4 outputs
     for a in (0, 1):
+        if no_debug:
+            break
         d3 = np.array(Image.open(f"{root}/Wrapped_phase_images/{ax[a]}/Wrapped_phase_image.bmp"))
         assert np.array_equal(d3, o.debug_image(3, a))
-    d4 = np.array(Image.open(f"{root}/Unwrapped_phase_images/Gray_coded/Vertical/Unwrapped_phase_vertical.bmp"))
-    assert np.array_equal(d4, o.debug_image(4, 0))
+    if not no_debug:
+        d4 = np.array(Image.open(f"{root}/Unwrapped_phase_images/Gray_coded/Vertical/Unwrapped_phase_vertical.bmp"))
+        assert np.array_equal(d4, o.debug_image(4, 0))
     # save_point_cloud(3): valid pixels in row-major scan order, float xyz, r,g,b of the texture (8/save_point_cloud.cpp:85-104)
     exp_xyz = o.intersection_points()[v].astype(np.float32)
     exp_rgb = texture[v]

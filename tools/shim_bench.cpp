@@ -184,8 +184,13 @@ int main(int argc, char **argv)
     const char *inputs[3] = {"files", "memory", "pinned"};
     for (int in = 0; in < 3; in++) {
         provide(in == 0 ? nullptr : in == 1 ? pageable.data() : pinned);
-        for (int host = 0; host < 2; host++) {
-            sl3d_shim_host_transpose(host);
+        // host: 0 = globals transposed on the device, 1 = by the host (both stage by stage, every global after every stage);
+        // 2, 3 = DEFERRED (sl3d_shim_globals): one launch of the timed fused kernel inside triangulate(), then valid_map +
+        // intersection_points (FINAL: what 8/save_point_cloud.cpp reads) or no global at all (NONE: the shim's own save_point_cloud()
+        // follows); the triangulate lap of NONE includes the wait for the launch (sl3d_shim_materialize(0))
+        for (int host = 0; host < 4; host++) {
+            sl3d_shim_host_transpose(host == 1);
+            sl3d_shim_globals(host == 2 ? (unsigned)SL3D_SHIM_G_FINAL : host == 3 ? (unsigned)SL3D_SHIM_G_NONE : (unsigned)SL3D_SHIM_G_ALL);
             std::vector<double> t[9];
             for (int s = 0; s < scans + 1; s++) {  // scan 0 warms up (context creation, first-touch of the globals)
                 double t0 = now_ms(), t1;
@@ -195,7 +200,9 @@ int main(int argc, char **argv)
                 unwrap_phase(0); lap(2);
                 unwrap_phase(1); lap(3);
                 compute_c_p_map(); lap(4);
-                triangulate(); lap(5);
+                triangulate();
+                if (host == 3) sl3d_shim_materialize(0);
+                lap(5);
                 if (sl3d_shim_last_status()) { fprintf(stderr, "%s\n", sl3d_shim_last_error()); return 10; }
             }
             // the cloud files are written from the device-resident result whatever the inputs were: timed in the first
@@ -215,15 +222,17 @@ int main(int argc, char **argv)
                     if (w) { t[6].push_back(t1 - t0); t[7].push_back(t2 - t1); }
                 }
             }
+            if (host == 3) sl3d_shim_materialize(SL3D_SHIM_G_VALID);
             long long n = 0;
             for (int c = 0; c < W; c++)
                 for (int r = 0; r < H; r++) n += valid_map[c][r];
+            if (npoints && n != npoints) { fprintf(stderr, "valid points differ between the routes: %lld vs %lld\n", n, npoints); return 12; }
             npoints = n;
             double six = 0;
             for (int k = 0; k < 6; k++) six += median(t[k]);
             printf(", \"%s/%s\": {\"wrapped_v\": %.3f, \"wrapped_h\": %.3f, \"unwrap_v\": %.3f, \"unwrap_h\": %.3f, \"c_p_map\": %.3f, \"triangulate\": %.3f, "
                    "\"six_stages\": %.3f",
-                   inputs[in], host ? "host_transposes" : "device_colrow", median(t[0]), median(t[1]), median(t[2]), median(t[3]), median(t[4]), median(t[5]), six);
+                   inputs[in], host == 0 ? "device_colrow" : host == 1 ? "host_transposes" : host == 2 ? "deferred_final" : "deferred_none", median(t[0]), median(t[1]), median(t[2]), median(t[3]), median(t[4]), median(t[5]), six);
             if (!t[6].empty()) printf(", \"save_point_cloud_ascii\": %.3f, \"save_point_cloud_binary\": %.3f", median(t[6]), median(t[7]));
             printf("}");
         }
