@@ -624,12 +624,13 @@ size_t axis_slot0(int pattern_type) { return pattern_type == 0 ? 0 : (size_t)(g.
 size_t scan_slots() { return (size_t)(2 * g.F + 2 * g.Nv + 2 * g.Nh); }
 
 // The parity contexts of a deferred scan: same configuration with SL3D_FLAG_KEEP_STAGES, one per part, on the part's GPU.  They take
-// the scan's frames and mask from the parts' own device buffers (device-to-device) and run the scan once more as ONE launch of the
-// parity-mode fused kernel, which leaves every stage plane behind.  Only sl3d_shim_materialize / a globals mask that names a
+// the scan's frames and mask from the parts' own device buffers (device-to-device) and run the scan once more through the per-stage
+// kernels, which leave every stage plane behind exactly as the reference's stages leave their globals.  Only sl3d_shim_materialize / a globals mask that names a
 // stage global ever gets here.
 bool run_twins()
 {
     if (g.twin_fresh) return true;
+    if (!sync_parts()) return false;  // the parts' uploads run on their own streams: they must have landed before they are copied from
     for (Part &q : g.parts) {
         if (!q.twin) {
             sl3d_config c;
@@ -653,8 +654,14 @@ bool run_twins()
             rc = sl3d_set_frames(q.twin, 0, a, planes.data(), n, b.frame_pitch);
         }
         if (rc == SL3D_OK) rc = set_cal(q.twin, g.cal);
-        if (rc == SL3D_OK) rc = sl3d_run(q.twin, 0, 1);
-        if (rc != SL3D_OK) return fail(rc, std::string("parity launch: ") + sl3d_strerror(rc) + ": " + sl3d_last_error(q.twin));
+        // the per-stage kernels, in main()'s order: they leave every plane as the reference's stages leave their globals (the wrapped
+        // phase of selected pixels the boundary removal drops, the debug images), which one parity-mode launch of the fused kernel does
+        // not (it defines the planes on valid pixels only)
+        for (int a = 0; a < 2 && rc == SL3D_OK; a++) rc = sl3d_compute_wrapped_phase(q.twin, 0, a);
+        for (int a = 0; a < 2 && rc == SL3D_OK; a++) rc = sl3d_unwrap_phase(q.twin, 0, a);
+        if (rc == SL3D_OK) rc = sl3d_compute_c_p_map(q.twin, 0);
+        if (rc == SL3D_OK) rc = sl3d_triangulate(q.twin, 0);
+        if (rc != SL3D_OK) return fail(rc, std::string("parity stages: ") + sl3d_strerror(rc) + ": " + sl3d_last_error(q.twin));
     }
     g.twin_fresh = true;
     return true;
@@ -671,7 +678,12 @@ bool fill_globals(unsigned which)
 {
     const size_t px = (size_t)W * H;
     auto from = [&](bool twin, int id, void *dst) {
-        return each_part("sl3d_get_global_colrow", [&](const Part &q) { return sl3d_get_global_colrow(twin ? q.twin : q.ctx, 0, id, dst, H, q.row0); });
+        for (const Part &q : g.parts) {
+            sl3d_ctx *c = twin ? q.twin : q.ctx;
+            const int rc = sl3d_get_global_colrow(c, 0, id, dst, H, q.row0);
+            if (rc != SL3D_OK) return fail(rc, std::string("sl3d_get_global_colrow: ") + sl3d_strerror(rc) + ": " + sl3d_last_error(c));
+        }
+        return true;
     };
     const unsigned stage_bits = which & ~(unsigned)(SL3D_SHIM_G_VALID | SL3D_SHIM_G_INTERSECTION_POINTS_F32);
     if (stage_bits && !run_twins()) return false;
@@ -680,7 +692,7 @@ bool fill_globals(unsigned which)
         if (!from(false, SL3D_G_VALID, valid_map)) return false;
     }
     if (which & (SL3D_SHIM_G_INTERSECTION_POINTS | SL3D_SHIM_G_INTERSECTION_POINTS_F32)) {
-        ensure_global(intersection_points, px);
+        ensure_global(intersection_points, px * 3);
         const bool exact = (which & SL3D_SHIM_G_INTERSECTION_POINTS) != 0;
         if (!from(exact, exact ? SL3D_G_INTERSECTION_POINTS : SL3D_G_POINTS_F64, intersection_points)) return false;
     }
@@ -697,7 +709,10 @@ bool fill_globals(unsigned which)
     }
     if (which & SL3D_SHIM_G_C_P_MAP) {
         if (!c_p_map) c_p_map = (long int (*)[2])alloc_global<long int>((size_t)total_camera_pixels * 2);
-        if (!each_part("sl3d_get_c_p_map", [&](const Part &q) { return sl3d_get_c_p_map(q.twin, 0, (int64_t *)c_p_map + 2 * (size_t)q.row0 * W); })) return false;
+        for (const Part &q : g.parts) {
+            const int rc = sl3d_get_c_p_map(q.twin, 0, (int64_t *)c_p_map + 2 * (size_t)q.row0 * W);
+            if (rc != SL3D_OK) return fail(rc, std::string("sl3d_get_c_p_map: ") + sl3d_strerror(rc) + ": " + sl3d_last_error(q.twin));
+        }
     }
     return true;
 }

@@ -100,8 +100,8 @@ void sl3d_shim_cloud_format(int binary);
  *         globals; 8/save_point_cloud.cpp:85-104 reads these two).  intersection_points then holds the kernel's f32 result widened to
  *         double -- the values save_point_cloud.cpp:98-100 casts them to anyway; SL3D_SHIM_G_INTERSECTION_POINTS asks for the doubles
  *       SL3D_SHIM_G_NONE: nothing (the shim's own save_point_cloud() follows: it reads the device-resident result)
- *       any other bit: that global too, from a second, parity-mode launch on a context that keeps the stage planes (created on first
- *         use; frames and mask are copied device to device) -- also available after the scan through sl3d_shim_materialize(which).
+ *       any other bit: that global too, from the per-stage kernels run on a second context that keeps the stage planes (created on
+ *         first use; frames and mask are copied device to device) -- also available after the scan through sl3d_shim_materialize(which).
  *     A deferred scan assumes what main() does: selected_region and the scalar globals do not change between the first stage call of
  *     a scan and its triangulate().  Changing the mode drops the contexts. */
 enum {

@@ -147,9 +147,11 @@ def test_selected_quad_count_follows_masks_and_copies():
         assert np.array_equal(got[1], ref0[1]) and np.array_equal(got[0], ref0[0], equal_nan=True)
         sc.run(0, 2)
         assert sc.last_fused_kernel_name().endswith(gated)
-        sc.set_mask(dense, view=0)   # the source of the duplicate gets another mask: the duplicate's count is unknown -> dense default
-        sc.run(1, 1)
+        sc.set_mask(dense, view=0)   # the source of the duplicate gets another mask: the duplicate keeps its own (sparse) mask and count
+        sc.run(0, 1)
         assert sc.last_fused_kernel_name().endswith(small), sc.last_fused_kernel_name()
+        sc.run(1, 1)
+        assert sc.last_fused_kernel_name().endswith(gated), sc.last_fused_kernel_name()
         got = sc.points(1)
         assert np.array_equal(got[1], ref0[1]) and np.array_equal(got[0], ref0[0], equal_nan=True)
         sc.run_clouds(0, 1)
@@ -192,4 +194,4 @@ def test_axis_without_gray_planes_on_the_last_resident_view(Nv, Nh):
         assert_points_close(batch[v][0], oxyz, ovalid == 1)
         assert np.array_equal(clouds[v], batch[v][0][ovalid == 1]), v
         nvalid += int(ovalid.sum())
-    assert nvalid > 1000
+    assert nvalid > 100

@@ -157,7 +157,7 @@ def test_shim_matches_oracle(tmp_path, devices, mode):
     assert np.array_equal(uh[o.valid_map(1) == 1], o.unwrapped_phi(1)[o.valid_map(1) == 1])
     assert np.array_equal(cp[v], o.c_p_map()[v])
     assert_points_close(ip, o.intersection_points(), v)
-    if deferred is not None and deferred & 0x800:   # the timed kernel's f32 points, widened: what save_point_cloud casts them to anyway
+    if deferred is not None and deferred & 0x800 and not deferred & 0x400:   # the timed kernel's f32 points, widened: what save_point_cloud casts them to anyway
         assert np.array_equal(ip[v], ip[v].astype(np.float32).astype(np.float64))
     elif deferred is not None:                       # the fp64 solve's own doubles (parity launch)
         assert not np.array_equal(ip[v], ip[v].astype(np.float32).astype(np.float64))
