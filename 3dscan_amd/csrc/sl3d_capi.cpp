@@ -1138,6 +1138,7 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
     void *mapped = nullptr;
     HIPCHK(x, hipHostGetDevicePointer(&mapped, x->h_counts, 0));
     P.cloud_totals = (unsigned long long *)mapped;
+    x->scan_state.assign(mv, 0);
     x->clouds_ready = true;
     return SL3D_OK;
 }
@@ -1156,7 +1157,30 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
     if (rc) return rc;
     rc = run_fused(x, first_view, n_views, false, 2);
     if (rc) return rc;
+    // A launch of a few views (the reference's one scan per call) leaves the scan of the segment counts to whoever consumes the
+    // clouds: the gap-closing kernel adds up the counts in front of its segments itself, so there is no scan launch -- 4.8 us + a
+    // kernel boundary behind a 26-us kernel -- between the fused kernel and its consumer; a consumer that wants the offsets as an
+    // array (sl3d_get_cloud_segments) gets the scan then.  Large launches scan here, as before: one launch for all views.
+    if (n_views <= SL3D_SMALL_LAUNCH_VIEWS) {
+        for (int v = first_view; v < first_view + n_views; v++) x->scan_state[v] = 1;
+        return SL3D_OK;
+    }
+    for (int v = first_view; v < first_view + n_views; v++) x->scan_state[v] = 0;
     return launched(x, launch_seg_scan(x->P, first_view, n_views, x->stream));
+}
+
+// offsets and totals of views [first_view, first_view + n_views) are (being) computed: k_seg_scan for the views that still lack them
+static int ensure_scanned(sl3d_ctx *x, int first_view, int n_views)
+{
+    for (int v = first_view; v < first_view + n_views;) {
+        if (x->scan_state[v] == 0) { v++; continue; }
+        int e = v;
+        while (e < first_view + n_views && x->scan_state[e] != 0) x->scan_state[e++] = 0;
+        const int rc = launched(x, launch_seg_scan(x->P, v, e - v, x->stream));
+        if (rc) return rc;
+        v = e;
+    }
+    return SL3D_OK;
 }
 
 static int ensure_packed(sl3d_ctx *x)
@@ -1173,9 +1197,31 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
     ON_DEVICE(x);
-    // the scan kernel stored the counts into pinned host memory itself: wait for it, read them
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    bool unscanned = false, no_total = false;
+    for (int v = first_view; v < first_view + n_views; v++) {
+        unscanned |= x->scan_state[v] != 0;
+        no_total |= x->scan_state[v] == 1;
+    }
     volatile unsigned long long *t = x->h_counts;
+    if (device_xyz && unscanned) {
+        // the contiguous copy by the gap-closing kernel that scans on entry: it leaves the totals too -- ONE launch, one wait
+        rc = ensure_packed(x);
+        if (rc) return rc;
+        float *dst = x->d_packed + 3 * (size_t)first_view * x->P.px_view_stride;
+        rc = launched(x, launch_seg_close_scan(x->P, first_view, n_views, dst, x->P.px_view_stride, ~0ull, x->stream));
+        if (rc) return rc;
+        HIPCHK(x, hipStreamSynchronize(x->stream));
+        for (int v = 0; v < n_views; v++) {
+            counts[v] = (int64_t)t[first_view + v];
+            if (x->scan_state[first_view + v] == 1) x->scan_state[first_view + v] = 2;
+        }
+        *device_xyz = dst;
+        if (view_stride_points) *view_stride_points = x->P.px_view_stride;
+        return SL3D_OK;
+    }
+    if (no_total && (rc = ensure_scanned(x, first_view, n_views))) return rc;
+    // the scan kernel (or a scanning consumer) stored the counts into pinned host memory itself: wait for it, read them
+    HIPCHK(x, hipStreamSynchronize(x->stream));
     for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[first_view + v];
     if (device_xyz) {  // the contiguous copy is made now, by one gap-closing launch over these views
         rc = ensure_packed(x);
@@ -1198,6 +1244,11 @@ extern "C" int sl3d_get_cloud_segments(sl3d_ctx *x, int first_view, int n_views,
     if (rc) return rc;
     if (!out) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
+    {   // this consumer wants the offsets as an array: the scan runs now if the launch left it out
+        ON_DEVICE(x);
+        rc = ensure_scanned(x, first_view, n_views);
+        if (rc) return rc;
+    }
     if (counts) {
         rc = sl3d_get_cloud_counts(x, first_view, n_views, nullptr, nullptr, counts);
         if (rc) return rc;
@@ -1221,6 +1272,24 @@ extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, fl
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
+    if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
+    if (n_views == 1 && xyz && capacity > 0 && x->scan_state[first_view] != 0) {
+        // ONE unscanned view into pinned host memory -- the reference's own consumer (8/save_point_cloud.cpp:85-104 fills a host cloud
+        // per scan): the gap-closing kernel scans on entry, stores straight into the mapped host buffer (clamped to its capacity)
+        // and leaves the count -- fused kernel, this kernel, one wait; no scan launch, no wait for the count in between
+        ON_DEVICE(x);
+        void *mapped = nullptr;
+        const char *zc = getenv("SL3D_ZEROCOPY");
+        if (!(zc && atoi(zc) == 0) && is_pinned_host(xyz) && hipHostGetDevicePointer(&mapped, xyz, 0) == hipSuccess && mapped) {
+            rc = launched(x, launch_seg_close_scan(x->P, first_view, 1, (float *)mapped, 0, (unsigned long long)capacity, x->stream));
+            if (rc) return rc;
+            HIPCHK(x, hipStreamSynchronize(x->stream));
+            counts[0] = (int64_t)((volatile unsigned long long *)x->h_counts)[first_view];
+            if (x->scan_state[first_view] == 1) x->scan_state[first_view] = 2;
+            return SL3D_OK;
+        }
+        (void)hipGetLastError();
+    }
     rc = sl3d_get_cloud_counts(x, first_view, n_views, nullptr, nullptr, counts);
     if (rc || !xyz) return rc;
     ON_DEVICE(x);
@@ -1233,6 +1302,8 @@ extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, fl
                            hipHostGetDevicePointer(&mapped, xyz, 0) == hipSuccess && mapped;
     if (!zero_copy) (void)hipGetLastError();
     if (zero_copy) {
+        rc = ensure_scanned(x, first_view, n_views);  // (k_seg_close reads the offsets array)
+        if (rc) return rc;
         int64_t off = 0;
         for (int v = 0; v < n_views; v++) {
             if (counts[v] > 0) {
@@ -1428,6 +1499,12 @@ extern "C" int sl3d_register_clouds(sl3d_ctx *x, int first_view, int n_views, fl
     if (rc) return rc;
     if (!total) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     std::vector<int64_t> counts((size_t)n_views);
+    if (!x->clouds_ready) return fail(x, SL3D_E_STATE, "sl3d_run_clouds has not been called");
+    {   // (k_seg_close<REG> reads the offsets array: the scan runs now if the launch left it out)
+        ON_DEVICE(x);
+        rc = ensure_scanned(x, first_view, n_views);
+        if (rc) return rc;
+    }
     rc = sl3d_get_cloud_counts(x, first_view, n_views, nullptr, nullptr, counts.data());
     if (rc) return rc;
     ON_DEVICE(x);

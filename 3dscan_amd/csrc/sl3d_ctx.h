@@ -60,6 +60,9 @@ struct sl3d_ctx {
     unsigned *d_seg_counts = nullptr;         // sl3d_run_clouds (segmented clouds): [view][n_segs] counts, their exclusive scan,
     unsigned long long *d_seg_offsets = nullptr;
     float *d_packed = nullptr;                // and the contiguous copy made on demand (also the output of sl3d_compact_views)
+    // per view, after sl3d_run_clouds: 0 = k_seg_scan has run (offsets and total valid), 1 = not scanned -- a launch of a few views
+    // leaves the scan to the consumer (k_seg_close<.., SCAN>), 2 = a scanning consumer has left the total, the offsets are still unset
+    std::vector<uint8_t> scan_state;
     bool clouds_ready = false;                // ensure_cloud_buffers ran to its end: every pointer sl3d_run_clouds needs is set
     unsigned long long *h_counts = nullptr;   // pinned + mapped: the per-view counts k_seg_scan stores, sl3d_get_cloud_counts reads
     uint8_t *d_texture = nullptr;             // [view][row][pitch][3] BGR texture of save_point_cloud (allocated by sl3d_set_texture)

@@ -136,6 +136,10 @@ int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmo
 int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream);
 // segments -> contiguous: view first_view+k's points to dst + 3*k*dst_view_stride_points (dst: device memory or mapped host memory)
 int launch_seg_close(const KParams &P, int first_view, int n_views, float *dst, size_t dst_view_stride_points, void *stream);
+// the same when the views' counts have not been scanned: the consumer scans on entry (k_seg_close<.., SCAN>), writes at most
+// capacity_points points per view and leaves the views' totals in P.cloud_totals
+int launch_seg_close_scan(const KParams &P, int first_view, int n_views, float *dst, size_t dst_view_stride_points, unsigned long long capacity_points,
+                          void *stream);
 // register_point_clouds on segmented input: view first_view+k rotated by R4[4*k..], written at out + 3*(out_base[k] + offset)
 int launch_seg_register(const KParams &P, int view, float *out, const float R4[4], float tx, float ty, float tz, void *stream);
 int fused_tiles(const KParams &P);  // number of 1024-pixel tiles per view (KParams::n_tiles)

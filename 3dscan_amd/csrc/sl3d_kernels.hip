@@ -715,19 +715,53 @@ int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream)
 }
 
 // REG = false: plain copy (closing the gaps); true: the rigid transform of k_register on the way (9/register_point_clouds.cpp:109-117)
-template <bool REG>
+// SCAN = false: the segments' offsets come from k_seg_scan.  true: the consumer scans on entry -- a block (4 segments) adds up the
+// counts in front of it itself (at most n_segs dwords from the L2, 16 bytes per lane and step: what every part of k_seg_scan does
+// for its carry), so a launch of a few views needs NO scan launch between the fused kernel and its consumer; the last block leaves
+// the view's total in total_out[view] (host memory mapped into the device: sl3d_get_cloud_counts' word).  Points whose index in the
+// closed cloud is >= capacity are not written (a destination smaller than the cloud takes its first `capacity` points).
+template <bool REG, bool SCAN>
 __global__ __launch_bounds__(256) void k_seg_close(const float *__restrict__ seg_xyz, const unsigned *__restrict__ counts,
                                                    const unsigned long long *__restrict__ offsets, int n_segs, size_t src_view_stride, float *dst,
-                                                   size_t dst_view_stride, float r00, float r02, float r20, float r22, float tx, float ty, float tz)
+                                                   size_t dst_view_stride, float r00, float r02, float r20, float r22, float tx, float ty, float tz,
+                                                   unsigned long long *total_out, unsigned long long capacity)
 {
     typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
-    const int seg = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u), v = blockIdx.y;
-    if (seg >= n_segs) return;
-    const unsigned cnt = counts[(size_t)v * n_segs + seg];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int seg = blockIdx.x * 4 + wave, lane = (int)(threadIdx.x & 63u), v = blockIdx.y;
+    const unsigned cnt = seg < n_segs ? counts[(size_t)v * n_segs + seg] : 0u;
+    unsigned long long off;
+    if (SCAN) {
+        __shared__ unsigned long long s_front[4];
+        __shared__ unsigned s_cnt[4];
+        const unsigned *cv = counts + (size_t)v * n_segs;
+        const int n_front = (int)blockIdx.x * 4;  // (whole 16-byte groups: n_segs = 4 * tiles, every row of counts is 16-byte aligned)
+        unsigned long long acc = 0ull;
+        for (int i = 4 * (int)threadIdx.x; i < n_front; i += 1024) {
+            const uint4 f = *(const uint4 *)(cv + i);
+            acc += (unsigned long long)f.x + f.y + f.z + f.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            s_front[wave] = acc;
+            s_cnt[wave] = cnt;
+        }
+        __syncthreads();
+        off = s_front[0] + s_front[1] + s_front[2] + s_front[3];
+#pragma unroll
+        for (int w = 0; w < 4; w++) off += w < wave ? s_cnt[w] : 0u;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 192) total_out[v] = off + cnt;  // (wave 3 of the last block: everything in front + its own)
+    } else {
+        if (seg >= n_segs) return;
+        off = offsets[(size_t)v * n_segs + seg];
+    }
     // (a 3-float vector type is PADDED to 16 bytes: points are addressed through float pointers, 12 bytes apart)
     const float *src = seg_xyz + 3 * ((size_t)v * src_view_stride + (size_t)seg * SL3D_SEG_POINTS);
-    float *out = dst + 3 * ((size_t)v * dst_view_stride + (size_t)offsets[(size_t)v * n_segs + seg]);
-    for (unsigned i = (unsigned)lane; i < cnt; i += 64u) {
+    float *out = dst + 3 * ((size_t)v * dst_view_stride + (size_t)off);
+    const unsigned long long room = off < capacity ? capacity - off : 0ull;
+    const unsigned n = SCAN ? (unsigned)(room < cnt ? room : cnt) : cnt;
+    for (unsigned i = (unsigned)lane; i < n; i += 64u) {
         f32x3 p = *(const f32x3 *)(src + 3 * (size_t)i);
         if (REG) {
             const float x = p.x - tx, y = p.y - ty, z = p.z - tz;
@@ -743,19 +777,33 @@ __global__ __launch_bounds__(256) void k_seg_close(const float *__restrict__ seg
 int launch_seg_close(const KParams &P, int first_view, int n_views, float *dst, size_t dst_view_stride_points, void *stream)
 {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_seg_close<false>, dim3((unsigned)((P.n_segs + 3) / 4), (unsigned)n_views), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_seg_close<false, false>), dim3((unsigned)((P.n_segs + 3) / 4), (unsigned)n_views), dim3(256), 0, (hipStream_t)stream,
                        P.clouds + 3 * (size_t)first_view * P.px_view_stride, P.seg_counts + (size_t)first_view * P.n_segs,
                        P.seg_offsets + (size_t)first_view * P.n_segs, P.n_segs, P.px_view_stride, dst, dst_view_stride_points, 0.f, 0.f, 0.f, 0.f, 0.f,
-                       0.f, 0.f);
+                       0.f, 0.f, (unsigned long long *)nullptr, ~0ull);
+    return (int)hipGetLastError();
+}
+
+// the same for views whose segment counts have NOT been scanned (sl3d_run_clouds over a few views leaves the scan to its consumer):
+// view first_view + k to dst + 3 * k * dst_view_stride_points, at most capacity_points points of each; the views' totals go to
+// P.cloud_totals
+int launch_seg_close_scan(const KParams &P, int first_view, int n_views, float *dst, size_t dst_view_stride_points, unsigned long long capacity_points,
+                          void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_seg_close<false, true>), dim3((unsigned)((P.n_segs + 3) / 4), (unsigned)n_views), dim3(256), 0, (hipStream_t)stream,
+                       P.clouds + 3 * (size_t)first_view * P.px_view_stride, P.seg_counts + (size_t)first_view * P.n_segs,
+                       (const unsigned long long *)nullptr, P.n_segs, P.px_view_stride, dst, dst_view_stride_points, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                       P.cloud_totals + first_view, capacity_points);
     return (int)hipGetLastError();
 }
 
 int launch_seg_register(const KParams &P, int view, float *out, const float R4[4], float tx, float ty, float tz, void *stream)
 {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_seg_close<true>, dim3((unsigned)((P.n_segs + 3) / 4), 1u), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_seg_close<true, false>), dim3((unsigned)((P.n_segs + 3) / 4), 1u), dim3(256), 0, (hipStream_t)stream,
                        P.clouds + 3 * (size_t)view * P.px_view_stride, P.seg_counts + (size_t)view * P.n_segs, P.seg_offsets + (size_t)view * P.n_segs,
-                       P.n_segs, P.px_view_stride, out, (size_t)0, R4[0], R4[1], R4[2], R4[3], tx, ty, tz);
+                       P.n_segs, P.px_view_stride, out, (size_t)0, R4[0], R4[1], R4[2], R4[3], tx, ty, tz, (unsigned long long *)nullptr, ~0ull);
     return (int)hipGetLastError();
 }
 

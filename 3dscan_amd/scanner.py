@@ -240,6 +240,11 @@ class Scanner:
     def set_masks(self, masks, first_view=0, n_views=None):
         """One launch for several views.  masks: one full-frame mask (every view gets it) or an array [n][full_height][full_width]."""
         m = np.ascontiguousarray(masks, dtype=np.uint8)
+        if os.environ.get("SL3D_LIB") and not hasattr(self.L, "sl3d_set_masks"):   # an older build under SL3D_LIB (A/B runs): view by view
+            n = (self.cfg.max_views - first_view if n_views is None else n_views) if m.ndim == 2 else m.shape[0]
+            for k in range(n):
+                self.set_mask(m if m.ndim == 2 else m[k], view=first_view + k)
+            return
         if m.ndim == 2:
             assert m.shape == (self.cfg.full_height, self.cfg.full_width), m.shape
             n, vs = (self.cfg.max_views - first_view if n_views is None else n_views), 0
@@ -367,6 +372,15 @@ class Scanner:
             off += n
         return res
 
+    def download_cloud_into(self, view, out):
+        """ONE call of sl3d_download_clouds for one view into `out` (flat float32 buffer; capacity = out.size // 3 points): the number
+        of valid points of the view (which may exceed the capacity: then the first `capacity` points were written).  With a pinned
+        buffer behind a run_clouds of a few views this is the route without a scan launch (the gap-closing kernel scans on entry)."""
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
+        counts = (C.c_int64 * 1)()
+        self._chk(self.L.sl3d_download_clouds(self._h, view, 1, out.ctypes.data, out.size // 3, counts), "sl3d_download_clouds")
+        return int(counts[0])
+
     def register_clouds(self, first_view, n_views, tx, ty, tz, rot_step):
         """register_views on the clouds of the last run_clouds (rotation applied while the segments are concatenated)."""
         n = C.c_int64(0)
@@ -402,6 +416,8 @@ class Scanner:
 
     def last_fused_kernel_name(self):
         """The k_fused instantiation the last fused launch of this context ran."""
+        if os.environ.get("SL3D_LIB") and not hasattr(self.L, "sl3d_last_fused_kernel_name"):
+            return "(a build without sl3d_last_fused_kernel_name)"
         buf = C.create_string_buffer(256)
         self._chk(self.L.sl3d_last_fused_kernel_name(self._h, buf, len(buf)), "sl3d_last_fused_kernel_name")
         return buf.value.decode()

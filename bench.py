@@ -244,6 +244,21 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
         for i in range(launches):
             run(i % V)
         ms = sc.timer_stop() / launches
+        to_host = None
+        if clouds:
+            # the consumer the reference has (8/save_point_cloud.cpp:85-104 fills a HOST cloud per scan): launch + the cloud in pinned
+            # host memory, wall clock per scan -- the fused kernel, then ONE gap-closing kernel that scans the segment counts on entry
+            # and stores over PCIe (which is what bounds it: 12 B per valid point)
+            pin = sc.pinned((W * H * 3,), np.float32)
+            ts, npts = [], 0
+            for i in range(24):
+                t0 = time.perf_counter()
+                run(i % V)
+                npts = sc.download_cloud_into(i % V, pin)
+                ts.append(time.perf_counter() - t0)
+            t = sorted(ts)[len(ts) // 2]
+            to_host = {"us_per_scan": round(t * 1e6, 1), "points": npts, "pcie_GBps": round(12.0 * npts / t / 1e9, 1),
+                       "how": "sl3d_run_clouds(1 view) + sl3d_download_clouds into pinned memory, wall clock, median of 24"}
         alg = 20 + 4 * N
         # what this launch really moves: the camera-side table (8 B/px for the radial model of the reference rig, 16 with tangential
         # terms) is read once per LAUNCH, and nothing amortises it when a launch is one view
@@ -252,7 +267,7 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
         return {"value": round(W * H / ms / 1e3, 1), "unit": "Mpixels/s", "launch_us": round(ms * 1e3, 2), "kernel": sc.fused_kernel_name(1, clouds=clouds),
                 "frac": round(alg * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": alg,
                 "frac_on_moved_bytes": round(moved * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "moved_bytes_per_pixel": moved,
-                "resident_views": V, "launches": launches,
+                "resident_views": V, "launches": launches, **({"to_host": to_host} if to_host else {}),
                 "note": f"1 view per launch, a different one of {V} resident views each launch (frames + results {V * (alg + 0) * W * H / 2**20:.0f} MiB "
                         f"> 256 MiB Infinity Cache): the frames come from HBM"}
 

@@ -195,3 +195,70 @@ def test_axis_without_gray_planes_on_the_last_resident_view(Nv, Nh):
         assert np.array_equal(clouds[v], batch[v][0][ovalid == 1]), v
         nvalid += int(ovalid.sum())
     assert nvalid > 100
+
+
+# ---- small launches leave the scan of the segment counts to the consumer ---------------------------------------------------------------
+@pytest.mark.parametrize("W,H", [(640, 203), (1021, 64), (96, 5)])
+def test_consumers_scan_on_entry_after_small_cloud_launches(W, H):
+    """sl3d_run_clouds over at most 4 views launches no k_seg_scan; whoever consumes the clouds gets offsets and totals on entry:
+    the one-view download into pinned memory (k_seg_close<.., SCAN>: scan + gap closing + count in one launch, also with a
+    destination smaller than the cloud), the contiguous device copy (sl3d_get_cloud_counts), the raw segments (the scan runs then),
+    the registration, and a large launch afterwards -- every cloud equals xyz[valid] of the dense launch, in scan order."""
+    S, syn = pkg("scanner"), pkg("synth")
+    PW, PH, N, fw, V = 512, 384, 8, 4, 6
+    rng = np.random.default_rng(W + H)
+    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=V) as sc:
+        sc.set_calibration(*cal)
+        masks = np.stack([_mask(rng, W, H, t) for t in range(V)])
+        masks[0] = syn.default_mask(W, H)
+        sc.set_masks(masks)
+        for v in range(V):
+            sc.synth_view(v, plane=(1.5 * v, 0.05, 0.04 - 0.01 * v), view_id=v, noise=2)
+        sc.run(0, V)
+        dense = [sc.points(v) for v in range(V)]
+        want = [xyz[val == 1] for xyz, val in dense]
+        pin = sc.pinned((W * H * 3,), np.float32)
+        for v in range(V):
+            sc.run_clouds(v, 1)
+            pin[:] = -7.0
+            n = sc.download_cloud_into(v, pin)                  # pinned, roomy: the scanning gap-closer
+            assert n == len(want[v]), v
+            assert np.array_equal(pin[:3 * n].reshape(n, 3), want[v]), v
+            assert (pin[3 * n:3 * n + 3] == -7.0).all()         # nothing past the cloud
+            if n > 10:                                          # a destination smaller than the cloud: its first points, the full count
+                sc.run_clouds(v, 1)
+                small = sc.pinned((3 * (n // 2),), np.float32)
+                small[:] = -7.0
+                assert sc.download_cloud_into(v, small) == n
+                assert np.array_equal(small.reshape(-1, 3), want[v][:n // 2]), v
+            sc.run_clouds(v, 1)
+            page = np.full(W * H * 3, -7.0, np.float32)         # pageable: counts first (the scan runs), then the copy
+            assert sc.download_cloud_into(v, page) == n and np.array_equal(page[:3 * n].reshape(n, 3), want[v])
+        # the contiguous device copy of a small launch (scan on entry of the gap-closer), then the raw segments of the same launch
+        sc.run_clouds(1, 3)
+        ptr, stride, counts = sc.cloud_counts(1, 3)
+        assert counts == [len(want[v]) for v in (1, 2, 3)]
+        for k, v in enumerate((1, 2, 3)):
+            a = np.empty((counts[k], 3), np.float32)
+            if counts[k]:
+                sc._d2h(a, ptr + 12 * k * stride)
+            assert np.array_equal(a, want[v]), v
+        seg, counts2 = sc.cloud_segments(1, 3)
+        assert counts2 == counts
+        offs = np.empty(seg.n_segments, np.uint64)
+        cnts = np.empty(seg.n_segments, np.uint32)
+        for k in range(3):
+            sc._d2h(offs, seg.offsets + 8 * k * seg.view_stride_segments)
+            sc._d2h(cnts, seg.counts + 4 * k * seg.view_stride_segments)
+            assert int(cnts.sum()) == counts[k] and np.array_equal(offs, np.concatenate([[0], np.cumsum(cnts.astype(np.uint64))[:-1]]).astype(np.uint64))
+        # registration straight from a small launch, against the dense route
+        sc.run_clouds(2, 2)
+        reg = sc.register_clouds(2, 2, 10.0, 0.0, 300.0, 7.5)
+        sc.run(2, 2)
+        ref = sc.register_views(2, 2, 10.0, 0.0, 300.0, 7.5)
+        assert np.array_equal(reg, ref)
+        # and a large launch afterwards scans by itself
+        got = sc.fused_clouds(0, V)
+        for v in range(V):
+            assert np.array_equal(got[v], want[v]), v

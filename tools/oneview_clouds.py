@@ -28,3 +28,14 @@ with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=R) as sc:
             run(i % R)
         ms = sc.timer_stop() / 3000
         print(f"one view per launch from HBM, {what}: {ms * 1e3:.2f} us per launch")
+    # the cloud where the reference's consumer wants it (a host cloud per scan): launch + download into pinned memory, wall clock
+    import time
+    import numpy as np
+    pin = sc.pinned((W * H * 3,), np.float32)
+    ts = []
+    for i in range(40):
+        t0 = time.perf_counter()
+        sc.run_clouds(i % R, 1)
+        n = sc.download_cloud_into(i % R, pin)
+        ts.append(time.perf_counter() - t0)
+    print(f"one view: sl3d_run_clouds + sl3d_download_clouds into pinned memory: {sorted(ts)[20] * 1e6:.1f} us per scan ({n} points)")
