@@ -262,6 +262,10 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
     for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_done) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_down) (void)hipEventDestroy(e);
+    if (x->s_warm) {
+        (void)hipStreamSynchronize(x->s_warm);
+        (void)hipStreamDestroy(x->s_warm);
+    }
     if (x->s_h2d) (void)hipStreamDestroy(x->s_h2d);
     if (x->s_d2h) (void)hipStreamDestroy(x->s_d2h);
     if (x->ev0) (void)hipEventDestroy(x->ev0);
@@ -889,6 +893,23 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     HIPCHK(x, hipEventElapsedTime(&t, x->ev0, x->ev1));
     if (ms) *ms = t;
     return SL3D_OK;
+}
+
+// Wake the GPU up ahead of a scan: `ms` milliseconds (at most 20) of trivial activity on a stream of its own, asynchronous -- the
+// call returns at once and nothing of the context waits for it.  See k_spin; bench.py side.one_scan_from_idle measures what it buys.
+extern "C" int sl3d_prewarm(sl3d_ctx *x, float ms)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    if (!(ms > 0.f)) return SL3D_OK;
+    ON_DEVICE(x);
+    if (!x->s_warm) {
+        HIPCHK(x, hipStreamCreateWithFlags(&x->s_warm, hipStreamNonBlocking));
+        hipDeviceProp_t prop;
+        HIPCHK(x, hipGetDeviceProperties(&prop, x->cfg.device));
+        x->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const unsigned long long ticks = (unsigned long long)((ms > 20.f ? 20.f : ms) * 1e5f);  // the constant clock runs at 100 MHz
+    return launched(x, launch_spin(x->n_cus, ticks, x->s_warm));
 }
 
 extern "C" int sl3d_timer_start(sl3d_ctx *x)

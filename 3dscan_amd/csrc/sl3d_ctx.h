@@ -52,6 +52,8 @@ struct sl3d_ctx {
     size_t und_bytes = 0;
     double und_key[16] = {0};  // K, dist, width, height of the map held in d_und (the 46 frames of a view share one map)
     bool und_map_valid = false;
+    hipStream_t s_warm = nullptr;                   // sl3d_prewarm: the spin kernel's own stream (created on first use)
+    int n_cus = 0;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // sl3d_process_views: upload and download run beside the compute stream
     std::vector<hipEvent_t> ev_up, ev_done, ev_down;  // per view slot: frames landed / kernel finished / results copied out
     float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)

@@ -169,6 +169,7 @@ int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t ds
 int launch_undistort_planes(const uint8_t *src, size_t spitch, size_t splane, uint8_t *dst, size_t dpitch, size_t dplane, int width, int height,
                             int n_planes, const double K[9], const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream);
 int launch_pattern(uint8_t *dst, size_t pitch, int PW, int PH, int axis, const uint8_t *profile, void *stream);
+int launch_spin(int blocks, unsigned long long ticks_100mhz, void *stream);  // sl3d_prewarm
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 
 }  // namespace sl3d

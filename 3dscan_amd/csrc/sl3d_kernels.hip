@@ -107,6 +107,29 @@ int launch_mask_prepare(const KParams &P, int first_view, int n_views, const Mas
     return (int)hipGetLastError();
 }
 
+// sl3d_prewarm: one wave per CU that does nothing but watch the constant-rate clock (100 MHz) until `ticks` have passed.  A GPU
+// that has idled for a second -- the reference's loop spends seconds projecting and capturing between two scans -- sits at its
+// lowest shader clock and takes milliseconds of activity to leave it; this is that activity, started while the scan's frames are
+// still on their way, on a stream of its own (it never sits in front of a context's own work).  Bounded: it ends by itself.
+__global__ __launch_bounds__(64) void k_spin(unsigned long long ticks, unsigned *sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned acc = 0;
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 64; i++) acc = acc * 1664525u + 1013904223u;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (acc == 0x12345u && sink) *sink = acc;  // (never true in practice: keeps the arithmetic alive)
+}
+
+int launch_spin(int blocks, unsigned long long ticks, void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_spin, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, ticks, (unsigned *)nullptr);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // staged kernels: one pixel per lane, stage boundaries as in the reference
 // ------------------------------------------------------------------------------------------------

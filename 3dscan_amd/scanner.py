@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
     "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_masks", "sl3d_set_mask_colrow", "sl3d_set_frames_range", "sl3d_get_global_colrow", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
-    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_last_fused_kernel_name", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
+    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_last_fused_kernel_name", "sl3d_prewarm", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
     "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
@@ -89,6 +89,7 @@ def load_library(path=None):
     try:
         L.sl3d_set_masks.argtypes = [vp, i, i, vp, C.c_size_t, C.c_size_t]
         L.sl3d_last_fused_kernel_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.sl3d_prewarm.argtypes = [vp, C.c_float]
     except AttributeError:   # an older build of the library under SL3D_LIB (A/B runs against a previous round)
         if not os.environ.get("SL3D_LIB"):
             raise
@@ -421,6 +422,9 @@ class Scanner:
         buf = C.create_string_buffer(256)
         self._chk(self.L.sl3d_last_fused_kernel_name(self._h, buf, len(buf)), "sl3d_last_fused_kernel_name")
         return buf.value.decode()
+
+    def prewarm(self, ms):
+        self._chk(self.L.sl3d_prewarm(self._h, ms), "sl3d_prewarm")
 
     def run_timed(self, first_view=0, n_views=1):
         ms = C.c_float(0)

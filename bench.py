@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--one-view-cold-only", action="store_true",
                     help="run only side.one_view_cold (one view per launch, a different resident view each launch: frames from HBM, not from "
                          "the Infinity Cache) and print it -- the command tools/profile.sh puts under rocprofv3 for that figure")
+    ap.add_argument("--idle-samples", type=int, default=20, help="samples per variant of side.one_scan_from_idle (0 = skip it; each sample sleeps --idle-sleep s)")
+    ap.add_argument("--idle-sleep", type=float, default=1.0, help="idle time in front of every sample of side.one_scan_from_idle, seconds")
+    ap.add_argument("--idle-only", action="store_true", help="run only side.one_scan_from_idle and print it")
     ap.add_argument("--cold-views", type=int, default=8, help="resident views the one-view-cold figure rotates over (8 x 97.5 MB of frames > 256 MiB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--devices", default="", help="comma-separated HIP device per rank (default: LOCAL_RANK). Repeating a device "
@@ -332,6 +335,68 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
                         "bytes over the time of BOTH kernels"}
 
 
+def one_scan_from_idle(args, scm, syn, np, dev_index):
+    """The reference's real duty cycle (m_tech_project_console.cpp:331-401): between two scans the loop projects and captures ~46
+    frames -- seconds in which the GPU falls back to its idle clocks.  Every sample: sleep `--idle-sleep` seconds, then ONE scan, timed
+    on the device (HIP events on the context's stream) and on the host (call to completion):
+      resident     : a new pinned mask (sl3d_set_mask) + one one-view launch on frames that are already in HBM
+      with_upload  : the Level-2 call as a caller of sl3d.h makes it -- the view's 46 frames from pinned memory (2 x sl3d_set_frames),
+                     the mask, the launch
+      ..._prewarm  : the same with sl3d_prewarm(3 ms) in front: the clocks rise under the upload
+    median and p90 over `--idle-samples` samples each; `steady` = the same calls back to back (no sleep)."""
+    W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
+    n, nap = max(3, args.idle_samples), args.idle_sleep
+    out = {"sleep_s": nap, "samples": n}
+    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=2, device=dev_index) as sc:
+        sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
+        mask = sc.pinned((H, W), np.uint8)
+        mask[:] = syn.default_mask(W, H)
+        for v in range(2):
+            sc.set_mask(mask, view=v)
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05), view_id=v, noise=args.noise)
+        sc.synchronize()
+        fv, fh = sc.frames(0, 0), sc.frames(1, 0)
+        pv, ph = sc.pinned((len(fv), H, W), np.uint8), sc.pinned((len(fh), H, W), np.uint8)
+        pv[:], ph[:] = np.stack(fv), np.stack(fh)
+        lv, lh = list(pv), list(ph)
+
+        def scan(upload, clouds, warm):
+            t0 = time.perf_counter()
+            if warm:
+                sc.prewarm(3.0)
+            sc.timer_start()
+            if upload:
+                sc.set_frames(0, lv, view=0)
+                sc.set_frames(1, lh, view=0)
+            sc.set_mask(mask, view=0)
+            (sc.run_clouds if clouds else sc.run)(0, 1)
+            dev_ms = sc.timer_stop()
+            return dev_ms * 1e3, (time.perf_counter() - t0) * 1e6
+
+        def series(upload, clouds, warm, pause):
+            dev, host = [], []
+            for _ in range(n):
+                if pause:
+                    sc.synchronize()
+                    time.sleep(pause)
+                d, h = scan(upload, clouds, warm)
+                dev.append(d)
+                host.append(h)
+            dev.sort(); host.sort()
+            return {"device_us": {"median": round(dev[n // 2], 1), "p90": round(dev[(9 * n) // 10], 1)},
+                    "host_us": {"median": round(host[n // 2], 1), "p90": round(host[(9 * n) // 10], 1)}}
+
+        for key, (upload, clouds, warm) in (("resident", (False, False, False)), ("resident_clouds", (False, True, False)),
+                                            ("with_upload", (True, False, False)), ("with_upload_prewarm", (True, False, True)),
+                                            ("with_upload_clouds_prewarm", (True, True, True))):
+            for _ in range(3):
+                scan(upload, clouds, False)
+            out[key] = {"steady": series(upload, clouds, False, 0.0), "from_idle": series(upload, clouds, warm, nap)}
+            s, i = out[key]["steady"]["device_us"]["median"], out[key]["from_idle"]["device_us"]["median"]
+            out[key]["idle_penalty"] = round(i / s, 2) if s > 0 else None
+    return out
+
+
 def side_figures(args, scm, syn, np, dev_index):
     """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
@@ -358,6 +423,8 @@ def side_figures(args, scm, syn, np, dev_index):
         out["one_view_cold"] = one_view_cold(args, scm, syn, np, dev_index)
         out["one_view_cold_clouds"] = one_view_cold(args, scm, syn, np, dev_index, launches=1000, clouds=True)
         import torch
+        if args.idle_samples > 0:
+            out["one_scan_from_idle"] = one_scan_from_idle(args, scm, syn, np, dev_index)
         out["per_scan_device"] = per_scan_device(args, scm, syn, np, torch, dev_index)
         out["per_scan_device_clouds"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, clouds=True)
         # (distorted: projector k1,k2,p1,p2 + camera tangential terms; general: a skewed camera matrix as well -- since round 3 both
@@ -467,6 +534,9 @@ def main():
     row0, rows = dmod.shard_rows(H, world, rank)
     n_views = V * world  # batch grows with the GPU count; each GPU holds `rows` rows of every view
 
+    if args.idle_only:
+        emit(json.dumps({"one_scan_from_idle": one_scan_from_idle(args, scm, syn, np, dev_index)}))
+        return
     if args.one_view_cold_only:
         emit(json.dumps({"one_view_cold": one_view_cold(args, scm, syn, np, dev_index, launches=max(args.steps, 200))}))
         return

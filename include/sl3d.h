@@ -259,6 +259,12 @@ int sl3d_fused_kernel_name(sl3d_ctx *ctx, int n_views, int clouds, char *buf, si
  * choice is recorded when the launch is made -- it depends on what was known about the views' masks at that moment (a small
  * launch over sparsely selected views takes another kernel), so a later prediction could name a different one. */
 int sl3d_last_fused_kernel_name(sl3d_ctx *ctx, char *buf, size_t capacity);
+/* Wake the GPU up ahead of a scan.  The reference's loop projects and captures ~46 frames between two scans
+ * (m_tech_project_console.cpp:331-401): seconds in which the GPU drops to its idle clocks, and the first launches after that run
+ * several times slower than the steady-state figures.  sl3d_prewarm starts `ms` milliseconds (at most 20) of trivial activity on a
+ * stream of its own and returns at once; called when a scan's frames start to arrive (the upload of 46 frames takes ~2 ms), the
+ * clocks are up by the time the fused kernel is launched.  Nothing of the context waits for it. */
+int sl3d_prewarm(sl3d_ctx *ctx, float ms);
 /* sl3d_run bracketed by HIP events on the context's stream; returns the kernel time of this launch */
 int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);
 int sl3d_synchronize(sl3d_ctx *ctx);
