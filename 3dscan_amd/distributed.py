@@ -176,6 +176,32 @@ def assemble_rotating(stripe, views_per_rank):
     return torch.cat([out[r, :, :rows[r]] for r in range(world)], dim=1)
 
 
+def assemble_rotating_interleaved(stripe, rows_by_rank=None):
+    """stripe: [n, rows, ...] with n a multiple of the world size -- a CHUNK of consecutive views.  View i of the chunk is assembled on
+    rank i % world (so every chunk keeps every link busy, and a pipeline can exchange chunk k while chunk k + 1 computes).
+    Returns this rank's [n // world, sum(rows), ...] assembled views: chunk views rank, rank + world, ...  One all_to_all_single.
+    rows_by_rank: every rank's stripe height, if the caller knows it (no collective, no host wait to find out)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    n = stripe.shape[0]
+    assert n % world == 0, (n, world)
+    m = n // world
+    if rows_by_rank is None:
+        stripe, rows = _equalise_rows(stripe)       # (one small all_gather and a host wait: a pipeline passes the row counts instead)
+    else:
+        rows, mx = list(rows_by_rank), max(rows_by_rank)
+        if stripe.shape[1] < mx:
+            pad = list(stripe.shape)
+            pad[1] = mx - stripe.shape[1]
+            stripe = torch.cat([stripe, stripe.new_zeros(pad)], dim=1)
+    mx = stripe.shape[1]
+    send = stripe.view(m, world, mx, *stripe.shape[2:]).transpose(0, 1).contiguous()   # [dst, j, rows, ...] = view j * world + dst
+    out = torch.empty_like(send)                                                       # [src, j, rows, ...]
+    dist.all_to_all_single(out, send)
+    return torch.cat([out[r, :, :rows[r]] for r in range(world)], dim=1)
+
+
 class RootAssembler:
     """Pipelined gather of row stripes to one root, chunk of views by chunk of views.
 

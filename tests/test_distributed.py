@@ -55,6 +55,12 @@ def _worker(rank, world, port, q):
             assert root is None
         mine = d.assemble_rotating(stripe, V)          # views [rank*V, (rank+1)*V) assembled here
         assert torch.equal(mine, full[rank * V:(rank + 1) * V])
+        # the chunked form bench.py pipelines: view i of a chunk is assembled on rank i % world
+        chunk = stripe[:2 * world]
+        mine = d.assemble_rotating_interleaved(chunk)
+        assert torch.equal(mine, full[:2 * world][rank::world])
+        mine = d.assemble_rotating_interleaved(chunk, [d.shard_rows(H, world, r)[1] for r in range(world)])
+        assert torch.equal(mine, full[:2 * world][rank::world])
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
