@@ -387,8 +387,7 @@ def one_scan_from_idle(args, scm, syn, np, dev_index):
                     "host_us": {"median": round(host[n // 2], 1), "p90": round(host[(9 * n) // 10], 1)}}
 
         for key, (upload, clouds, warm) in (("resident", (False, False, False)), ("resident_clouds", (False, True, False)),
-                                            ("with_upload", (True, False, False)), ("with_upload_prewarm", (True, False, True)),
-                                            ("with_upload_clouds_prewarm", (True, True, True))):
+                                            ("with_upload", (True, False, False)), ("with_upload_prewarm", (True, False, True))):
             for _ in range(3):
                 scan(upload, clouds, False)
             out[key] = {"steady": series(upload, clouds, False, 0.0), "from_idle": series(upload, clouds, warm, nap)}
