@@ -306,12 +306,14 @@ __device__ __forceinline__ double radial_factor_m1(double r0sq, const IntrT &I)
 }
 
 // s(r0^2) from a radial table (RadEntry, here in LDS): the node nearest to r0^2 * scale, one 16-byte read, one float FMA + multiply,
-// one double add
+// one double add.  The node coordinate t and the distance w to the node are formed in fp64 (r0^2 is a double anyway): in fp32, t up
+// to 255 carries 1.5e-5 node spacings of rounding error into w, i.e. ~1e-9 |k1| into s -- several times the interpolation remainder
+// the table was sized for; in fp64 only that remainder (~1e-10) is left.
 __device__ __forceinline__ double radial_lookup(const RadEntry *tab, float scale, double r0sq)
 {
-    const float t = (float)r0sq * scale;
-    const int i = min(__float2int_rn(t), SL3D_RAD_NODES - 1);  // (a rejected pixel's harmless index 0 and anything past the table end: clamped)
-    const float w = t - (float)i;
+    const double t = r0sq * (double)scale;
+    const int i = min(__double2int_rn(t), SL3D_RAD_NODES - 1);  // (a rejected pixel's harmless index 0 and anything past the table end: clamped)
+    const float w = (float)(t - (double)i);
     const RadEntry e = tab[i];
     return e.c0 + (double)(fmaf(e.c2, w, e.c1) * w);
 }

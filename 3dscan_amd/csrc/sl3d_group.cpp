@@ -41,14 +41,16 @@ struct RcclApi {
     bool ok = false;
 };
 
-RcclApi &rccl()
+// allow_override: the caller created its group with SL3D_FLAG_GROUP_DISTINCT_SIDES (the flag of the one-GPU tests).  Only then is
+// SL3D_RCCL_LIB honoured -- another library with the same seven entry points (a test double that pairs sends with receives itself, so
+// that the N-rank exchange runs on one GPU); a production group never loads a library an environment variable names.  The first
+// caller of the process decides.
+RcclApi &rccl(bool allow_override = false)
 {
     static RcclApi R;
     static std::once_flag once;
-    std::call_once(once, [] {
-        // SL3D_RCCL_LIB: another library with the same seven entry points (tests bind a test double that pairs sends with
-        // receives itself, so that the N-rank exchange runs on one GPU); never set in production
-        const char *override_lib = getenv("SL3D_RCCL_LIB");
+    std::call_once(once, [allow_override] {
+        const char *override_lib = allow_override ? getenv("SL3D_RCCL_LIB") : nullptr;
         if (override_lib && *override_lib) {
             R.lib = dlopen(override_lib, RTLD_NOW | RTLD_LOCAL);
             if (!R.lib) {
@@ -228,7 +230,7 @@ extern "C" int sl3d_group_create(const sl3d_config *cfg, const int *devices, int
     // transport: RCCL as soon as a stripe lives on another GPU than the root (or when asked for), unless it cannot be loaded
     const bool wants_rccl = ((g->gpus.size() > 1) || g->force_rccl) && !(cfg->flags & SL3D_FLAG_GROUP_NO_RCCL);
     if (wants_rccl) {
-        RcclApi &R = rccl();
+        RcclApi &R = rccl((cfg->flags & SL3D_FLAG_GROUP_DISTINCT_SIDES) != 0);
         if (!R.ok) {
             if (g->force_rccl) return bail(SL3D_E_UNSUPPORTED, "RCCL requested but unavailable: " + R.err);
         } else {
