@@ -1,12 +1,13 @@
 // sl3d_maskbits.h -- H0 / S3b / S3d as bit-plane arithmetic: the selection mask -> the valid map after stage 3's boundary
-// removal (3/wrapped_phase.cpp:106-115, then :253-279 / :306-318), 4 pixels per lane, R rows per lane, no per-pixel loads.
+// removal (3/wrapped_phase.cpp:106-115, then :253-279 / :306-318), 16 pixels x R rows per lane, no per-pixel loads.
 //
 // Shared by k_mask_prepare (sl3d_kernels.hip) and by the CPU emulation the test suite compares with the literal scan of the reference's loop
 // (tests/native/mask_bits_emul.c): plain C, no HIP types.
 //
-// The closed form (sl3d_device.h, MaskView) written per ROW of 12 neighbouring pixels held as 12 bits of one register -- bit i of
-// a row word is the pixel at plane byte 4*x - 4 + i, i.e. the lane's own dword is bits 4..7 and its left / right neighbour
-// dwords are bits 0..3 / 8..11 (everything the 4 results depend on lies within 2 columns):
+// The closed form (sl3d_device.h, MaskView) written per ROW of OWN + 8 neighbouring pixels held as bits of one register -- bit i of
+// a row word is the pixel at plane byte (first own byte) - 4 + i, i.e. the lane's OWN pixels (16: one 16-byte load; the emulation also
+// runs 4) are bits 4 .. 4 + OWN - 1 and the dword to their left / right is bits 0..3 / OWN + 4 .. OWN + 7 (everything a result
+// depends on lies within 2 columns):
 //   V      selected (byte == 1), 0 outside the staged region (which never leaves the frame)
 //   nV3    = nV | nV<<1 | nV>>1          some pixel of the 3 columns around is unselected            (nV = ~V)
 //   L(r)   = nV(r)>>1 | nV3(r+1)         E, SW, S or SE neighbour unselected: those are scanned LATER than the pixel
@@ -25,12 +26,12 @@
 #define SL3D_MB_FN static inline
 #endif
 
-// bits i of a 12-bit row word whose coordinate base + i lies in [lo, hi)
-SL3D_MB_FN unsigned mb_range_bits(int lo, int hi, int base)
+// bits i of an nbits-bit row word (nbits <= 24) whose coordinate base + i lies in [lo, hi)
+SL3D_MB_FN unsigned mb_range_bits(int lo, int hi, int base, int nbits)
 {
     int a = lo - base, b = hi - base;
-    a = a < 0 ? 0 : (a > 12 ? 12 : a);
-    b = b < 0 ? 0 : (b > 12 ? 12 : b);
+    a = a < 0 ? 0 : (a > nbits ? nbits : a);
+    b = b < 0 ? 0 : (b > nbits ? nbits : b);
     return b > a ? ((1u << b) - (1u << a)) : 0u;
 }
 
@@ -52,14 +53,14 @@ typedef struct MbCols {
     unsigned INTC;  // interior columns: 1 <= gx <= fullW - 2
 } MbCols;
 
-SL3D_MB_FN MbCols mb_cols(int x /* dword of the plane row */, int col0, int lpad, int fullW, int bx0, int bx1)
+SL3D_MB_FN MbCols mb_cols(int own_byte0 /* plane byte of the lane's first own pixel */, int own, int col0, int lpad, int fullW, int bx0, int bx1)
 {
     MbCols c;
-    const int b0 = 4 * x - 4;            // plane byte of bit 0
+    const int b0 = own_byte0 - 4;        // plane byte of bit 0
     const int gx0 = col0 - lpad + b0;    // its frame column
-    c.REG = mb_range_bits(bx0, bx1, b0);
-    c.INF = mb_range_bits(0, fullW, gx0);
-    c.INTC = mb_range_bits(1, fullW - 1, gx0);
+    c.REG = mb_range_bits(bx0, bx1, b0, own + 8);
+    c.INF = mb_range_bits(0, fullW, gx0, own + 8);
+    c.INTC = mb_range_bits(1, fullW - 1, gx0, own + 8);
     return c;
 }
 
@@ -85,7 +86,7 @@ SL3D_MB_FN MbRow mb_row(unsigned V, const MbCols c, int gy, int fullH)
 
 SL3D_MB_FN unsigned mb_L(const MbRow r, const MbRow below) { return (r.nV >> 1) | below.nV3; }
 SL3D_MB_FN unsigned mb_OK(const MbRow r, unsigned L, const MbRow above) { return r.V | (r.INT & (L | above.bu3 | (r.bu << 1))); }
-// valid bits of row y (bits 4..7 are the lane's own pixels) from OK of the row above and of the row itself
+// valid bits of row y (bits 4 .. 4 + OWN - 1 are the lane's own pixels) from OK of the row above and of the row itself
 SL3D_MB_FN unsigned mb_valid(const MbRow r, unsigned L, unsigned OK_above, unsigned OK_row)
 {
     const unsigned ok3 = OK_above & (OK_above << 1) & (OK_above >> 1);

@@ -11,14 +11,15 @@
 #define HALO 2
 #define LPAD 16
 
-/* mask: full-frame bytes (fullW x fullH, row stride `stride`).  Window (col0,row0,W,H).  R rows per lane.
- * Outputs: norm plane [(H+4)][mpitch] (mpitch = pitch + 32, pitch = W rounded up to 16), band [H][pitch]; returns the quads
- * with a valid pixel. */
-long emul_mask_prepare(const uint8_t *mask, size_t stride, int fullW, int fullH, int col0, int row0, int W, int H, int R, uint8_t *norm, uint8_t *band)
+/* mask: full-frame bytes (fullW x fullH, row stride `stride`).  Window (col0,row0,W,H).  R rows per lane, OWN (4 or 16) pixels per lane
+ * and row -- the kernel runs 16.  Outputs: norm plane [(H+4)][mpitch] (mpitch = pitch + 32, pitch = W rounded up to 16), band [H][pitch];
+ * returns the quads with a valid pixel. */
+long emul_mask_prepare(const uint8_t *mask, size_t stride, int fullW, int fullH, int col0, int row0, int W, int H, int R, int OWN, uint8_t *norm,
+                       uint8_t *band)
 {
-    const int pitch = (W + 15) & ~15, mpitch = pitch + 2 * LPAD, rows = H + 2 * HALO, dwpr = mpitch >> 2;
+    const int pitch = (W + 15) & ~15, mpitch = pitch + 2 * LPAD, rows = H + 2 * HALO, cpr = mpitch / OWN, nd = OWN / 4;
     /* the staging plane: zero outside the copied region, exactly what sl3d_set_masks builds */
-    uint8_t *raw = (uint8_t *)calloc((size_t)mpitch * rows + 8, 1);
+    uint8_t *raw = (uint8_t *)calloc((size_t)mpitch * rows + 32, 1);
     const int gy0 = row0 - HALO < 0 ? 0 : row0 - HALO, gy1 = row0 + H + HALO > fullH ? fullH : row0 + H + HALO;
     const int gx0 = col0 - HALO < 0 ? 0 : col0 - HALO, gx1 = col0 + W + HALO > fullW ? fullW : col0 + W + HALO;
     const int bx0 = LPAD + gx0 - col0, bx1 = LPAD + gx1 - col0, r0 = gy0 - row0 + HALO, r1 = gy1 - row0 + HALO;
@@ -26,41 +27,48 @@ long emul_mask_prepare(const uint8_t *mask, size_t stride, int fullW, int fullH,
     long quads = 0;
     const int strips = (rows + R - 1) / R;
     MbRow *row = (MbRow *)malloc(sizeof(MbRow) * (R + 3));
-    unsigned *own = (unsigned *)malloc(sizeof(unsigned) * (R + 3)), *L = (unsigned *)malloc(sizeof(unsigned) * (R + 3)),
+    unsigned *own = (unsigned *)malloc(sizeof(unsigned) * (R + 3) * 4), *L = (unsigned *)malloc(sizeof(unsigned) * (R + 3)),
              *OK = (unsigned *)malloc(sizeof(unsigned) * (R + 3));
+    const unsigned own_mask = OWN == 16 ? 0xffffu : 0xfu;
     for (int strip = 0; strip < strips; strip++)
-        for (int x = 0; x < dwpr; x++) {
+        for (int x = 0; x < cpr; x++) {
             const int pr0 = strip * R;
-            const MbCols c = mb_cols(x, col0, LPAD, fullW, bx0, bx1);
-            const unsigned own_bytes = mb_expand_nibble(c.REG >> 4) * 0xffu;
-            const unsigned outw = (mb_range_bits(LPAD, LPAD + W, 4 * x - 4) >> 4) & 0xfu;
+            const MbCols c = mb_cols(OWN * x, OWN, col0, LPAD, fullW, bx0, bx1);
+            const unsigned reg_own = (c.REG >> 4) & own_mask;
+            const unsigned outw = (mb_range_bits(LPAD, LPAD + W, OWN * x - 4, OWN + 8) >> 4) & own_mask;
             for (int a = 0; a < R + 3; a++) {
                 const int pr = pr0 + a - 2;
-                unsigned dl = 0, dc = 0, dr = 0;
+                unsigned dl = 0, dr = 0, d[4] = {0, 0, 0, 0};
                 if (pr >= r0 && pr < r1) {
-                    const uint8_t *p = raw + (size_t)pr * mpitch + 4 * x;
-                    if (c.REG & 0x00fu) memcpy(&dl, p - 4, 4);
-                    if (c.REG & 0x0f0u) memcpy(&dc, p, 4);
-                    if (c.REG & 0xf00u) memcpy(&dr, p + 4, 4);
+                    const uint8_t *p = raw + (size_t)pr * mpitch + OWN * x;
+                    for (int k = 0; k < nd; k++)
+                        if (reg_own & (0xfu << (4 * k))) memcpy(&d[k], p + 4 * k, 4);
+                    if (c.REG & 0xfu) memcpy(&dl, p - 4, 4);
+                    if (c.REG & (0xfu << (OWN + 4))) memcpy(&dr, p + OWN, 4);
                 }
-                const unsigned bc = mb_eq1_bytes(dc);
-                const unsigned V = (mb_pack_nibble(mb_eq1_bytes(dl)) | (mb_pack_nibble(bc) << 4) | (mb_pack_nibble(mb_eq1_bytes(dr)) << 8)) & c.REG;
-                row[a] = mb_row(V, c, row0 + pr - HALO, fullH);
-                own[a] = bc & own_bytes;
+                unsigned V = mb_pack_nibble(mb_eq1_bytes(dl)) | (mb_pack_nibble(mb_eq1_bytes(dr)) << (OWN + 4));
+                for (int k = 0; k < nd; k++) {
+                    const unsigned bk = mb_eq1_bytes(d[k]);
+                    V |= mb_pack_nibble(bk) << (4 + 4 * k);
+                    own[4 * a + k] = bk & (mb_expand_nibble(reg_own >> (4 * k)) * 0xffu);
+                }
+                row[a] = mb_row(V & c.REG, c, row0 + pr - HALO, fullH);
             }
             for (int a = 1; a < R + 2; a++) {
                 L[a] = mb_L(row[a], row[a + 1]);
                 OK[a] = mb_OK(row[a], L[a], row[a - 1]);
             }
-            const int xb = x - (LPAD >> 2);
+            const int xb = x - LPAD / OWN;
             for (int a = 2; a < R + 2; a++) {
                 const int pr = pr0 + a - 2, wr = pr - HALO;
-                if (pr < rows) memcpy(norm + (size_t)pr * mpitch + (size_t)x * 4, &own[a], 4);
-                if (xb >= 0 && xb < (pitch >> 2) && wr >= 0 && wr < H) {
+                if (pr < rows) memcpy(norm + (size_t)pr * mpitch + (size_t)x * OWN, &own[4 * a], (size_t)OWN);
+                if (xb >= 0 && xb < pitch / OWN && wr >= 0 && wr < H) {
                     const unsigned v = (mb_valid(row[a], L[a], OK[a - 1], OK[a]) >> 4) & outw;
-                    const unsigned b = mb_expand_nibble(v);
-                    memcpy(band + (size_t)wr * pitch + (size_t)xb * 4, &b, 4);
-                    quads += v != 0;
+                    for (int k = 0; k < nd; k++) {
+                        const unsigned b = mb_expand_nibble(v >> (4 * k));
+                        memcpy(band + (size_t)wr * pitch + (size_t)xb * OWN + 4 * k, &b, 4);
+                        quads += ((v >> (4 * k)) & 0xfu) != 0;
+                    }
                 }
             }
         }
@@ -87,9 +95,12 @@ int emul_check_byte_helpers(void)
         for (int lo = -20; lo < 20; lo++)
             for (int hi = -20; hi < 24; hi++) {
                 unsigned e = 0;
-                for (int i = 0; i < 12; i++)
-                    if (base + i >= lo && base + i < hi) e |= 1u << i;
-                if (mb_range_bits(lo, hi, base) != e) return 4;
+                for (int nbits = 12; nbits <= 24; nbits += 12) {
+                    e = 0;
+                    for (int i = 0; i < nbits; i++)
+                        if (base + i >= lo && base + i < hi) e |= 1u << i;
+                    if (mb_range_bits(lo, hi, base, nbits) != e) return 4;
+                }
             }
     return 0;
 }

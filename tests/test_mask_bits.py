@@ -20,17 +20,17 @@ def emul(tmp_path_factory):
                            os.path.join(ROOT, "tests", "native", "mask_bits_emul.c"), "-o", out])
     L = C.CDLL(out)
     L.emul_mask_prepare.restype = C.c_long
-    L.emul_mask_prepare.argtypes = [C.c_void_p, C.c_size_t] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
+    L.emul_mask_prepare.argtypes = [C.c_void_p, C.c_size_t] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
     return L
 
 
-def run_emul(L, mask, win, R):
+def run_emul(L, mask, win, R, own=16):
     FH, FW = mask.shape
     x0, y0, w, h = win
     pitch = (w + 15) & ~15
     norm = np.full((h + 4, pitch + 32), 0xEE, np.uint8)
     band = np.full((h, pitch), 0xEE, np.uint8)
-    q = L.emul_mask_prepare(mask.ctypes.data, mask.strides[0], FW, FH, x0, y0, w, h, R, norm.ctypes.data, band.ctypes.data)
+    q = L.emul_mask_prepare(mask.ctypes.data, mask.strides[0], FW, FH, x0, y0, w, h, R, own, norm.ctypes.data, band.ctypes.data)
     return norm, band, q
 
 
@@ -62,9 +62,9 @@ def test_byte_helpers_exhaustive(emul):
     assert emul.emul_check_byte_helpers() == 0
 
 
-@pytest.mark.parametrize("R", [1, 4, 8])
-def test_bit_plane_boundary_removal_equals_literal_scan(emul, R):
-    rng = np.random.default_rng(100 + R)
+@pytest.mark.parametrize("R,own", [(1, 16), (4, 16), (8, 16), (4, 4), (3, 4)])
+def test_bit_plane_boundary_removal_equals_literal_scan(emul, R, own):
+    rng = np.random.default_rng(100 + R + own)
     for trial in range(40):
         FW, FH = int(rng.integers(3, 90)), int(rng.integers(3, 70))
         mask = random_mask(rng, FW, FH, trial)
@@ -75,7 +75,7 @@ def test_bit_plane_boundary_removal_equals_literal_scan(emul, R):
             wins.append((int(rng.integers(0, FW - w + 1)), int(rng.integers(0, FH - h + 1)), w, h))
         for win in wins:
             x0, y0, w, h = win
-            norm, band, q = run_emul(emul, mask, win, R)
+            norm, band, q = run_emul(emul, mask, win, R, own)
             assert np.array_equal(band[:, :w], ref[y0:y0 + h, x0:x0 + w]), (trial, win)
             assert not band[:, w:].any(), (trial, win)  # the pitch padding stays 0
             # the 0/1 plane: selected bytes of window + halo inside the frame, 0 elsewhere
@@ -94,5 +94,5 @@ def test_degenerate_frames(emul):
         for trial in range(6):
             mask = random_mask(rng, FW, FH, trial)
             ref = oracle_valid(mask) if FW >= 3 and FH >= 3 else (mask == 1).astype(np.uint8)
-            norm, band, q = run_emul(emul, mask, (0, 0, FW, FH), 4)
+            norm, band, q = run_emul(emul, mask, (0, 0, FW, FH), 4, 16 if trial % 2 else 4)
             assert np.array_equal(band[:, :FW], ref), (FW, FH, trial)
