@@ -20,63 +20,75 @@ namespace sl3d {
 // sl3d_set_mask(s) on the device (H0 / S3b / S3d).  The source is either the staging plane the host copy filled or the caller's
 // own device-resident mask (MaskSrc: address of plane row 0 / byte 0, row stride, and the part of the plane that holds source
 // bytes -- window + 2-pixel halo clipped to the frame; everything else counts as unselected and is never loaded).
-// One lane = 16 pixels of a plane row x R rows: per row ONE 16-byte load (+ the dword to its left and to its right), `byte == 1`
-// of those 24 bytes becomes 24 bits of one register, and the closed form of the boundary removal (3/wrapped_phase.cpp:253-279) is
-// evaluated on those bits (sl3d_maskbits.h) -- no per-pixel loads, no per-pixel branches, 16-byte stores.  It writes the 0/1 plane
-// (what the per-stage kernel k_wrap reads) and the `band` plane (final valid bytes of every window pixel: what the fused kernel
-// reads), and counts the quads that hold a valid pixel.  One wave per block (a 1080p mask is ~520 waves: every CU gets some), and
-// ONE 8-byte store per wave {seq, count} into host memory mapped into the device -- no device atomics, no memset, no copy behind
-// the kernel; the host adds the words up when it needs the number (sparse_views, sl3d_capi.cpp) and knows by the sequence number
-// whether every wave of THIS preparation has landed.
-template <int R>
-__global__ __launch_bounds__(64) void k_mask_prepare(const KParams P, int first_view, const MaskSrc S, unsigned long long *__restrict__ partials,
-                                                     unsigned seq)
+// One lane = OWN pixels of a plane row x R rows: per row ONE load of OWN bytes (+ the dword to its left and to its right), `byte == 1`
+// of those OWN + 8 bytes becomes OWN + 8 bits of one register, and the closed form of the boundary removal (3/wrapped_phase.cpp:
+// 253-279) is evaluated on those bits (sl3d_maskbits.h) -- no per-pixel loads, no per-pixel branches.  It writes the 0/1 plane (what
+// the per-stage kernel k_wrap reads) and the `band` plane (final valid bytes of every window pixel: what the fused kernel reads),
+// and counts the quads that hold a valid pixel: ONE 8-byte store per block {seq, count} into host memory mapped into the device --
+// no device atomics, no memset, no copy behind the kernel; the host adds the words up when it needs the number (sparse_views,
+// sl3d_capi.cpp) and knows by the sequence number whether every block of THIS preparation has landed.
+// Two shapes (launch_mask_prepare; both measured per view with rocprofv3, profiles/r05_mask_variants.txt):
+//   OWN = 4,  256-thread blocks: many short waves -- the latency of a ~2-Mpx mask (1080p: 5.7 us against 6.5)
+//   OWN = 16, one wave per block: 16-byte loads and stores, a third of the arithmetic per pixel -- larger masks (12 Mpx: 13.0 us
+//             against 16.4) and several views per launch
+template <int R, int OWN, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_mask_prepare(const KParams P, int first_view, const MaskSrc S, unsigned long long *__restrict__ partials,
+                                                        unsigned seq)
 {
+    static_assert(OWN == 4 || OWN == 16, "one dword or one 16-byte quad per lane and row");
+    constexpr int ND = OWN / 4;
+    constexpr unsigned OWN_MASK = (1u << OWN) - 1u;
     typedef unsigned u32x4a __attribute__((ext_vector_type(4), aligned(4)));  // (a caller's device mask is only 4-byte aligned)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ unsigned s_quads;
+    if (BLOCK > 64) {
+        if (threadIdx.x == 0) s_quads = 0u;
+        __syncthreads();
+    }
     const int view = first_view + (int)blockIdx.y;
-    const int qpr = P.mpitch >> 4, rows = P.H + 2 * SL3D_MASK_HALO;  // 16-byte columns of a plane row
-    const unsigned t = blockIdx.x * 64u + threadIdx.x;
-    const int strip = (int)(t / (unsigned)qpr), xq = (int)(t - (unsigned)strip * (unsigned)qpr);
+    const int cpr = P.mpitch / OWN, rows = P.H + 2 * SL3D_MASK_HALO;  // OWN-byte columns of a plane row
+    const unsigned t = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
+    const int strip = (int)(t / (unsigned)cpr), xc = (int)(t - (unsigned)strip * (unsigned)cpr);
     const int pr0 = strip * R;  // first plane row of the lane
     unsigned wave_quads = 0u;
     if (pr0 < rows) {
-        const MbCols c = mb_cols(16 * xq, 16, P.col0, SL3D_MASK_LPAD, P.fullW, S.bx0, S.bx1);
-        const unsigned reg_own = (c.REG >> 4) & 0xffffu;
-        const bool whole = reg_own == 0xffffu;  // all 16 own bytes hold source pixels: one 16-byte load
-        unsigned own_bytes[4];
+        const MbCols c = mb_cols(OWN * xc, OWN, P.col0, SL3D_MASK_LPAD, P.fullW, S.bx0, S.bx1);
+        const unsigned reg_own = (c.REG >> 4) & OWN_MASK;
+        const bool whole = reg_own == OWN_MASK;  // all own bytes hold source pixels: one load
+        unsigned own_bytes[ND];
 #pragma unroll
-        for (int k = 0; k < 4; k++) own_bytes[k] = mb_expand_nibble(reg_own >> (4 * k)) * 0xffu;
-        const unsigned outw = (mb_range_bits(SL3D_MASK_LPAD, SL3D_MASK_LPAD + P.W, 16 * xq - 4, 24) >> 4) & 0xffffu;  // own pixels inside the window
+        for (int k = 0; k < ND; k++) own_bytes[k] = mb_expand_nibble(reg_own >> (4 * k)) * 0xffu;
+        const unsigned outw = (mb_range_bits(SL3D_MASK_LPAD, SL3D_MASK_LPAD + P.W, OWN * xc - 4, OWN + 8) >> 4) & OWN_MASK;  // own pixels inside the window
         const uintptr_t src = S.origin + (uintptr_t)blockIdx.y * S.view_stride;
         MbRow row[R + 3];
-        u32x4 own[R];
+        unsigned own[R][ND];
 #pragma unroll
         for (int a = 0; a < R + 3; a++) {
             const int pr = pr0 + a - 2;
-            unsigned dl = 0u, dr = 0u;
-            u32x4 d = {0u, 0u, 0u, 0u};
+            unsigned dl = 0u, dr = 0u, d[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) d[k] = 0u;
             if (pr >= S.r0 && pr < S.r1) {
-                const uintptr_t p = src + (uintptr_t)pr * S.stride + (uintptr_t)(16 * xq);
-                if (whole) {
-                    d = *(const u32x4a *)p;
-                } else {  // (the lanes at the region's edge: dword by dword, nothing outside the region is touched)
-                    if (reg_own & 0x000fu) d.x = *(const unsigned *)p;
-                    if (reg_own & 0x00f0u) d.y = *(const unsigned *)(p + 4);
-                    if (reg_own & 0x0f00u) d.z = *(const unsigned *)(p + 8);
-                    if (reg_own & 0xf000u) d.w = *(const unsigned *)(p + 12);
+                const uintptr_t p = src + (uintptr_t)pr * S.stride + (uintptr_t)(OWN * xc);
+                if (ND == 4 && whole) {
+                    const u32x4 q = *(const u32x4a *)p;
+                    d[0] = q.x; d[ND > 1 ? 1 : 0] = q.y; d[ND > 2 ? 2 : 0] = q.z; d[ND > 3 ? 3 : 0] = q.w;
+                } else {  // (one dword per lane, or the lanes at the region's edge: dword by dword, nothing outside the region is touched)
+#pragma unroll
+                    for (int k = 0; k < ND; k++)
+                        if (reg_own & (0xfu << (4 * k))) d[k] = *(const unsigned *)(p + 4 * k);
                 }
-                if (c.REG & 0x00000fu) dl = *(const unsigned *)(p - 4);
-                if (c.REG & 0xf00000u) dr = *(const unsigned *)(p + 16);
+                if (c.REG & 0xfu) dl = *(const unsigned *)(p - 4);
+                if (c.REG & (0xfu << (OWN + 4))) dr = *(const unsigned *)(p + OWN);
             }
-            const unsigned b0 = mb_eq1_bytes(d.x), b1 = mb_eq1_bytes(d.y), b2 = mb_eq1_bytes(d.z), b3 = mb_eq1_bytes(d.w);
-            const unsigned V = (mb_pack_nibble(mb_eq1_bytes(dl)) | (mb_pack_nibble(b0) << 4) | (mb_pack_nibble(b1) << 8) | (mb_pack_nibble(b2) << 12) |
-                                (mb_pack_nibble(b3) << 16) | (mb_pack_nibble(mb_eq1_bytes(dr)) << 20)) & c.REG;
-            row[a] = mb_row(V, c, P.row0 + pr - SL3D_MASK_HALO, P.fullH);
-            if (a >= 2 && a < R + 2) {
-                const u32x4 o = {b0 & own_bytes[0], b1 & own_bytes[1], b2 & own_bytes[2], b3 & own_bytes[3]};
-                own[a - 2] = o;
+            unsigned V = mb_pack_nibble(mb_eq1_bytes(dl)) | (mb_pack_nibble(mb_eq1_bytes(dr)) << (OWN + 4));
+#pragma unroll
+            for (int k = 0; k < ND; k++) {
+                const unsigned bk = mb_eq1_bytes(d[k]);
+                V |= mb_pack_nibble(bk) << (4 + 4 * k);
+                if (a >= 2 && a < R + 2) own[a >= 2 && a < R + 2 ? a - 2 : 0][k] = bk & own_bytes[k];
             }
+            row[a] = mb_row(V & c.REG, c, P.row0 + pr - SL3D_MASK_HALO, P.fullH);
         }
         unsigned L[R + 3], OK[R + 3];
 #pragma unroll
@@ -86,40 +98,63 @@ __global__ __launch_bounds__(64) void k_mask_prepare(const KParams P, int first_
         }
         uint8_t *mask = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
         uint8_t *band = (uint8_t *)P.band + (size_t)view * P.px_view_stride;
-        const int xb = xq - (SL3D_MASK_LPAD >> 4);  // 16-byte column of the band row
-        const bool in_band = xb >= 0 && xb < (P.pitch >> 4);
+        const int xb = xc - SL3D_MASK_LPAD / OWN;  // OWN-byte column of the band row
+        const bool in_band = xb >= 0 && xb < P.pitch / OWN;
 #pragma unroll
         for (int a = 2; a < R + 2; a++) {
             const int pr = pr0 + a - 2, wr = pr - SL3D_MASK_HALO;
-            if (pr < rows) *(u32x4 *)(mask + (size_t)pr * P.mpitch + (size_t)xq * 16) = own[a - 2];
             unsigned v = 0u;
-            if (in_band && wr >= 0 && wr < P.H) {
-                v = (mb_valid(row[a], L[a], OK[a - 1], OK[a]) >> 4) & outw;
-                const u32x4 o = {mb_expand_nibble(v), mb_expand_nibble(v >> 4), mb_expand_nibble(v >> 8), mb_expand_nibble(v >> 12)};
-                *(u32x4 *)(band + (size_t)wr * P.pitch + (size_t)xb * 16) = o;
+            const bool has_band = in_band && wr >= 0 && wr < P.H;
+            if (has_band) v = (mb_valid(row[a], L[a], OK[a - 1], OK[a]) >> 4) & outw;
+            if (ND == 4) {
+                if (pr < rows) {
+                    const u32x4 o = {own[a - 2][0], own[a - 2][ND > 1 ? 1 : 0], own[a - 2][ND > 2 ? 2 : 0], own[a - 2][ND > 3 ? 3 : 0]};
+                    *(u32x4 *)(mask + (size_t)pr * P.mpitch + (size_t)xc * 16) = o;
+                }
+                if (has_band) {
+                    const u32x4 o = {mb_expand_nibble(v), mb_expand_nibble(v >> 4), mb_expand_nibble(v >> 8), mb_expand_nibble(v >> 12)};
+                    *(u32x4 *)(band + (size_t)wr * P.pitch + (size_t)xb * 16) = o;
+                }
+            } else {
+                if (pr < rows) *(unsigned *)(mask + (size_t)pr * P.mpitch + (size_t)xc * 4) = own[a - 2][0];
+                if (has_band) *(unsigned *)(band + (size_t)wr * P.pitch + (size_t)xb * 4) = mb_expand_nibble(v);
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) wave_quads += (unsigned)__popcll(__ballot(((v >> (4 * k)) & 0xfu) != 0u));
+            for (int k = 0; k < ND; k++) wave_quads += (unsigned)__popcll(__ballot(((v >> (4 * k)) & 0xfu) != 0u));
         }
     }
-    // (lane 0 has the smallest strip of the wave: if it is past the last row, so is every lane)
+    // (lane 0 of a wave has the wave's smallest strip: if it is past the last row, so is every lane of the wave)
+    if (BLOCK > 64) {
+        if ((threadIdx.x & 63u) == 0u && wave_quads) atomicAdd(&s_quads, wave_quads);  // LDS
+        __syncthreads();
+        wave_quads = s_quads;
+    }
     if (threadIdx.x == 0) partials[(size_t)view * gridDim.x + blockIdx.x] = ((unsigned long long)seq << 32) | wave_quads;
 }
 
 #ifndef SL3D_MASK_ROWS_PER_LANE
 #define SL3D_MASK_ROWS_PER_LANE 4
 #endif
+// The shape is a property of the context (the host reads mask_prepare_blocks(P) words per view, whatever a call covers): masks of up
+// to SL3D_MASK_WIDE_PX pixels take the many-short-waves shape, larger ones the 16-byte one
+#ifndef SL3D_MASK_WIDE_PX
+#define SL3D_MASK_WIDE_PX (6l << 20)
+#endif
+static bool mask_wide(const KParams &P) { return (long)P.pitch * P.H > SL3D_MASK_WIDE_PX; }
 int mask_prepare_blocks(const KParams &P)
 {
     const long strips = (P.H + 2 * SL3D_MASK_HALO + SL3D_MASK_ROWS_PER_LANE - 1) / SL3D_MASK_ROWS_PER_LANE;
-    return (int)(((long)(P.mpitch >> 4) * strips + 63) / 64);
+    return mask_wide(P) ? (int)(((long)(P.mpitch >> 4) * strips + 63) / 64) : (int)(((long)(P.mpitch >> 2) * strips + 255) / 256);
 }
 
 int launch_mask_prepare(const KParams &P, int first_view, int n_views, const MaskSrc &S, unsigned long long *partials, unsigned seq, void *stream)
 {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_mask_prepare<SL3D_MASK_ROWS_PER_LANE>, dim3((unsigned)mask_prepare_blocks(P), (unsigned)n_views), dim3(64), 0, (hipStream_t)stream, P,
-                       first_view, S, partials, seq);
+    const dim3 grid((unsigned)mask_prepare_blocks(P), (unsigned)n_views);
+    if (mask_wide(P))
+        hipLaunchKernelGGL((k_mask_prepare<SL3D_MASK_ROWS_PER_LANE, 16, 64>), grid, dim3(64), 0, (hipStream_t)stream, P, first_view, S, partials, seq);
+    else
+        hipLaunchKernelGGL((k_mask_prepare<SL3D_MASK_ROWS_PER_LANE, 4, 256>), grid, dim3(256), 0, (hipStream_t)stream, P, first_view, S, partials, seq);
     return (int)hipGetLastError();
 }
 

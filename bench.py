@@ -327,7 +327,8 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
         mask_bytes = W * H + (W + 32) * (H + 4) + W * H      # read the mask, write the 0/1 plane with its halo and the valid-byte plane
         return {"scan_us": round(us, 2), "mask_us": round(mask_us, 2), "masks_of_%d_views_one_launch_us" % V: round(batch_us, 2),
                 "value": round(W * H / us, 1), "unit": "Mpixels/s", "frac": round(alg * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                "mask_kernel": {"kernel": "sl3d::k_mask_prepare<4>", "algorithmic_bytes": mask_bytes,
+                "mask_kernel": {"kernel": "sl3d::k_mask_prepare<4, 16, 64>" if ((W + 15) // 16 * 16) * H > (6 << 20) else "sl3d::k_mask_prepare<4, 4, 256>",
+                                "algorithmic_bytes": mask_bytes,
                                 "frac": round(mask_bytes / (mask_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                 "kernel": kernel, "resident_views": V, "scans": scans,
                 "note": "per scan: sl3d_set_masks on a device-resident mask (no copy: the kernel reads the caller's buffer) + sl3d_run"
