@@ -30,7 +30,7 @@ def main():
             col0 = int(rng.integers(0, max(1, fullW // 8))) * 4
             row0 = int(rng.integers(0, max(1, fullH // 2)))
             W, H = int(rng.integers(1, fullW - col0 + 1)), int(rng.integers(1, fullH - row0 + 1))
-        Nv, Nh = int(rng.integers(1, 13)), int(rng.integers(1, 13))
+        Nv, Nh = int(rng.integers(0, 13)), int(rng.integers(0, 13))   # (0: an axis without Gray planes is a valid configuration)
         fwv, fwh = int(rng.choice([1, 2, 3, 4, 8, 32])), int(rng.choice([1, 2, 3, 5, 16]))
         PW = int(min(fwv * (1 << Nv), rng.integers(4, 3000)))
         PH = int(min(fwh * (1 << Nh), rng.integers(4, 2000)))
