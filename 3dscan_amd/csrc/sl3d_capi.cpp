@@ -1017,7 +1017,9 @@ extern "C" int sl3d_get_points(sl3d_ctx *x, int view, float *xyz, uint8_t *valid
 extern "C" void *sl3d_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    // portable + mapped, explicitly: the buffers of a group are read / written by EVERY GPU of the group (per-stripe uploads and
+    // downloads over each GPU's own PCIe link), and the zero-copy cloud download stores into them from a kernel
+    return hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess ? p : nullptr;
 }
 extern "C" void sl3d_host_free(void *p)
 {

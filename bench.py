@@ -964,6 +964,45 @@ def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, 
                 res["dense_rotating_pipelined"] = {"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 3),
                                                    "chunks": len(chunks), "overlapped_with_compute": True,
                                                    "note": "view i of a chunk is assembled on rank i mod N: one all_to_all per chunk on the communication stream"}
+        # ---- the OTHER sharding of a batch of independent views ("implement the specified one, measure both"): whole views
+        # per GPU instead of row stripes -- rank r takes V whole views, every view's dense planes are complete on one GPU (the very
+        # end state of the rotating assemblies above) and NOTHING is exchanged.  Reported beside the row-sharded variants, never the
+        # headline: BASELINE's configs[3] and the north star specify row stripes + a gather
+        try:
+            import importlib
+            syn_ = importlib.import_module("3dscan_amd.synth")
+            scm_ = importlib.import_module("3dscan_amd.scanner")
+            with scm_.Scanner(W, H, W, H, args.ngray, args.ngray, args.fringe_width, args.fringe_width, max_views=V, device=dev.index) as sw:
+                sw.set_calibration(*rig_calibration(syn_, np_mod, args.rig, W, H, W, H))
+                sw.set_masks(syn_.default_mask(W, H), 0, V)
+                for j in range(V):
+                    vid = rank * V + j
+                    sw.synth_view(j, plane=(0.75 * vid, 0.05, 0.05 - 0.003 * vid), view_id=vid, noise=args.noise)
+                for _ in range(5):
+                    sw.run(0, V)
+                sw.synchronize()
+
+                def whole_step(first):
+                    sw.run(0, V)
+                    if first:
+                        sw.synchronize()
+
+                def timed_whole(reps):
+                    whole_step(True)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        whole_step(False)
+                    sw.synchronize()
+                    barrier()
+                    return dmod.max_over_ranks((time.perf_counter() - t0) / reps, dev if nccl else None)
+
+                t = timed_whole(max(reps, args.steps))
+                res["whole_views_no_exchange"] = {"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 4),
+                                                  "note": f"the other sharding of the same batch: {V} WHOLE views per GPU instead of row stripes of {n_views}; every view is "
+                                                          "complete on one GPU (the end state of the rotating assemblies) with no exchange at all; not the headline"}
+        except Exception as e:
+            res["whole_views_no_exchange"] = {"error": repr(e)}
         # ---- the headline of an N > 1 line: the best ASSEMBLED variant, timed once more over exactly --steps steps between barriers
         # (the calibration runs above decide which; the choice is the same on every rank: the figures are MAX-over-ranks already) ----
         best = max((k for k in steps_of if "value" in res.get(k, {})), key=lambda k: res[k]["value"], default=None)

@@ -42,6 +42,7 @@ def test_bench_spawns_ranks_and_assembly_equals_single_rank(world, height):
     # the headline of an N > 1 line is an assembled figure over exactly --steps steps; the compute-only rate sits beside it
     assert many["value_is"] == wa["headline"] and many["value"] == wa[wa["headline"]]["headline_value"] > 0
     assert many["compute_only"]["value"] > 0
+    assert wa["whole_views_no_exchange"]["value"] > 0 and many["value_is"] != "whole_views_no_exchange"   # the other sharding: reported, never the headline
     assert many["check"]["dense_sha256"] == one["check"]["dense_sha256"]
     assert many["check"]["compact_sha256"] == one["check"]["compact_sha256"]
     assert wa["compact_root_gather"]["points_per_step"] == one["to_compacted_clouds"]["valid_points_per_step_rank0"]
