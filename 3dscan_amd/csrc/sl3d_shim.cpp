@@ -54,6 +54,7 @@ struct Shim {
     std::vector<uint8_t> default_mask;  // 1 inside the border, built once
     uint8_t *staging = nullptr;         // pinned: the decoded planes of one stage call, back to back (file inputs)
     size_t staging_planes = 0;
+    std::vector<std::vector<uint8_t>> decode_scratch;  // one per staging slot: a file's raw pixel array on its way to the slot
     // save_point_cloud()'s buffers, kept between scans (the reference saves a cloud per scan of its 360-degree loop): 1.9 M points
     // are ~190 MB of text + values, and touching that much FRESH memory costs more than filling it -- every first touch of a page
     // is a fault under the process-wide mm lock, which is what kept 32 formatting threads from scaling.  sl3d_shim_reset frees them.
@@ -160,8 +161,9 @@ bool ok(int rc, const char *what)
 // with OpenCV's fixed-point weights (B 1868, G 9617, R 4899, >> 14).
 inline uint8_t bgr2gray(int b, int gch, int r) { return (uint8_t)((b * 1868 + gch * 9617 + r * 4899 + (1 << 13)) >> 14); }
 
-// out: W * H bytes, top-down rows of W bytes
-bool read_bmp_gray(const std::string &path, uint8_t *out)
+// out: W * H bytes, top-down rows of W bytes.  scratch: the file's pixel array is read into it in one piece; a caller that decodes
+// the same number of files scan after scan hands in the same vectors again, so their pages are touched once, not once per scan
+bool read_bmp_gray(const std::string &path, uint8_t *out, std::vector<uint8_t> *scratch = nullptr)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -188,7 +190,9 @@ bool read_bmp_gray(const std::string &path, uint8_t *out)
     const size_t rowbytes = (((size_t)w * bpp + 31) / 32) * 4;
     bool identity = bpp == 8;  // the grey ramp cvSaveImage writes for a 1-channel image: rows are copied, not looked up
     for (int i = 0; i < 256 && identity; i++) identity = pal[i] == (uint8_t)i;
-    std::vector<uint8_t> file(rowbytes * (size_t)H);  // one read for the whole pixel array
+    std::vector<uint8_t> own;
+    std::vector<uint8_t> &file = scratch ? *scratch : own;
+    file.resize(rowbytes * (size_t)H);  // one read for the whole pixel array
     fseek(f, data_off, SEEK_SET);
     if (fread(file.data(), 1, file.size(), f) != file.size()) { fclose(f); return false; }
     fclose(f);
@@ -389,6 +393,7 @@ bool load_frames(const std::vector<std::vector<std::string>> &names, std::vector
         g.staging_planes = g.staging ? capacity : 0;
         if (!g.staging) return fail(SL3D_E_NOMEM, "cannot allocate the pinned staging area for the input frames");
     }
+    if (g.decode_scratch.size() < capacity) g.decode_scratch.resize(capacity);
     std::vector<char> ok_flag(n, 1);
     const std::string root = data_root();
     parallel_for((int)from_file.size(), [&](int k) {
@@ -396,7 +401,7 @@ bool load_frames(const std::vector<std::vector<std::string>> &names, std::vector
         uint8_t *dst = g.staging + (slot0 + i) * (size_t)W * H;   // frames that all come from files end up back to back
         bool got = false;
         for (const auto &nm : names[i])
-            if (!got && read_bmp_gray(root + "/" + nm, dst)) got = true;
+            if (!got && read_bmp_gray(root + "/" + nm, dst, &g.decode_scratch[slot0 + i])) got = true;
         ok_flag[i] = got;
         out[i].data = dst;
         out[i].stride = (size_t)W;
@@ -749,6 +754,7 @@ extern "C" void sl3d_shim_reset(void)
     std::vector<std::string>().swap(g.ply_rows);
     std::vector<float>().swap(g.cloud_xyz);
     std::vector<uint8_t>().swap(g.cloud_rgb);
+    std::vector<std::vector<uint8_t>>().swap(g.decode_scratch);
 }
 extern "C" void sl3d_shim_host_transpose(int enable) { g.host_transpose = enable != 0; }
 extern "C" void sl3d_shim_globals(unsigned mask)
