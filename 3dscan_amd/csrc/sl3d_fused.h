@@ -364,10 +364,10 @@ __device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned 
 #pragma unroll
     for (int a = 0; a < 2; a++) {
         const int N = a == 0 ? Nv : Nh;
-        // (an axis WITHOUT Gray planes -- sl3d_config allows 0 -- has no plane of its own to pad with: its padded loads, all of them
-        // masked out by the decode, read plane 0 of the view instead of whatever follows the axis, which for the last axis of the last
-        // resident view would be the first bytes past the frame stack)
-        const unsigned pg = (PLANES == 2 && N == 0) ? 0u : (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
+        // (PLANES == 2 needs N >= 1 on both axes: an axis WITHOUT Gray planes has no plane of its own to pad with, and its padded loads
+        // would read whatever follows the axis -- for the last axis of the last resident view the first bytes past the frame stack.
+        // choose_fused sends such pattern sets to the per-plane-test kernel)
+        const unsigned pg = (unsigned)((a == 0 ? 0 : F + 2 * Nv) + F) * psv;
         // (behind an empty asm: everything derived from it is loop-invariant, and 40 hoisted plane offsets + 20 masks are more
         // SGPRs than there are)
         int pad = NMAX - N;
@@ -1003,13 +1003,14 @@ inline FusedChoice choose_fused(bool keep, bool fgen, int cmode, int nv, int nh,
     const int m = nv > nh ? nv : nh;
     c.exact = !keep && !fgen && nv == nh && nv >= 6 && nv <= 12;
     if (c.exact) c.nmax = nv;
-    else if (!keep && m <= 12) c.nmax = m < 6 ? 6 : m;  // padded (4-/5-step fringes: always)
+    else if (!keep && m <= 12 && nv > 0 && nh > 0) c.nmax = m < 6 ? 6 : m;  // padded (4-/5-step fringes: always)
+    else if (!keep) c.nmax = SL3D_MAX_GRAY;  // more than 12 planes, or an axis with NONE (sl3d_config allows 0): the per-plane tests
     else c.nmax = m <= 8 ? 8 : (m <= 12 ? 12 : SL3D_MAX_GRAY);
     c.small = !keep && !fgen && n_views <= SL3D_SMALL_LAUNCH_VIEWS && !prefer_gated;
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_NO_SMALL")) c.small = false;
 #endif
-    const bool pipelined = !keep && rig != 0 && m <= 12;
+    const bool pipelined = !keep && rig != 0 && m <= 12 && nv > 0 && nh > 0;
     c.early = c.small ? pipelined : (pipelined && !fgen && !prefer_gated);
     return c;
 }

@@ -41,7 +41,7 @@ static int views_per_lane(unsigned bx, int n_views, int cam_table_kind, bool sma
 // one whose per-plane-test form does not spill)
 static int timed_rig(const KParams &P, int rig)
 {
-    if (P.Nv > 12 || P.Nh > 12) return 0;
+    if (P.Nv > 12 || P.Nh > 12 || P.Nv == 0 || P.Nh == 0) return 0;  // (an axis without Gray planes: no plane to pad the straight-line kernels with)
     return rig == 1 ? 1 : (rig == 2 && P.proj_disp) ? 2 : (rig == 3 && P.proj_rad && P.F == 3) ? 3 : 0;
 }
 
