@@ -69,7 +69,15 @@ struct Shim {
     // SL3D_SHIM_G_ALL: every stage runs its own kernel and fills its globals when it returns (the contexts keep the stage planes).
     // Anything else = DEFERRED: the three phase stages only bring their inputs to the GPU, triangulate() runs the whole scan as ONE
     // launch of the timed fused kernel and fills the globals the mask names.
-    unsigned globals_mask = SL3D_SHIM_G_ALL;
+    // (never set through sl3d_shim_globals: $SL3D_SHIM_GLOBALS = all | final | none | <hex mask> decides -- a relinked main() can be
+    // switched to the deferred mode without touching its source)
+    unsigned globals_mask = [] {
+        const char *e = getenv("SL3D_SHIM_GLOBALS");
+        if (!e || !*e || !strcmp(e, "all")) return (unsigned)SL3D_SHIM_G_ALL;
+        if (!strcmp(e, "final")) return (unsigned)SL3D_SHIM_G_FINAL;
+        if (!strcmp(e, "none")) return (unsigned)SL3D_SHIM_G_NONE;
+        return (unsigned)strtoul(e, nullptr, 16) & (unsigned)SL3D_SHIM_G_EVERY;
+    }();
     bool ctx_deferred = false;   // the mode the contexts were created in
     bool scan_open = false;      // deferred: a stage call of the current scan has been made (cleared by triangulate())
     bool mask_fresh = false;     // deferred: selected_region of the current scan is on the device

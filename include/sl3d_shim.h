@@ -115,7 +115,7 @@ enum {
     SL3D_SHIM_G_EVERY = (1u << 12) - 1u,             /* deferred, every global (intersection_points as doubles) */
     SL3D_SHIM_G_ALL = 0xffffffffu                    /* stage by stage (default) */
 };
-void sl3d_shim_globals(unsigned mask);
+void sl3d_shim_globals(unsigned mask);  /* (without a call: $SL3D_SHIM_GLOBALS = all | final | none | <hex mask>; default all) */
 /* after a deferred scan: fill the named globals now (returns an sl3d_status, also in sl3d_shim_last_status); which = 0 fills
  * nothing and only waits until the scan's launch has finished (triangulate() with SL3D_SHIM_G_NONE returns right after launching) */
 int sl3d_shim_materialize(unsigned which);

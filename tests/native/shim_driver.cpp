@@ -98,8 +98,15 @@ int main(int argc, char **argv)
     }
     // SL3D_SHIM_GLOBALS=<hex mask>: the deferred mode (sl3d_shim_globals); SL3D_SHIM_SCANS=n: main()'s scan loop n times -- every scan
     // but the last one with ANOTHER selection (a block cleared), so that a stale mask or stale frames would show in the dump
-    const unsigned gmask = getenv("SL3D_SHIM_GLOBALS") ? (unsigned)strtoul(getenv("SL3D_SHIM_GLOBALS"), nullptr, 16) : (unsigned)SL3D_SHIM_G_ALL;
-    sl3d_shim_globals(gmask);
+    // (all | final | none | a hex mask -- the shim reads the same variable by itself when sl3d_shim_globals is never called:
+    // SL3D_SHIM_DRIVER_NO_CALL=1 leaves the choice to it, the way a relinked main() without any source change would)
+    unsigned gmask = (unsigned)SL3D_SHIM_G_ALL;
+    if (const char *ge = getenv("SL3D_SHIM_GLOBALS")) {
+        const std::string v = ge;
+        gmask = v == "all" ? (unsigned)SL3D_SHIM_G_ALL : v == "final" ? (unsigned)SL3D_SHIM_G_FINAL : v == "none" ? (unsigned)SL3D_SHIM_G_NONE
+                                                                                                                : (unsigned)strtoul(ge, nullptr, 16);
+    }
+    if (!getenv("SL3D_SHIM_DRIVER_NO_CALL")) sl3d_shim_globals(gmask);
     const int scans = getenv("SL3D_SHIM_SCANS") ? atoi(getenv("SL3D_SHIM_SCANS")) : 1;
     for (int scan = 0; scan < scans; scan++) {
     if (scans > 1) {

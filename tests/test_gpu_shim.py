@@ -37,7 +37,8 @@ DEFERRED = {"every": 0xfff, "final": 0x804, "none": 0x0, "phases": 0x804 | 0x78}
                                           ("0,0,0", "host_transpose"), (None, "binary"),
                                           (None, "files+deferred_every"), (None, "files+deferred_final"), (None, "memory+deferred_none"),
                                           ("0,0,0", "files+deferred_final"), ("0,0,0", "memory+deferred_every"), (None, "files+deferred_phases"),
-                                          (None, "memory+deferred_final_x3"), (None, "files+deferred_none_x2"), (None, "files+stagewise_x2")])
+                                          (None, "memory+deferred_final_x3"), (None, "files+deferred_none_x2"), (None, "files+stagewise_x2"),
+                                          (None, "memory+deferredenv_final")])
 def test_shim_matches_oracle(tmp_path, devices, mode):
     """devices = "0,0,0": SL3D_DEVICES splits the scan into three row stripes (sl3d_group_*; here all on GPU 0): every
     reference-layout global and both cloud files must come out exactly as on one context.
@@ -54,7 +55,10 @@ def test_shim_matches_oracle(tmp_path, devices, mode):
         parts = extra.split("_")
         if parts[-1].startswith("x"):
             scans = int(parts.pop()[1:])
-        deferred = DEFERRED[parts[1]] if parts[0] == "deferred" else None
+        deferred = DEFERRED[parts[1]] if parts[0] in ("deferred", "deferredenv") else None
+        by_env = parts[0] == "deferredenv"   # the mode comes from $SL3D_SHIM_GLOBALS alone: the driver never calls sl3d_shim_globals
+    else:
+        by_env = False
     syn = pkg("synth")
     cap = syn.make_capture(W, H, PW, PH, NV, NH, FWV, FWH, noise=2)
     rng = np.random.default_rng(5)
@@ -119,6 +123,8 @@ def test_shim_matches_oracle(tmp_path, devices, mode):
     env.update({"memory": {"SL3D_SHIM_MEMORY": "1"}, "host_transpose": {"SL3D_SHIM_HOST_TRANSPOSE": "1"}, "binary": {"SL3D_SHIM_BINARY": "1"}}.get(mode, {}))
     if deferred is not None:
         env["SL3D_SHIM_GLOBALS"] = "%x" % deferred
+    if by_env:
+        env.update(SL3D_SHIM_GLOBALS="final", SL3D_SHIM_DRIVER_NO_CALL="1")
     if scans > 1:
         env["SL3D_SHIM_SCANS"] = str(scans)
     no_debug = deferred == 0   # (without the debug images nothing touches the parity contexts before sl3d_shim_materialize does)
