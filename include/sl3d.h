@@ -215,7 +215,10 @@ int sl3d_run(sl3d_ctx *ctx, int first_view, int n_views);
  * ~47 + 12*valid_fraction + 1 bytes per pixel instead of 60 for the dense pass + 25 for a separate compaction.  Timed mode only
  * (no SL3D_FLAG_KEEP_STAGES).  Asynchronous.
  *   SEGMENTED clouds.  Every wave of the kernel compacts the 256 consecutive scan pixels it owns into its own fixed slot
- *   (points [256*s, 256*s + count_s) of the view's region) and stores count_s; a small scan kernel turns the counts into offsets.
+ *   (points [256*s, 256*s + count_s) of the view's region) and stores count_s.  The counts become offsets by a small scan kernel
+ *   right behind a launch of more than 4 views; a launch of up to 4 views -- the reference's one scan per call -- leaves the scan
+ *   to its consumer (the gap-closing kernel adds up the counts in front of its segments on entry; sl3d_get_cloud_segments and
+ *   sl3d_register_clouds, which want the offsets as an array, run the scan kernel when they are called).
  *   No tile ever waits for another one, scan order is preserved inside and across segments, so a view's cloud is the
  *   concatenation of its segments -- and the consumers that exist anyway close the gaps for free: sl3d_download_clouds (host
  *   copy), sl3d_register_clouds (turntable registration), the pack before a group's RCCL send, or any device consumer through
