@@ -11,6 +11,9 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <map>
 #include <fcntl.h>
 #include <sched.h>
@@ -131,6 +134,82 @@ int usable_threads()
     return n;
 }
 
+// The host threads behind parallel_for: started once, parked on a condition variable between bursts.  (Until round 5 every burst
+// spawned and joined its own std::threads: ~0.1 ms per stage call of a scan that takes 2-4 ms, four times per scan.)
+class WorkerPool {
+public:
+    static WorkerPool &get()
+    {
+        static WorkerPool *p = new WorkerPool(usable_threads() - 1);  // (never destroyed: the workers may outlive static destruction order)
+        return *p;
+    }
+    // runs job(i) for i in [0, n) on the calling thread and up to `helpers` workers; returns when all items are done
+    void run(int n, int helpers, const std::function<void(int)> &job)
+    {
+        std::unique_lock<std::mutex> serial(run_mu_);  // one burst at a time
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &job;
+            n_ = n;
+            next_.store(0);
+            pending_ = n;
+            wanted_ = std::min(helpers, (int)workers_.size());
+            generation_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0 && active_ == 0; });
+        wanted_ = 0;  // (a worker that has not woken yet stays parked)
+        job_ = nullptr;
+    }
+
+private:
+    explicit WorkerPool(int k)
+    {
+        for (int i = 0; i < k; i++) workers_.emplace_back([this] { loop(); }), workers_.back().detach();
+    }
+    void work()
+    {
+        int done = 0;
+        for (int i; (i = next_.fetch_add(1)) < n_;) {
+            (*job_)(i);
+            done++;
+        }
+        if (done) {
+            std::lock_guard<std::mutex> lk(mu_);
+            pending_ -= done;
+            if (pending_ == 0) done_cv_.notify_all();
+        }
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen && wanted_ > 0; });
+                seen = generation_;
+                wanted_--;
+                active_++;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                active_--;
+                if (pending_ == 0 && active_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, pending_ = 0, wanted_ = 0, active_ = 0;
+    unsigned long long generation_ = 0;
+};
+
 // fn(i) for i in [0, n) on up to usable_threads() threads (work items are handed out one by one); the calling thread takes part
 template <typename Fn>
 void parallel_for(int n, Fn fn)
@@ -140,14 +219,8 @@ void parallel_for(int n, Fn fn)
         for (int i = 0; i < n; i++) fn(i);
         return;
     }
-    std::atomic<int> next{0};
-    auto work = [&] {
-        for (int i; (i = next.fetch_add(1)) < n;) fn(i);
-    };
-    std::vector<std::thread> pool;
-    for (int k = 1; k < t; k++) pool.emplace_back(work);
-    work();
-    for (auto &th : pool) th.join();
+    const std::function<void(int)> job = [&](int i) { fn(i); };
+    WorkerPool::get().run(n, t - 1, job);
 }
 
 bool fail(int code, const std::string &msg)
