@@ -149,3 +149,12 @@ def test_bench_two_ranks_over_rccl_assemble_the_single_rank_result():
     assert two["check"]["compact_sha256"] == one["check"]["compact_sha256"]
     assert two["value_is"] in wa and two["value"] == wa[two["value_is"]]["headline_value"]
     assert two["compute_only"]["value"] >= two["value"]
+
+
+@needs_two
+@pytest.mark.parametrize("mode", ["memory", "memory+deferred_final"])
+def test_shim_over_two_devices(tmp_path, mode):
+    """The drop-in shim with SL3D_DEVICES=0,1: the scan as two row stripes on two GPUs, stage by stage and deferred -- every global
+    and both cloud files as on one context (the same checks tests/test_gpu_shim.py makes with all stripes on GPU 0)."""
+    import test_gpu_shim
+    test_gpu_shim.test_shim_matches_oracle(tmp_path, "0,1", mode)
