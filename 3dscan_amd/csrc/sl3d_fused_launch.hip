@@ -56,7 +56,8 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: consecutive tiles go round the 8 XCDs
     // (`small` is the SIZE of the launch, not the kernel it takes: a launch of up to 4 sparsely selected views runs the large-launch
     // kernel (prefer_gated) but keeps the views-per-lane rule of small launches -- the A/B that chose that kernel for sparse
-    // selections, profiles/r04_sparse_mask.txt, was measured with it)
+    // selections, profiles/r04_sparse_mask.txt, was measured with it; following the kernel instead is 5-12 % slower at 19 % / 5 %
+    // coverage with 4 views per launch, 1-4 % faster at 50 %: profiles/r05_sparse_small_launch_vpt_ab.txt)
     const int vpt = views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0, !keep && P.F == 3 && n_views <= SL3D_SMALL_LAUNCH_VIEWS);
     const dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1);
     // the timed kernels read the camera-side T1 from the per-calibration table whatever the batch is: with 8 views per lane it
