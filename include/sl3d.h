@@ -306,7 +306,7 @@ enum sl3d_global {
     SL3D_G_VALID_V = 0, SL3D_G_VALID_H = 1, SL3D_G_VALID = 2, SL3D_G_WRAPPED_V = 3, SL3D_G_WRAPPED_H = 4,
     SL3D_G_UNWRAPPED_V = 5, SL3D_G_UNWRAPPED_H = 6, SL3D_G_CODE_V = 7, SL3D_G_CODE_H = 8, SL3D_G_INTERSECTION_POINTS = 9,
     /* double [W][H][3] like SL3D_G_INTERSECTION_POINTS, but the dense f32 result of sl3d_run widened to double (NaN where invalid):
-     * what a context WITHOUT SL3D_FLAG_KEEP_STAGES has of intersection_points -- the very values 8/save_point_cloud.cpp:98-100
+     * what a context WITHOUT SL3D_FLAG_KEEP_STAGES has of intersection_points -- the very values 8/save_point_cloud.cpp:94-96
      * casts them to, i.e. all that the reference's only reader of that global ever sees (like SL3D_G_VALID, no KEEP_STAGES needed) */
     SL3D_G_POINTS_F64 = 10
 };

@@ -98,7 +98,8 @@ void sl3d_shim_cloud_format(int binary);
  *     one bench.py measures -- and then fills the globals the mask names:
  *       SL3D_SHIM_G_FINAL = valid_map + intersection_points: all that the rest of the reference reads (main() reads none of the
  *         globals; 8/save_point_cloud.cpp:85-104 reads these two).  intersection_points then holds the kernel's f32 result widened to
- *         double -- the values save_point_cloud.cpp:98-100 casts them to anyway; SL3D_SHIM_G_INTERSECTION_POINTS asks for the doubles
+ *         double -- the values save_point_cloud.cpp:94-96 casts them to anyway (the average point spacing it prints, :160-191, then
+ *         carries the f32 rounding: ~1e-4 relative); SL3D_SHIM_G_INTERSECTION_POINTS asks for the doubles
  *       SL3D_SHIM_G_NONE: nothing (the shim's own save_point_cloud() follows: it reads the device-resident result)
  *       any other bit: that global too, from the per-stage kernels run on a second context that keeps the stage planes (created on
  *         first use; frames and mask are copied device to device) -- also available after the scan through sl3d_shim_materialize(which).
