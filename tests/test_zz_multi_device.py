@@ -2,7 +2,8 @@
 of a context on a device other than 0 and of bench.py's RCCL branch that no one-GPU test can execute -- real ncclCommInitAll over
 distinct devices, peer enabling and hipMemcpyPeerAsync between two GPUs, ncclSend/ncclRecv over xGMI, a context on `device != 0`.
 Every case compares with what ONE context on GPU 0 produces, bit for bit (the stripes never exchange anything while they compute).
-No scaling figure is claimed here or anywhere else until these have run."""
+No scaling figure is claimed here or anywhere else until these have run.
+(The file's name sorts it LAST: what has never run on hardware cannot keep `pytest -x` from reaching everything that has.)"""
 import json
 import os
 import subprocess
