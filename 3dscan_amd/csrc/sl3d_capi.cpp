@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <set>
 #include <algorithm>
 #include <string>
@@ -28,6 +29,31 @@ int sl3d_fail(sl3d_ctx *c, int code, const std::string &msg)
     return code;
 }
 
+// classifies the exception in flight (called from a catch (...) handler only); see sl3d_ctx.h
+int sl3d_caught(sl3d_ctx *c, std::string *other) noexcept
+{
+    int code = SL3D_E_INTERNAL;
+    const char *what = "unknown C++ exception";
+    char buf[256];
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = SL3D_E_NOMEM;
+        what = "out of host memory (std::bad_alloc)";
+    } catch (const std::exception &e) {
+        snprintf(buf, sizeof buf, "internal error: %s", e.what());
+        what = buf;
+    } catch (...) {
+    }
+    try {  // (storing the text allocates: if even that fails the status alone goes back)
+        if (other) *other = what;
+        else if (c) c->err = what;
+        else g_create_err = what;
+    } catch (...) {
+    }
+    return code;
+}
+
 extern "C" const char *sl3d_version(void) { return SL3D_VERSION_STRING " (gfx950, hip)"; }
 
 extern "C" const char *sl3d_strerror(int s)
@@ -39,7 +65,8 @@ extern "C" const char *sl3d_strerror(int s)
     case SL3D_E_HIP: return "HIP runtime error";
     case SL3D_E_STATE: return "call order violated";
     case SL3D_E_UNSUPPORTED: return "unsupported configuration";
-    case SL3D_E_NOMEM: return "out of device memory";
+    case SL3D_E_NOMEM: return "out of memory";
+    case SL3D_E_INTERNAL: return "internal error (a C++ exception was stopped at the C boundary)";
     default: return "unknown status";
     }
 }
@@ -79,7 +106,7 @@ static void build_atan_tables(std::vector<float> &tab)
 }
 
 extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
-{
+try {
     if (!cfg || !out) return fail(nullptr, SL3D_E_INVALID_ARG, "null argument");
     *out = nullptr;
     sl3d_config c = *cfg;
@@ -104,6 +131,11 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     if (c.device < 0 || c.device >= ndev) return fail(nullptr, SL3D_E_INVALID_ARG, "device ordinal out of range");
 
     sl3d_ctx *x = new sl3d_ctx();
+    // whatever leaves this function early -- an error return or an exception -- releases what exists so far
+    struct Unwind {
+        sl3d_ctx *p;
+        ~Unwind() { if (p) sl3d_destroy(p); }
+    } unwind{x};
     x->cfg = c;
     x->keep = (c.flags & SL3D_FLAG_KEEP_STAGES) != 0;
 #define CREATE_CHK(call)                                                                 \
@@ -111,7 +143,6 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
         hipError_t e_ = (call);                                                          \
         if (e_ != hipSuccess) {                                                          \
             g_create_err = std::string(#call) + ": " + hipGetErrorString(e_);            \
-            sl3d_destroy(x);                                                             \
             return e_ == hipErrorOutOfMemory ? SL3D_E_NOMEM : SL3D_E_HIP;                \
         }                                                                                \
     } while (0)
@@ -137,7 +168,6 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     P.pitch = (c.width + 15) & ~15;
     P.planes_per_view = 2 * P.F + 2 * P.Nv + 2 * P.Nh;
     if ((size_t)P.pitch * (size_t)P.H >= ((size_t)1 << 32)) {  // the kernels address a plane with 32-bit byte offsets
-        sl3d_destroy(x);
         return fail(nullptr, SL3D_E_UNSUPPORTED, "window too large: a plane must stay below 4 GiB (split it into row stripes)");
     }
     P.plane_stride = (size_t)P.pitch * P.H;
@@ -149,7 +179,6 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
 
     if ((P.view_stride >> 32) != 0) {
         g_create_err = "one view's frame stack exceeds 4 GiB: shard the frame by rows";
-        sl3d_destroy(x);
         return SL3D_E_UNSUPPORTED;
     }
     const size_t V = (size_t)c.max_views;
@@ -157,7 +186,6 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
 #define ALLOC(ptr, count)                                              \
     if ((rc = dev_alloc(x, &(ptr), (count))) != SL3D_OK) {             \
         g_create_err = x->err;                                         \
-        sl3d_destroy(x);                                               \
         return rc;                                                     \
     }
     ALLOC(x->d_frames, V * P.view_stride);
@@ -185,6 +213,16 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     x->quad_sum.assign(V, 0u);
     x->quad_src.resize(V);
     for (size_t v = 0; v < V; v++) x->quad_src[v] = (int)v;
+    x->quad_kind.assign(V, 0);
+    x->pend.assign(V, sl3d_ctx::PendingMask());
+    x->eager_mask = (c.flags & SL3D_FLAG_EAGER_MASK) != 0;
+    if (!x->keep && P.F == 3) {  // what a MASKIN launch leaves per wave (sl3d_fused.h: maskin_count)
+        x->mi_part_stride = fused_maskin_part_stride(P);
+        x->mi_part_words = fused_maskin_part_words(P);
+        CREATE_CHK(hipHostMalloc((void **)&x->h_mi_part, V * (size_t)x->mi_part_stride * sizeof(unsigned), hipHostMallocMapped));
+        memset((void *)x->h_mi_part, 0, V * (size_t)x->mi_part_stride * sizeof(unsigned));
+        CREATE_CHK(hipHostGetDevicePointer((void **)&x->d_mi_part, (void *)x->h_mi_part, 0));
+    }
     CREATE_CHK(hipMemsetAsync(x->d_mask, 0, V * P.mask_view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_frames, 0, V * P.view_stride, x->stream));
     CREATE_CHK(hipMemsetAsync(x->d_valid, 0, V * P.px_view_stride, x->stream));
@@ -214,8 +252,7 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
             if (h_cnt != 0) {
                 g_create_err = "device atan2 differs from the host libm atan2 on " + std::to_string(h_cnt) +
                                " of 521731 lattice points: bit-exact parity cannot be guaranteed on this host/GPU pair";
-                sl3d_destroy(x);
-                return SL3D_E_UNSUPPORTED;
+                        return SL3D_E_UNSUPPORTED;
             }
             verified.insert(c.device);
         }
@@ -247,25 +284,24 @@ extern "C" int sl3d_create(const sl3d_config *cfg, sl3d_ctx **out)
     CREATE_CHK(hipStreamSynchronize(x->stream));
 #undef ALLOC
 #undef CREATE_CHK
+    unwind.p = nullptr;
     *out = x;
     return SL3D_OK;
 }
+SL3D_CATCH(nullptr)
 
 extern "C" void sl3d_destroy(sl3d_ctx *x)
-{
+try {
     if (!x) return;
     DeviceGuard dev_guard_(x->cfg.device);
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     for (void *p : x->allocs) (void)hipFree(p);
     if (x->h_counts) (void)hipHostFree(x->h_counts);
     if (x->h_quad_part) (void)hipHostFree((void *)x->h_quad_part);
+    if (x->h_mi_part) (void)hipHostFree((void *)x->h_mi_part);
     for (hipEvent_t e : x->ev_up) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_done) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->ev_down) (void)hipEventDestroy(e);
-    if (x->s_warm) {
-        (void)hipStreamSynchronize(x->s_warm);
-        (void)hipStreamDestroy(x->s_warm);
-    }
     if (x->s_h2d) (void)hipStreamDestroy(x->s_h2d);
     if (x->s_d2h) (void)hipStreamDestroy(x->s_d2h);
     if (x->ev0) (void)hipEventDestroy(x->ev0);
@@ -273,6 +309,7 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
     if (x->own_stream && x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
 }
+SL3D_CATCH_VOID
 
 // ---- stage 7 per-scan constants (host, double) ---------------------------------------------------
 // cvRodrigues2 (vector -> matrix): theta = |r|; R = cos*I + (1-cos)*rr^T + sin*[r]x   (7/triangulation.cpp:1072,1080)
@@ -320,9 +357,61 @@ static void fill_intr(Intr &I, const double K[9], const double d[5])
     I.identity = (I.plain && !I.has_dist) ? 1 : 0;
 }
 
+// Camera table kind 3 (cam_poly_eval, sl3d_device.h): the cubic t*(c0 + t*(c1 + t*c2)) closest to s(t) = (factor of the last of
+// cvUndistortPoints' 5 iterations) - 1 of a purely radial model over t = r0^2 in [0, tmax] -- least squares on Chebyshev nodes, in
+// the scaled variable u = t / tmax.  Returns the largest |s - cubic| seen on a 4x finer grid: what the f32 residual table will hold.
+static double fit_cam_poly(const Intr &I, double tmax, double c[3])
+{
+    auto s_of = [&](double t0) {
+        double r2 = t0, icd = 1.0;
+        for (int j = 0; j < 5; j++) {
+            icd = 1.0 / (1.0 + ((I.k3 * r2 + I.k2) * r2 + I.k1) * r2);
+            r2 = t0 * icd * icd;
+        }
+        return icd - 1.0;
+    };
+    const int M = 64;
+    double A[3][3] = {{0}}, b[3] = {0};
+    for (int i = 0; i < M; i++) {
+        const double u = 0.5 - 0.5 * std::cos(M_PI * (i + 0.5) / M), y = s_of(u * tmax);
+        const double phi[3] = {u, u * u, u * u * u};
+        for (int r = 0; r < 3; r++) {
+            for (int q = 0; q < 3; q++) A[r][q] += phi[r] * phi[q];
+            b[r] += phi[r] * y;
+        }
+    }
+    for (int k = 0; k < 3; k++) {  // 3x3 Gauss elimination with partial pivoting
+        int piv = k;
+        for (int r = k + 1; r < 3; r++)
+            if (std::fabs(A[r][k]) > std::fabs(A[piv][k])) piv = r;
+        std::swap(b[k], b[piv]);
+        for (int q = 0; q < 3; q++) std::swap(A[k][q], A[piv][q]);
+        if (A[k][k] == 0.0) return HUGE_VAL;
+        for (int r = k + 1; r < 3; r++) {
+            const double f = A[r][k] / A[k][k];
+            for (int q = k; q < 3; q++) A[r][q] -= f * A[k][q];
+            b[r] -= f * b[k];
+        }
+    }
+    double a[3];
+    for (int k = 2; k >= 0; k--) {
+        double acc = b[k];
+        for (int q = k + 1; q < 3; q++) acc -= A[k][q] * a[q];
+        a[k] = acc / A[k][k];
+    }
+    c[0] = a[0] / tmax; c[1] = a[1] / (tmax * tmax); c[2] = a[2] / (tmax * tmax * tmax);
+    double worst = 0.0;
+    for (int i = 0; i <= 4 * M; i++) {
+        const double t = tmax * i / (4.0 * M);
+        const double r = s_of(t) - t * ((c[2] * t + c[1]) * t + c[0]);
+        if (!(std::fabs(r) <= worst)) worst = std::fabs(r);  // (NaN counts as infinitely bad)
+    }
+    return worst;
+}
+
 extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
                                     const double Kp[9], const double dp[5], const double rp[3], const double tp[3])
-{
+try {
     if (!x || !Kc || !dc || !rc || !tc || !Kp || !dp || !rp || !tp) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (Kc[0] == 0 || Kc[4] == 0 || Kp[0] == 0 || Kp[4] == 0) return fail(x, SL3D_E_INVALID_ARG, "zero focal length");
     projection_matrix(Kc, rc, tc, x->C.Ac);
@@ -376,18 +465,38 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     x->P.proj_rad = nullptr;
     x->P.cam_tab = nullptr;
     x->P.cam_tab_kind = 0;
+    x->P.cam_tab_f32 = 0;
     if (!x->keep && x->C.cam.has_dist) {  // timed mode: T1 of the camera per window pixel (k_cam_table)
         const int kind = x->C.cam.has_tan ? 2 : 1;
-        if (!x->d_cam_tab || x->cam_tab_doubles < (size_t)kind * x->P.px_view_stride) {
+        // kind 1: px_view_stride doubles, and behind them as many floats (kind 3, the table of small launches)
+        const size_t want = (size_t)kind * x->P.px_view_stride + (kind == 1 ? (x->P.px_view_stride + 1) / 2 : 0);
+        if (kind == 1 && x->P.F == 3) {
+            // r0^2 is convex in the pixel: its maximum over the window is at a corner
+            const Intr &I = x->C.cam;
+            double tmax = 0.0;
+            for (int k = 0; k < 4; k++) {
+                const double x0 = ((double)(x->P.col0 + (k & 1 ? x->P.pitch - 1 : 0)) - I.cx) * I.ifx;
+                const double y0 = ((double)(x->P.row0 + (k & 2 ? x->P.H - 1 : 0)) - I.cy) * I.ify;
+                tmax = std::max(tmax, x0 * x0 + y0 * y0);
+            }
+            double c[3] = {0, 0, 0};
+            const double worst = tmax > 0.0 ? fit_cam_poly(I, tmax, c) : HUGE_VAL;
+            if (worst <= 1.0 / 1024.0) {  // an f32 residual of at most 2^-10 is rounded by at most 2^-35
+                memcpy(x->C.cam_poly, c, sizeof c);
+                x->P.cam_tab_f32 = 1;
+                HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
+            }
+        }
+        if (!x->d_cam_tab || x->cam_tab_doubles < want) {
             if (x->d_cam_tab) {  // a radial-only table that has to grow into a two-double one (no launch reads it: synchronised above)
                 (void)hipFree(x->d_cam_tab);
                 x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_cam_tab), x->allocs.end());
                 x->d_cam_tab = nullptr;
                 x->cam_tab_doubles = 0;
             }
-            const int st = dev_alloc(x, &x->d_cam_tab, (size_t)kind * x->P.px_view_stride);
+            const int st = dev_alloc(x, &x->d_cam_tab, want);
             if (st) return st;
-            x->cam_tab_doubles = (size_t)kind * x->P.px_view_stride;
+            x->cam_tab_doubles = want;
         }
         const int st = launch_cam_table(x->P, x->d_cal, kind, x->d_cam_tab, x->stream);
         if (st) return fail(x, SL3D_E_HIP, std::string("k_cam_table: ") + hipGetErrorString((hipError_t)st));
@@ -422,15 +531,17 @@ extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const doubl
     x->have_cal = true;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_projection_matrices(sl3d_ctx *x, double A_cam[12], double A_proj[12])
-{
+try {
     if (!x || !A_cam || !A_proj) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     memcpy(A_cam, x->C.Ac, sizeof x->C.Ac);
     memcpy(A_proj, x->C.Ap, sizeof x->C.Ap);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 static int launched(sl3d_ctx *x, int hip_err);
 static int need_keep(sl3d_ctx *x);
@@ -446,12 +557,21 @@ static bool quads_known(const sl3d_ctx *x, int view, unsigned *quads)
         *quads = x->quad_sum[view];
         return true;
     }
-    const volatile unsigned long long *p = x->h_quad_part + (size_t)x->quad_src[view] * x->quad_blocks;
     unsigned sum = 0u;
-    for (int b = 0; b < x->quad_blocks; b++) {
-        const unsigned long long w = p[b];
-        if ((unsigned)(w >> 32) != seq) return false;
-        sum += (unsigned)w;
+    if (x->quad_kind[view] == 1) {  // the view's last preparation was a MASKIN launch: one word per wave that owns pixels
+        const volatile unsigned *p = x->h_mi_part + (size_t)x->quad_src[view] * x->mi_part_stride;
+        for (unsigned i = 0; i < x->mi_part_words; i++) {
+            const unsigned w = p[i];
+            if ((w >> 8) != (seq & 0xffffffu)) return false;
+            sum += w & 0xffu;
+        }
+    } else {
+        const volatile unsigned long long *p = x->h_quad_part + (size_t)x->quad_src[view] * x->quad_blocks;
+        for (int b = 0; b < x->quad_blocks; b++) {
+            const unsigned long long w = p[b];
+            if ((unsigned)(w >> 32) != seq) return false;
+            sum += (unsigned)w;
+        }
     }
     x->quad_sum_seq[view] = seq;
     x->quad_sum[view] = sum;
@@ -500,9 +620,12 @@ static int memory_kind(const void *p, int *device = nullptr)
 static bool is_pinned_host(const void *p) { return memory_kind(p) == 1; }
 
 // the staging plane(s) of sl3d_set_mask(s): `slots` planes, zero outside the region the copies fill
+static int flush_masks(sl3d_ctx *x, int first_view, int n_views, bool callers_only = false);
 static int ensure_mask_staging(sl3d_ctx *x, int slots)
 {
     if (slots <= x->mask_raw_slots) return SL3D_OK;
+    const int frc = flush_masks(x, 0, x->cfg.max_views);  // (deferred masks still lie in the plane that is about to be freed)
+    if (frc) return frc;
     HIPCHK(x, hipStreamSynchronize(x->stream));
     (void)hipFree(x->d_mask_raw);
     x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_mask_raw), x->allocs.end());
@@ -540,13 +663,96 @@ static int prepare_masks(sl3d_ctx *x, int first_view, int n_views, const MaskSrc
     return launched(x, launch_mask_prepare(x->P, first_view, n_views, S, x->d_quad_part, seq, x->stream));
 }
 
+// ---- deferred masks ---------------------------------------------------------------------------------------------------------------
+// image_scissor hands main() a new selection every scan (m_tech_project_console.cpp:366) and a scan is ONE view: k_mask_prepare in
+// front of a one-view launch was a fifth of the per-scan device time.  A timed context therefore only RECORDS where the selection of
+// up to SL3D_SMALL_LAUNCH_VIEWS views lies; run_fused hands it to a MASKIN launch (the fused kernel evaluates H0 / S3b / S3d itself
+// and leaves every plane and count k_mask_prepare would have left) when the launch qualifies, and anything else that reads the views'
+// mask planes prepares them first.
+static bool can_defer(const sl3d_ctx *x, int n_views, const MaskSrc &S, int lo, int hi)
+{
+    const KParams &P = x->P;
+    return !x->keep && !x->eager_mask && x->h_mi_part && n_views <= SL3D_SMALL_LAUNCH_VIEWS && P.F == 3 && P.Nv >= 1 && P.Nv <= 12 && P.Nh >= 1 &&
+           P.Nh <= 12 && hi - lo >= 8 && (unsigned long long)(P.H + 2 * SL3D_MASK_HALO) * S.stride < (1ull << 32);
+}
+
+// the masks of views [first_view, first_view + n_views) that are still deferred go through k_mask_prepare now (callers_only: only
+// those whose source is the caller's own memory -- what a synchronising call owes the caller)
+static int flush_masks(sl3d_ctx *x, int first_view, int n_views, bool callers_only)
+{
+    if (x->n_pending == 0) return SL3D_OK;
+    for (int v = first_view; v < first_view + n_views; v++) {
+        sl3d_ctx::PendingMask &pm = x->pend[(size_t)v];
+        if (!pm.pending || (callers_only && pm.ours)) continue;
+        MaskSrc S;
+        (void)mask_region(x->P, S);
+        S.origin = pm.origin;
+        S.stride = pm.stride;
+        S.view_stride = 0;
+        pm.pending = false;
+        x->n_pending--;
+        const int rc = prepare_masks(x, v, 1, S);
+        if (rc) return rc;
+    }
+    return SL3D_OK;
+}
+
+// views [first_view, first_view + n_views) are about to get a new mask whose staging overwrites slots [0, slots): their own deferred
+// masks are superseded, other views' deferred masks that still lie in those slots are prepared first
+static int supersede_masks(sl3d_ctx *x, int first_view, int n_views, int slots)
+{
+    if (x->n_pending == 0) return SL3D_OK;
+    const uintptr_t lo = (uintptr_t)x->d_mask_raw, hi = lo + (uintptr_t)slots * x->P.mask_view_stride;
+    for (int v = 0; v < x->cfg.max_views; v++) {
+        sl3d_ctx::PendingMask &pm = x->pend[(size_t)v];
+        if (!pm.pending) continue;
+        if (v >= first_view && v < first_view + n_views) {
+            pm.pending = false;
+            x->n_pending--;
+        } else if (pm.ours && pm.origin >= lo && pm.origin < hi) {
+            const int rc = flush_masks(x, v, 1);
+            if (rc) return rc;
+        }
+    }
+    return SL3D_OK;
+}
+
+static void defer_masks(sl3d_ctx *x, int first_view, int n_views, const MaskSrc &S, bool ours, int lo, int hi)
+{
+    for (int k = 0; k < n_views; k++) {
+        sl3d_ctx::PendingMask &pm = x->pend[(size_t)(first_view + k)];
+        if (!pm.pending) x->n_pending++;
+        pm.pending = true;
+        pm.ours = ours;
+        pm.origin = S.origin + (uintptr_t)k * S.view_stride;
+        pm.stride = S.stride;
+        pm.lo = lo;
+        pm.hi = hi;
+    }
+}
+
+// the stream is drained for the caller: what was deferred on the CALLER's memory is prepared first (include/sl3d.h: a device-resident
+// mask stays unchanged until the next synchronising call)
+static int sync_for_caller(sl3d_ctx *x)
+{
+    const int rc = flush_masks(x, 0, x->cfg.max_views, true);
+    if (rc) return rc;
+    HIPCHK(x, hipStreamSynchronize(x->stream));
+    return SL3D_OK;
+}
+#define SYNC_FOR_CALLER(x)                     \
+    do {                                       \
+        const int rc_ = sync_for_caller(x);    \
+        if (rc_) return rc_;                   \
+    } while (0)
+
 // selected_region -> the context's mask planes, on the device (H0, S3b, S3d: m_tech_project_console.cpp:366, 3/wrapped_phase.cpp:
 // 106-115, :253-279).  Host memory: the rows of the window + 2-pixel halo (clipped to the frame) go up as ONE 2-D copy per distinct
 // mask into a staging plane.  Device memory of this context's GPU (4-byte aligned rows): no copy at all -- the kernel reads the
 // caller's buffer.  ONE launch of k_mask_prepare then serves every view of the call.  No host pass over a mask, no allocation
 // after the first call of a given shape, no stream synchronisation unless the source is pageable host memory.
 extern "C" int sl3d_set_masks(sl3d_ctx *x, int first_view, int n_views, const uint8_t *m, size_t stride, size_t view_stride)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!m || stride < (size_t)x->cfg.full_width) return fail(x, SL3D_E_INVALID_ARG, "mask: null or stride < full_width");
@@ -566,9 +772,11 @@ extern "C" int sl3d_set_masks(sl3d_ctx *x, int first_view, int n_views, const ui
         S.origin = (uintptr_t)((intptr_t)m + ((intptr_t)P.row0 - SL3D_MASK_HALO) * (intptr_t)stride + P.col0 - SL3D_MASK_LPAD);
         S.stride = stride;
         S.view_stride = view_stride;
+        rc = supersede_masks(x, first_view, n_views, 0);
+        if (rc) return rc;
     } else {
         rc = ensure_mask_staging(x, distinct);
-        if (rc) return rc;
+        if (rc || (rc = supersede_masks(x, first_view, n_views, distinct))) return rc;
         for (int k = 0; k < distinct; k++) {
             uint8_t *dst = x->d_mask_raw + (size_t)k * P.mask_view_stride + (size_t)S.r0 * P.mpitch + S.bx0;
             HIPCHK_DRAIN(x, hipMemcpy2DAsync(dst, P.mpitch, m + (size_t)k * view_stride + (size_t)g.gy0 * stride + g.gx0, stride, (size_t)(g.gx1 - g.gx0),
@@ -578,11 +786,18 @@ extern "C" int sl3d_set_masks(sl3d_ctx *x, int first_view, int n_views, const ui
         S.stride = (size_t)P.mpitch;
         S.view_stride = distinct > 1 ? P.mask_view_stride : 0;
     }
-    rc = prepare_masks(x, first_view, n_views, S);
-    if (rc) return rc;
+    // plane bytes of a row a kernel may read: all of the staging plane's row, the frame's columns of a caller's mask
+    const int lo = direct ? SL3D_MASK_LPAD - P.col0 : 0, hi = direct ? SL3D_MASK_LPAD - P.col0 + P.fullW : P.mpitch;
+    if (can_defer(x, n_views, S, lo, hi)) {
+        defer_masks(x, first_view, n_views, S, !direct, lo, hi);
+    } else {
+        rc = prepare_masks(x, first_view, n_views, S);
+        if (rc) return rc;
+    }
     if (kind == 0) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_set_mask(sl3d_ctx *x, int view, const uint8_t *m, size_t stride) { return sl3d_set_masks(x, view, 1, m, stride, 0); }
 
@@ -606,7 +821,7 @@ static int ensure_colrow(sl3d_ctx *x, size_t bytes)
 // contiguous runs of rows -> one 2-D copy; k_mask_from_colrow transposes them into the byte staging plane, k_mask_prepare does
 // the rest (as for sl3d_set_mask).
 extern "C" int sl3d_set_mask_colrow(sl3d_ctx *x, int view, const int32_t *sel)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     if (!sel) return fail(x, SL3D_E_INVALID_ARG, "mask: null");
@@ -619,19 +834,24 @@ extern "C" int sl3d_set_mask_colrow(sl3d_ctx *x, int view, const int32_t *sel)
     S.stride = (size_t)P.mpitch;
     S.view_stride = 0;
     rc = ensure_colrow(x, std::max((size_t)ncols * nrows * sizeof(int), (size_t)P.W * P.H * 24));
-    if (rc) return rc;
+    if (rc || (rc = supersede_masks(x, view, 1, 1))) return rc;
     HIPCHK(x, hipMemcpy2DAsync(x->d_colrow, (size_t)nrows * sizeof(int), sel + (size_t)gx0 * P.fullH + gy0, (size_t)P.fullH * sizeof(int),
                                (size_t)nrows * sizeof(int), (size_t)ncols, hipMemcpyHostToDevice, x->stream));
     rc = launched(x, launch_mask_from_colrow(P, (const int *)x->d_colrow, gx0, gy0, ncols, nrows, x->d_mask_raw, x->stream));
     if (rc) return rc;
-    rc = prepare_masks(x, view, 1, S);
-    if (rc) return rc;
+    if (can_defer(x, 1, S, 0, P.mpitch)) {
+        defer_masks(x, view, 1, S, true, 0, P.mpitch);
+    } else {
+        rc = prepare_masks(x, view, 1, S);
+        if (rc) return rc;
+    }
     if (!is_pinned_host(sel)) HIPCHK(x, hipStreamSynchronize(x->stream));  // pageable source: consumed before we return
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_global_colrow(sl3d_ctx *x, int view, int which, void *out, int out_height, int out_row0)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     const KParams &P = x->P;
@@ -650,12 +870,13 @@ extern "C" int sl3d_get_global_colrow(sl3d_ctx *x, int view, int which, void *ou
     else
         HIPCHK(x, hipMemcpy2DAsync(dst, (size_t)out_height * elem, x->d_colrow, (size_t)P.H * elem, (size_t)P.H * elem, (size_t)P.W, hipMemcpyDeviceToHost,
                                    x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_set_frames_range(sl3d_ctx *x, int view, int axis, int first_plane, const uint8_t *const *planes, int n_planes, size_t stride)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     const KParams &P = x->P;
@@ -686,9 +907,10 @@ extern "C" int sl3d_set_frames_range(sl3d_ctx *x, int view, int axis, int first_
     if (!all_pinned) HIPCHK(x, hipStreamSynchronize(x->stream));
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_set_frames(sl3d_ctx *x, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     const KParams &P = x->P;
@@ -697,13 +919,14 @@ extern "C" int sl3d_set_frames(sl3d_ctx *x, int view, int axis, const uint8_t *c
         return fail(x, SL3D_E_INVALID_ARG, "set_frames: expected n_fringe + 2*n_gray planes (fringe, gray, inverse) and stride >= width");
     return sl3d_set_frames_range(x, view, axis, 0, planes, n_planes, stride);  // the whole axis
 }
+SL3D_CATCH(x)
 
 // sl3d_set_frames for RAW captures: what the acquisition stage does between the camera and the files stage 3/4 read
 // (cvUndistort2 with the camera calibration, 2/project_pattern.cpp:220,232,287,...) happens on the device, one launch for
 // all planes of the axis with the camera's map (built once per calibration).  Whole frames only: a window or a row stripe
 // would need source rows from outside itself.
 extern "C" int sl3d_set_frames_raw(sl3d_ctx *x, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     const KParams &P = x->P;
@@ -732,17 +955,19 @@ extern "C" int sl3d_set_frames_raw(sl3d_ctx *x, int view, int axis, const uint8_
                                              !x->raw_map_valid, x->stream));
     if (rc) return rc;
     x->raw_map_valid = true;
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
-{
+try {
     int rc = check_view(x, src);
     if (rc || (rc = check_view(x, dst))) return rc;
     if (src == dst) return SL3D_OK;
     const KParams &P = x->P;
     ON_DEVICE(x);
+    if ((rc = flush_masks(x, src, 1)) || (rc = supersede_masks(x, dst, 1, 0))) return rc;
     HIPCHK(x, hipMemcpyAsync(x->d_frames + (size_t)dst * P.view_stride, x->d_frames + (size_t)src * P.view_stride, P.view_stride,
                              hipMemcpyDeviceToDevice, x->stream));
     HIPCHK(x, hipMemcpyAsync(x->d_mask + (size_t)dst * P.mask_view_stride, x->d_mask + (size_t)src * P.mask_view_stride,
@@ -751,15 +976,17 @@ extern "C" int sl3d_copy_view(sl3d_ctx *x, int src, int dst)
                              hipMemcpyDeviceToDevice, x->stream));
     x->quad_seq[dst] = x->quad_seq[src];  // the duplicate's count of selected quads is the source's (until either mask is set again)
     x->quad_src[dst] = x->quad_src[src];
+    x->quad_kind[dst] = x->quad_kind[src];
     x->quad_sum_seq[dst] = 0u;  // (a sum cached for dst under the same sequence number -- one sl3d_set_masks call serves many views -- is not the source's)
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 
 // Synthetic capture of one view written straight into the resident frame stack (N1; formulas of
 // 1/pattern_generator.cpp:80-105,302,313,497 -- see k_synth).  Benchmark / test input, not part of the timed path.
 extern "C" int sl3d_synth_view(sl3d_ctx *x, int view, const double plane[3], uint64_t seed, int view_id, int noise, float gain, float offset)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     if (!plane) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -772,10 +999,11 @@ extern "C" int sl3d_synth_view(sl3d_ctx *x, int view, const double plane[3], uin
     S.seed = seed; S.view_id = view_id; S.noise = noise; S.gain = gain; S.offset = offset;
     return launched(x, launch_synth(x->P, x->C, S, view, x->stream));
 }
+SL3D_CATCH(x)
 
 // the resident frames of one axis of one view, back to host planes (fringe, gray, inverse gray order)
 extern "C" int sl3d_get_frames(sl3d_ctx *x, int view, int axis, uint8_t *const *planes, int n_planes, size_t stride)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     const KParams &P = x->P;
@@ -788,9 +1016,10 @@ extern "C" int sl3d_get_frames(sl3d_ctx *x, int view, int axis, uint8_t *const *
         const uint8_t *src = x->d_frames + (size_t)view * P.view_stride + (size_t)(base + i) * P.plane_stride;
         HIPCHK_DRAIN(x, hipMemcpy2DAsync(planes[i], stride, src, P.pitch, P.W, P.H, hipMemcpyDeviceToHost, x->stream));
     }
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // ---- compute -------------------------------------------------------------------------------------
 static int need_keep(sl3d_ctx *x)
@@ -806,80 +1035,147 @@ static int launched(sl3d_ctx *x, int hip_err)
 }
 
 extern "C" int sl3d_compute_wrapped_phase(sl3d_ctx *x, int view, int axis)
-{
+try {
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
     if (axis != 0 && axis != 1) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
     ON_DEVICE(x);
     return launched(x, launch_wrap(x->P, view, axis, x->stream));
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_unwrap_phase(sl3d_ctx *x, int view, int axis)
-{
+try {
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
     if (axis != 0 && axis != 1) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
     ON_DEVICE(x);
     return launched(x, launch_unwrap(x->P, view, axis, x->stream));
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_compute_c_p_map(sl3d_ctx *x, int view)
-{
+try {
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
     ON_DEVICE(x);
     return launched(x, launch_corr(x->P, view, x->stream));
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_triangulate(sl3d_ctx *x, int view)
-{
+try {
     int rc = check_view(x, view);
     if (rc || (rc = need_keep(x))) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE(x);
     return launched(x, launch_tri(x->P, x->C, view, x->stream));
 }
+SL3D_CATCH(x)
 
 // every fused launch of the library goes through here: the kernel is chosen by what is known about the views' masks NOW, and the
 // choice is recorded (sl3d_last_fused_kernel_name reports the instantiation that ran, not a later prediction)
+// can the launch over views [first_view, first_view + n_views) evaluate their (deferred) selections itself?  Every view's mask is
+// deferred, in one layout, the launch has a MASKIN instantiation, and the views are not known -- by their LAST counts -- to be
+// sparsely selected (a MASKIN launch requests and computes every pixel of the window before it knows the selection; sparse views keep
+// the two-kernel route whose plane requests wait for the valid bits)
+static bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep, bool prefer_gated)
+{
+    if (x->n_pending == 0 || prefer_gated || !fused_maskin_available(x->P, x->rig, n_views, keep)) return false;
+    const sl3d_ctx::PendingMask &p0 = x->pend[(size_t)first_view];
+    for (int v = first_view; v < first_view + n_views; v++) {
+        const sl3d_ctx::PendingMask &pm = x->pend[(size_t)v];
+        if (!pm.pending || pm.stride != p0.stride || pm.lo != p0.lo || pm.hi != p0.hi) return false;
+    }
+    return true;
+}
+
 static int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode)
 {
     const bool prefer_gated = sparse_views(x, first_view, n_views);
+    const bool maskin = maskin_launch(x, first_view, n_views, keep, prefer_gated);
     x->last_fused.n_views = n_views;
     x->last_fused.cmode = cmode;
     x->last_fused.keep = keep;
     x->last_fused.prefer_gated = prefer_gated;
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, prefer_gated));
+    x->last_fused.maskin = maskin;
+    if (!maskin) {
+        const int rc = flush_masks(x, first_view, n_views);
+        if (rc) return rc;
+        return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, prefer_gated));
+    }
+    MaskIn mi;
+    MaskSrc S;
+    (void)mask_region(x->P, S);
+    memset(&mi, 0, sizeof mi);
+    const unsigned seq = ++x->mask_seq;
+    for (int k = 0; k < n_views; k++) {
+        sl3d_ctx::PendingMask &pm = x->pend[(size_t)(first_view + k)];
+        mi.origin[k] = pm.origin;
+        mi.stride = pm.stride;
+        mi.lo = pm.lo;
+        mi.hi = pm.hi;
+        pm.pending = false;
+        x->n_pending--;
+        x->quad_seq[(size_t)(first_view + k)] = seq;  // the launch leaves the views' counts under a new sequence number
+        x->quad_src[(size_t)(first_view + k)] = first_view + k;
+        x->quad_kind[(size_t)(first_view + k)] = 1;
+    }
+    mi.bx0 = S.bx0; mi.bx1 = S.bx1; mi.r0 = S.r0; mi.r1 = S.r1;
+    mi.part = x->d_mi_part;
+    mi.part_stride = x->mi_part_stride;
+    mi.seq = seq & 0xffffffu;
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, false, &mi));
 }
 
 extern "C" int sl3d_last_fused_kernel_name(sl3d_ctx *x, char *buf, size_t capacity)
-{
+try {
     if (!x || !buf || capacity == 0) return fail(x, SL3D_E_INVALID_ARG, "last_fused_kernel_name: null argument");
     if (x->last_fused.n_views < 1) return fail(x, SL3D_E_STATE, "no fused launch has been made on this context");
-    const int n = fused_kernel_name(x->P, x->rig, x->last_fused.n_views, x->last_fused.keep, x->last_fused.cmode, buf, capacity, x->last_fused.prefer_gated);
+    const int n = fused_kernel_name(x->P, x->rig, x->last_fused.n_views, x->last_fused.keep, x->last_fused.cmode, buf, capacity, x->last_fused.prefer_gated,
+                                    x->last_fused.maskin);
     return n > 0 && (size_t)n < capacity ? SL3D_OK : fail(x, SL3D_E_INVALID_ARG, "last_fused_kernel_name: buffer too small");
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_run(sl3d_ctx *x, int first_view, int n_views)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE(x);
     return run_fused(x, first_view, n_views, x->keep, 0);
 }
+SL3D_CATCH(x)
 
 // the k_fused instantiation sl3d_run / sl3d_run_clouds launches for a batch of n_views views of this context, as rocprofv3 spells it
 extern "C" int sl3d_fused_kernel_name(sl3d_ctx *x, int n_views, int clouds, char *buf, size_t capacity)
-{
+try {
     if (!x || !buf || capacity == 0 || n_views < 1) return fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: null argument");
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called (the rig class is part of the name)");
-    const int n = fused_kernel_name(x->P, x->rig, n_views, x->keep, clouds ? 2 : 0, buf, capacity, n_views <= x->cfg.max_views && sparse_views(x, 0, n_views));
+    const bool fits = n_views <= x->cfg.max_views, gated = fits && sparse_views(x, 0, n_views);
+    const int n = fused_kernel_name(x->P, x->rig, n_views, x->keep, clouds ? 2 : 0, buf, capacity, gated, fits && maskin_launch(x, 0, n_views, x->keep, gated));
     return n > 0 && (size_t)n < capacity ? SL3D_OK : fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: buffer too small");
 }
+SL3D_CATCH(x)
+
+extern "C" int sl3d_camera_table_bytes_per_pixel(sl3d_ctx *x, int n_views)
+try {
+    if (!x || n_views < 1) return fail(x, SL3D_E_INVALID_ARG, "camera_table_bytes_per_pixel: null context or no views");
+    if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
+    if (!x->P.cam_tab) return 0;
+    if (x->P.cam_tab_kind == 2) return 16;
+    char name[256];
+    const bool gated = n_views <= x->cfg.max_views && sparse_views(x, 0, n_views);
+    (void)fused_kernel_name(x->P, x->rig, n_views, x->keep, 0, name, sizeof name, gated);
+    // (kind 3 is read by the small-launch instantiations -- k_fused<..., false, EARLY> -- where the calibration offers it: launch_fused)
+    const bool small = strstr(name, ", false, true>") || strstr(name, ", false, false>");
+    return small && x->P.cam_tab_f32 ? 4 : 8;
+}
+SL3D_CATCH(x)
 
 extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *ms)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
@@ -894,34 +1190,19 @@ extern "C" int sl3d_run_timed(sl3d_ctx *x, int first_view, int n_views, float *m
     if (ms) *ms = t;
     return SL3D_OK;
 }
-
-// Wake the GPU up ahead of a scan: `ms` milliseconds (at most 20) of trivial activity on a stream of its own, asynchronous -- the
-// call returns at once and nothing of the context waits for it.  See k_spin; bench.py side.one_scan_from_idle measures what it buys.
-extern "C" int sl3d_prewarm(sl3d_ctx *x, float ms)
-{
-    if (!x) return SL3D_E_INVALID_ARG;
-    if (!(ms > 0.f)) return SL3D_OK;
-    ON_DEVICE(x);
-    if (!x->s_warm) {
-        HIPCHK(x, hipStreamCreateWithFlags(&x->s_warm, hipStreamNonBlocking));
-        hipDeviceProp_t prop;
-        HIPCHK(x, hipGetDeviceProperties(&prop, x->cfg.device));
-        x->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const unsigned long long ticks = (unsigned long long)((ms > 20.f ? 20.f : ms) * 1e5f);  // the constant clock runs at 100 MHz
-    return launched(x, launch_spin(x->n_cus, ticks, x->s_warm));
-}
+SL3D_CATCH(x)
 
 extern "C" int sl3d_timer_start(sl3d_ctx *x)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     ON_DEVICE(x);
     HIPCHK(x, hipEventRecord(x->ev0, x->stream));
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_timer_stop(sl3d_ctx *x, float *ms)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     ON_DEVICE(x);
     HIPCHK(x, hipEventRecord(x->ev1, x->stream));
@@ -931,14 +1212,16 @@ extern "C" int sl3d_timer_stop(sl3d_ctx *x, float *ms)
     if (ms) *ms = t;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_synchronize(sl3d_ctx *x)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     ON_DEVICE(x);
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // ---- getters -------------------------------------------------------------------------------------
 template <typename T>
@@ -954,77 +1237,87 @@ static int get_plane(sl3d_ctx *x, int view, const T *dev_base, int comps, T *out
     const T *src = dev_base + (size_t)view * P.px_view_stride * comps;
     HIPCHK(x, hipMemcpy2DAsync(out, out_stride_elems * sizeof(T), src, (size_t)P.pitch * comps * sizeof(T), (size_t)P.W * comps * sizeof(T),
                                P.H, hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
 
 extern "C" int sl3d_get_valid_map(sl3d_ctx *x, int view, int which, uint8_t *out, size_t stride)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     const uint8_t *src = which == SL3D_VALID_MERGED ? x->P.valid : (which == 0 || which == 1) ? x->P.valid_axis[which] : nullptr;
     if (which < 0 || which > 2) return fail(x, SL3D_E_INVALID_ARG, "which must be 0, 1 or 2");
     return get_plane<uint8_t>(x, view, src, 1, out, stride);
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_wrapped_phase(sl3d_ctx *x, int view, int axis, float *out, size_t stride)
-{
+try {
     if (!x || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
     return get_plane<float>(x, view, x->P.wrapped[axis], 1, out, stride);
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_unwrapped_phase(sl3d_ctx *x, int view, int axis, float *out, size_t stride)
-{
+try {
     if (!x || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
     return get_plane<float>(x, view, x->P.unwrapped[axis], 1, out, stride);
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_code(sl3d_ctx *x, int view, int axis, int32_t *out, size_t stride)
-{
+try {
     if (!x || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "axis must be 0 or 1");
     return get_plane<int32_t>(x, view, x->P.code[axis], 1, out, stride);
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_debug_image(sl3d_ctx *x, int view, int stage, int axis, uint8_t *out, size_t stride)
-{
+try {
     if (!x || (axis != 0 && axis != 1) || (stage != 3 && stage != 4)) return fail(x, SL3D_E_INVALID_ARG, "stage must be 3 or 4, axis 0 or 1");
     return get_plane<uint8_t>(x, view, stage == 3 ? x->P.dbg3[axis] : x->P.dbg4[axis], 1, out, stride);
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_c_p_map(sl3d_ctx *x, int view, int64_t *out)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     return get_plane<int64_t>(x, view, (const int64_t *)x->P.cpmap, 2, out, (size_t)x->P.W * 2);
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_intersection_points(sl3d_ctx *x, int view, double *out)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     return get_plane<double>(x, view, x->P.ipoints, 3, out, (size_t)x->P.W * 3);
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_points(sl3d_ctx *x, int view, float *xyz, uint8_t *valid)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     int rc = SL3D_OK;
     if (xyz) rc = get_plane<float>(x, view, x->P.points, 3, xyz, (size_t)x->P.W * 3);
     if (rc == SL3D_OK && valid) rc = get_plane<uint8_t>(x, view, x->P.valid, 1, valid, (size_t)x->P.W);
     return rc;
 }
+SL3D_CATCH(x)
 
 // ---- host-buffer pipeline -------------------------------------------------------------------------------------------
 // Pinned host memory for frames and results: with it the uploads and downloads of sl3d_process_views are true asynchronous
 // DMA (pageable memory still works, but every copy is then staged and serialised by the runtime).
 extern "C" void *sl3d_host_alloc(size_t bytes)
-{
+try {
     void *p = nullptr;
     // portable + mapped, explicitly: the buffers of a group are read / written by EVERY GPU of the group (per-stripe uploads and
     // downloads over each GPU's own PCIe link), and the zero-copy cloud download stores into them from a kernel
     return hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess ? p : nullptr;
 }
+SL3D_CATCH_RETURN(nullptr)
 extern "C" void sl3d_host_free(void *p)
-{
+try {
     if (p) (void)hipHostFree(p);
 }
+SL3D_CATCH_VOID
 
 // A batch of views that live in HOST memory, through the view slots of the context as a three-stage pipeline on three
 // HIP streams: upload of view k+1 (46 plane copies), fused kernel of view k, download of the xyz / valid planes of view
@@ -1111,7 +1404,7 @@ int sl3d_process_views_wait(sl3d_ctx *x)
 }
 
 extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     const size_t px = (size_t)x->P.W * x->P.H;
     const int rc = sl3d_process_views_enqueue(x, n_views, planes, stride, xyz, px * 3, valid, px, (size_t)x->P.W);
@@ -1125,6 +1418,7 @@ extern "C" int sl3d_process_views(sl3d_ctx *x, int n_views, const uint8_t *const
     }
     return rc2;
 }
+SL3D_CATCH(x)
 
 // ---- compacted clouds straight from the fused kernel ----------------------------------------------------------------
 static int ensure_cloud_buffers(sl3d_ctx *x)
@@ -1170,7 +1464,7 @@ static int ensure_cloud_buffers(sl3d_ctx *x)
 // clouds): one launch reads every frame byte once and writes the valid map and the compacted points of every view -- no dense xyz
 // plane, no second pass over the results -- then one small scan launch turns the segment counts into offsets and totals.
 extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
@@ -1191,6 +1485,7 @@ extern "C" int sl3d_run_clouds(sl3d_ctx *x, int first_view, int n_views)
     for (int v = first_view; v < first_view + n_views; v++) x->scan_state[v] = 0;
     return launched(x, launch_seg_scan(x->P, first_view, n_views, x->stream));
 }
+SL3D_CATCH(x)
 
 // offsets and totals of views [first_view, first_view + n_views) are (being) computed: k_seg_scan for the views that still lack them
 static int ensure_scanned(sl3d_ctx *x, int first_view, int n_views)
@@ -1214,7 +1509,7 @@ static int ensure_packed(sl3d_ctx *x)
 
 // counts (and the device address) of the clouds the last sl3d_run_clouds over these views produced; synchronises
 extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -1233,7 +1528,7 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
         float *dst = x->d_packed + 3 * (size_t)first_view * x->P.px_view_stride;
         rc = launched(x, launch_seg_close_scan(x->P, first_view, n_views, dst, x->P.px_view_stride, ~0ull, x->stream));
         if (rc) return rc;
-        HIPCHK(x, hipStreamSynchronize(x->stream));
+        SYNC_FOR_CALLER(x);
         for (int v = 0; v < n_views; v++) {
             counts[v] = (int64_t)t[first_view + v];
             if (x->scan_state[first_view + v] == 1) x->scan_state[first_view + v] = 2;
@@ -1244,7 +1539,7 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
     }
     if (no_total && (rc = ensure_scanned(x, first_view, n_views))) return rc;
     // the scan kernel (or a scanning consumer) stored the counts into pinned host memory itself: wait for it, read them
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[first_view + v];
     if (device_xyz) {  // the contiguous copy is made now, by one gap-closing launch over these views
         rc = ensure_packed(x);
@@ -1254,15 +1549,16 @@ extern "C" int sl3d_get_cloud_counts(sl3d_ctx *x, int first_view, int n_views, c
         if (rc) return rc;
         // the copy is handed to consumers on OTHER streams too (a group's communication stream, a caller's RCCL stream):
         // like the counts, it is complete when this call returns
-        HIPCHK(x, hipStreamSynchronize(x->stream));
+        SYNC_FOR_CALLER(x);
         *device_xyz = dst;
     }
     if (view_stride_points) *view_stride_points = x->P.px_view_stride;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_cloud_segments(sl3d_ctx *x, int first_view, int n_views, sl3d_cloud_segments *out, int64_t *counts)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!out) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -1286,12 +1582,13 @@ extern "C" int sl3d_get_cloud_segments(sl3d_ctx *x, int first_view, int n_views,
     out->view_stride_segments = (size_t)P.n_segs;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // The host copy of the clouds of the last sl3d_run_clouds, back to back (8/save_point_cloud.cpp:85-104 fills a host cloud).
 // Segmented clouds + pinned destination: the gap-closing kernel stores straight into the (mapped) host buffer -- the PCIe link is
 // the bound either way, so closing the gaps costs nothing; pageable destination: a contiguous device copy goes down by DMA.
 extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -1306,7 +1603,7 @@ extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, fl
         if (!(zc && atoi(zc) == 0) && is_pinned_host(xyz) && hipHostGetDevicePointer(&mapped, xyz, 0) == hipSuccess && mapped) {
             rc = launched(x, launch_seg_close_scan(x->P, first_view, 1, (float *)mapped, 0, (unsigned long long)capacity, x->stream));
             if (rc) return rc;
-            HIPCHK(x, hipStreamSynchronize(x->stream));
+            SYNC_FOR_CALLER(x);
             counts[0] = (int64_t)((volatile unsigned long long *)x->h_counts)[first_view];
             if (x->scan_state[first_view] == 1) x->scan_state[first_view] = 2;
             return SL3D_OK;
@@ -1347,12 +1644,13 @@ extern "C" int sl3d_download_clouds(sl3d_ctx *x, int first_view, int n_views, fl
             off += n;
         }
     }
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_compact(sl3d_ctx *x, int view, const float **device_xyz, int64_t *count)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     if (!count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -1363,14 +1661,15 @@ extern "C" int sl3d_compact(sl3d_ctx *x, int view, const float **device_xyz, int
     if (rc) return rc;
     unsigned long long n = 0;
     HIPCHK(x, hipMemcpyAsync(&n, x->d_total, sizeof n, hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     *count = (int64_t)n;
     if (device_xyz) *device_xyz = x->d_cloud;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacity, int64_t *count)
-{
+try {
     if (!x || !count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     ON_DEVICE(x);
     // row-major scan, valid pixels only (8/save_point_cloud.cpp:85-104), compacted on the device
@@ -1380,15 +1679,16 @@ extern "C" int sl3d_get_cloud(sl3d_ctx *x, int view, float *xyz, int64_t capacit
     const int64_t n = *count < capacity ? *count : capacity;
     if (xyz && n > 0) {
         HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
-        HIPCHK(x, hipStreamSynchronize(x->stream));
+        SYNC_FOR_CALLER(x);
     }
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // The compaction of a whole batch of views in three launches and one read-back: what a pipeline that goes from
 // device-resident frames to compacted clouds runs after sl3d_run (bench.py reports it as `to_compacted_clouds`).
 extern "C" int sl3d_compact_views(sl3d_ctx *x, int first_view, int n_views, const float **device_xyz, size_t *view_stride_points, int64_t *counts)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!counts) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -1403,16 +1703,17 @@ extern "C" int sl3d_compact_views(sl3d_ctx *x, int first_view, int n_views, cons
     if (rc) return rc;
     std::vector<unsigned long long> t((size_t)n_views);
     HIPCHK(x, hipMemcpyAsync(t.data(), x->d_totals + first_view, sizeof(unsigned long long) * (size_t)n_views, hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     for (int v = 0; v < n_views; v++) counts[v] = (int64_t)t[(size_t)v];
     if (device_xyz) *device_xyz = x->d_packed + 3 * (size_t)first_view * P.px_view_stride;
     if (view_stride_points) *view_stride_points = P.px_view_stride;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // host copy of the batched compaction: the clouds of the views back to back in xyz (at most `capacity` points in all)
 extern "C" int sl3d_get_clouds(sl3d_ctx *x, int first_view, int n_views, float *xyz, int64_t capacity, int64_t *counts)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     ON_DEVICE(x);
     const float *dev = nullptr;
@@ -1425,14 +1726,15 @@ extern "C" int sl3d_get_clouds(sl3d_ctx *x, int first_view, int n_views, float *
         if (n > 0) HIPCHK_DRAIN(x, hipMemcpyAsync(xyz + 3 * off, dev + 3 * (size_t)v * stride, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         off += n > 0 ? n : 0;
     }
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // the colour image save_point_cloud() takes the r,g,b of every valid pixel from (8/save_point_cloud.cpp:46-52: cvLoadImage
 // of Point_cloud/texture.bmp, split into blue / green / red planes)
 extern "C" int sl3d_set_texture(sl3d_ctx *x, int view, const uint8_t *bgr, size_t stride)
-{
+try {
     int rc = check_view(x, view);
     if (rc) return rc;
     const KParams &P = x->P;
@@ -1445,15 +1747,16 @@ extern "C" int sl3d_set_texture(sl3d_ctx *x, int view, const uint8_t *bgr, size_
         if (rc) return rc;
         x->have_texture.assign((size_t)x->cfg.max_views, 0);
     }
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     HIPCHK(x, hipMemcpy2D(x->d_texture + (size_t)view * P.px_view_stride * 3, (size_t)P.pitch * 3, bgr, stride, (size_t)P.W * 3, (size_t)P.H,
                           hipMemcpyHostToDevice));
     x->have_texture[view] = 1;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_cloud_rgb(sl3d_ctx *x, int view, float *xyz, uint8_t *rgb, int64_t capacity, int64_t *count)
-{
+try {
     if (!x || !count) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     if (!x->d_texture || view < 0 || view >= (int)x->have_texture.size() || !x->have_texture[view])
         return fail(x, SL3D_E_INVALID_ARG, "no texture set for this view (sl3d_set_texture)");
@@ -1465,17 +1768,18 @@ extern "C" int sl3d_get_cloud_rgb(sl3d_ctx *x, int view, float *xyz, uint8_t *rg
     if (n > 0) {
         if (xyz) HIPCHK(x, hipMemcpyAsync(xyz, dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
         if (rgb) HIPCHK_DRAIN(x, hipMemcpyAsync(rgb, x->d_cloud_rgb, (size_t)n * 3, hipMemcpyDeviceToHost, x->stream));
-        HIPCHK(x, hipStreamSynchronize(x->stream));
+        SYNC_FOR_CALLER(x);
     }
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // register_point_clouds(), 9/register_point_clouds.cpp:23-155, without the PLY files: the clouds are the
 // compacted clouds of the resident views, view k is rotated about Y by theta_k around (tx,ty,tz), theta_0 = 0,
 // theta_{k+1} = theta_k + rot_step in float (:145), angles in degrees converted with Pi = 22/7 (:89-93).
 extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, float tx, float ty, float tz, float rot_step, float *xyz,
                                    int64_t capacity, int64_t *total)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!total) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -1503,21 +1807,22 @@ extern "C" int sl3d_register_views(sl3d_ctx *x, int first_view, int n_views, flo
         off += n;
         theta += rot_step;
     }
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     *total = off;
     const int64_t m = off < capacity ? off : capacity;
     if (xyz && m > 0) {
         HIPCHK(x, hipMemcpyAsync(xyz, x->d_reg, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
-        HIPCHK(x, hipStreamSynchronize(x->stream));
+        SYNC_FOR_CALLER(x);
     }
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // register_point_clouds() on the clouds of the last sl3d_run_clouds: the segments of view k are rotated by theta_k while they are
 // concatenated (k_seg_close<REG>), so neither a dense plane nor a separate compaction nor a gap-closing pass is needed.
 extern "C" int sl3d_register_clouds(sl3d_ctx *x, int first_view, int n_views, float tx, float ty, float tz, float rot_step, float *xyz,
                                     int64_t capacity, int64_t *total)
-{
+try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!total) return fail(x, SL3D_E_INVALID_ARG, "null argument");
@@ -1552,14 +1857,15 @@ extern "C" int sl3d_register_clouds(sl3d_ctx *x, int first_view, int n_views, fl
     *total = off;
     const int64_t m = off < capacity ? off : capacity;
     if (xyz && m > 0) HIPCHK(x, hipMemcpyAsync(xyz, x->d_reg, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // ---- N4: cvUndistort2 (2/project_pattern.cpp:220,232,...) -------------------------------------------------------------
 extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride, int width, int height, int channels, const double K[9],
                               const double dist[5], uint8_t *dst, size_t dst_stride)
-{
+try {
     if (!x || !src || !dst || !K || !dist || width < 1 || height < 1 || (channels != 1 && channels != 3) || width > 32767 || height > 32767)
         return fail(x, SL3D_E_INVALID_ARG, "undistort: null argument, size, or channels not 1 / 3");
     const size_t row = (size_t)width * channels, img = (((row + 15) / 16) * 16) * (size_t)height;
@@ -1567,7 +1873,7 @@ extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride
     const size_t pitch = ((row + 15) / 16) * 16, maps = (size_t)width * height * 6, need = 2 * img + maps + 128;
     ON_DEVICE(x);
     if (need > x->und_bytes) {
-        HIPCHK(x, hipStreamSynchronize(x->stream));
+        SYNC_FOR_CALLER(x);
         if (x->d_und) {
             (void)hipFree(x->d_und);
             x->allocs.erase(std::remove(x->allocs.begin(), x->allocs.end(), (void *)x->d_und), x->allocs.end());
@@ -1595,15 +1901,16 @@ extern "C" int sl3d_undistort(sl3d_ctx *x, const uint8_t *src, size_t src_stride
     memcpy(x->und_key, key, sizeof key);
     x->und_map_valid = true;
     HIPCHK(x, hipMemcpy2DAsync(dst, dst_stride, d_dst, pitch, row, (size_t)height, hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // One cloud of 9/register_point_clouds.cpp:83-128 that lives in host memory (the reference reads each from a PLY file):
 // p -> R_y(theta) * (p - t) + t with the reference's float / double-accumulator arithmetic (k_register), theta in degrees
 // converted with Pi = 22/7.  The caller advances theta by rot_step IN FLOAT from cloud to cloud, as :145 does.
 extern "C" int sl3d_transform_cloud(sl3d_ctx *x, const float *xyz_in, int64_t n, float theta_deg, float tx, float ty, float tz, float *xyz_out)
-{
+try {
     if (!x || n < 0 || (n > 0 && (!xyz_in || !xyz_out))) return fail(x, SL3D_E_INVALID_ARG, "transform_cloud: null argument");
     if (n == 0) return SL3D_OK;
     ON_DEVICE(x);
@@ -1620,17 +1927,19 @@ extern "C" int sl3d_transform_cloud(sl3d_ctx *x, const float *xyz_in, int64_t n,
     if (rc) return fail(x, SL3D_E_HIP, std::string("transform_cloud: ") + hipGetErrorString((hipError_t)rc));
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 // ---- N1: projector patterns (1/pattern_generator.cpp) ---------------------------------------------------------------
 #define PI_REF 22.0 / 7.0 /* PROJECT_GLOBAL/global_cv.h:62: unparenthesised on purpose */
 
 extern "C" int sl3d_pattern_counts(int proj_extent, int fringe_width, int *n_codes, int *n_planes)
-{
+try {
     if (proj_extent < 1 || fringe_width < 1 || !n_codes || !n_planes) return SL3D_E_INVALID_ARG;
     *n_codes = (int)ceil((float)proj_extent / (float)fringe_width);                 // :224 / :228
     *n_planes = (int)ceil((logf((float)*n_codes) / logf(2.0)));                     // :226 / :229
     return SL3D_OK;
 }
+SL3D_CATCH(nullptr)
 
 // the values of one pattern along its varying axis, with the reference's expressions and the host libm it calls
 static void pattern_profile(int kind, int F, int index, int extent, int fw, int nplanes, uint8_t *out)
@@ -1659,7 +1968,7 @@ static void pattern_profile(int kind, int F, int index, int extent, int fw, int 
 
 extern "C" int sl3d_generate_pattern(sl3d_ctx *x, int kind, int axis, int index, uint8_t *host_dst, size_t stride,
                                      const uint8_t **device_ptr, size_t *device_pitch)
-{
+try {
     if (!x) return SL3D_E_INVALID_ARG;
     const int PW = x->cfg.proj_width, PH = x->cfg.proj_height, F = x->cfg.n_fringe;
     if (kind < SL3D_PATTERN_FRINGE || kind > SL3D_PATTERN_BINARY || (axis != 0 && axis != 1)) return fail(x, SL3D_E_INVALID_ARG, "pattern: kind or axis");
@@ -1681,47 +1990,56 @@ extern "C" int sl3d_generate_pattern(sl3d_ctx *x, int kind, int axis, int index,
     HIPCHK(x, hipMemcpy(x->d_profile, prof.data(), extent_max, hipMemcpyHostToDevice));
     int rc = launched(x, launch_pattern(x->d_pattern, pitch, PW, PH, axis, x->d_profile, x->stream));
     if (rc) return rc;
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     if (host_dst) HIPCHK(x, hipMemcpy2D(host_dst, stride, x->d_pattern, pitch, (size_t)PW, (size_t)PH, hipMemcpyDeviceToHost));
     if (device_ptr) *device_ptr = x->d_pattern;
     if (device_pitch) *device_pitch = pitch;
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 #ifdef SL3D_MEASURE
 // measurement builds (-DSL3D_TRACE): the per-wave phase stamps of the dense kernel (tools/phase_trace.py)
 extern "C" int sl3d_debug_buffer(sl3d_ctx *x, const void **dev, size_t *bytes, int *n_tiles)
-{
+try {
     if (!x || !x->P.dbg || !x->dbg_words) return SL3D_E_STATE;
     *dev = x->P.dbg;
     *bytes = x->dbg_words * sizeof(unsigned long long);
     *n_tiles = fused_tiles(x->P);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 #endif
 
 extern "C" int sl3d_download(sl3d_ctx *x, void *host_dst, const void *device_src, size_t bytes)
-{
+try {
     if (!x || (bytes && (!host_dst || !device_src))) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     ON_DEVICE(x);
     if (bytes) HIPCHK(x, hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, x->stream));
-    HIPCHK(x, hipStreamSynchronize(x->stream));
+    SYNC_FOR_CALLER(x);
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_download_2d(sl3d_ctx *x, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes, size_t height)
-{
+try {
     if (!x || !host_dst || !device_src || dst_pitch < width_bytes || src_pitch < width_bytes) return fail(x, SL3D_E_INVALID_ARG, "download_2d: null argument or pitch < width");
     ON_DEVICE(x);
     if (width_bytes && height)
         HIPCHK(x, hipMemcpy2DAsync(host_dst, dst_pitch, device_src, src_pitch, width_bytes, height, hipMemcpyDeviceToHost, x->stream));
     return SL3D_OK;
 }
+SL3D_CATCH(x)
 
 extern "C" int sl3d_get_device_buffers(sl3d_ctx *x, sl3d_device_buffers *o)
-{
+try {
     if (!x || !o) return fail(x, SL3D_E_INVALID_ARG, "null argument");
     const KParams &P = x->P;
+    if (x->n_pending) {  // the caller is about to read the mask plane where it lies: deferred masks are prepared first
+        ON_DEVICE(x);
+        const int rc = flush_masks(x, 0, x->cfg.max_views);
+        if (rc) return rc;
+    }
     o->frames = x->d_frames;
     o->frame_pitch = P.pitch;
     o->plane_stride = P.plane_stride;
@@ -1738,3 +2056,4 @@ extern "C" int sl3d_get_device_buffers(sl3d_ctx *x, sl3d_device_buffers *o)
     o->valid_view_stride = P.px_view_stride;
     return SL3D_OK;
 }
+SL3D_CATCH(x)

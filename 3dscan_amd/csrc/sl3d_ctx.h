@@ -37,8 +37,25 @@ struct sl3d_ctx {
     std::vector<int> quad_src;                // [max_views] the view whose blocks hold this view's count (sl3d_copy_view duplicates masks)
     mutable std::vector<unsigned> quad_sum_seq, quad_sum;  // [max_views] the sum once it was complete, and the preparation it belongs to
     unsigned mask_seq = 0;
+    // Deferred masks (sl3d_set_mask(s) of at most SL3D_SMALL_LAUNCH_VIEWS views on a timed context, unless SL3D_FLAG_EAGER_MASK): the
+    // view's selection has been handed over but not prepared -- the next small launch over such views evaluates it inside the fused
+    // kernel (a MASKIN launch, sl3d_fused.h), every other consumer of the view's planes prepares it first (flush_masks, sl3d_capi.cpp).
+    struct PendingMask {
+        bool pending = false;
+        bool ours = false;     // the source is the context's staging plane (else the CALLER's device memory: prepared at the next synchronising call at the latest)
+        uintptr_t origin = 0;  // MaskSrc::origin of this view
+        size_t stride = 0;
+        int lo = 0, hi = 0;    // plane bytes of a row that may be read (MaskIn)
+    };
+    std::vector<PendingMask> pend;            // [max_views]
+    int n_pending = 0;
+    bool eager_mask = false;
+    volatile unsigned *h_mi_part = nullptr;   // MASKIN launches: per view and wave {seq << 8 | quads with a valid pixel} (mapped host memory)
+    unsigned *d_mi_part = nullptr;
+    unsigned mi_part_stride = 0, mi_part_words = 0;
+    std::vector<uint8_t> quad_kind;           // [max_views] whose words hold the view's count: 0 = k_mask_prepare's blocks, 1 = a MASKIN launch's waves
     // the fused launch made last on this context (sl3d_last_fused_kernel_name: the instantiation that RAN, not a prediction)
-    struct { int n_views = 0, cmode = 0; bool keep = false, prefer_gated = false; } last_fused;
+    struct { int n_views = 0, cmode = 0; bool keep = false, prefer_gated = false, maskin = false; } last_fused;
     float *d_points = nullptr;
     unsigned *d_blk_cnt = nullptr;            // compaction scratch: per-1024-pixel block counts,
     unsigned long long *d_blk_off = nullptr;  // their exclusive scan, and the total
@@ -52,8 +69,6 @@ struct sl3d_ctx {
     size_t und_bytes = 0;
     double und_key[16] = {0};  // K, dist, width, height of the map held in d_und (the 46 frames of a view share one map)
     bool und_map_valid = false;
-    hipStream_t s_warm = nullptr;                   // sl3d_prewarm: the spin kernel's own stream (created on first use)
-    int n_cus = 0;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // sl3d_process_views: upload and download run beside the compute stream
     std::vector<hipEvent_t> ev_up, ev_done, ev_down;  // per view slot: frames landed / kernel finished / results copied out
     float *d_clouds = nullptr;                // batched compaction: one region of px_view_stride points per view (first use)
@@ -86,6 +101,14 @@ struct sl3d_ctx {
 // records the message on the context (or, without one, as the thread's creation error) and returns `code`
 __attribute__((visibility("hidden"))) int sl3d_fail(sl3d_ctx *c, int code, const std::string &msg);
 #define fail sl3d_fail
+// The exception barrier of the C ABI (no exceptions across the boundary).  Every extern "C" entry point that can allocate
+// (new, std::vector, std::string ...) is a function-try-block whose handler ends in one of these: the exception in flight is
+// classified (std::bad_alloc -> SL3D_E_NOMEM, anything else -> SL3D_E_INTERNAL), its text becomes the context's last error if that
+// still can be stored, and the status is returned.  Nothing in here throws.
+__attribute__((visibility("hidden"))) int sl3d_caught(sl3d_ctx *c, std::string *err_of_other_owner = nullptr) noexcept;
+#define SL3D_CATCH(ctx) catch (...) { return sl3d_caught(ctx); }
+#define SL3D_CATCH_RETURN(value) catch (...) { (void)sl3d_caught(nullptr); return value; }
+#define SL3D_CATCH_VOID catch (...) { (void)sl3d_caught(nullptr); }
 // sl3d_process_views in two halves (sl3d_capi.cpp), shared with sl3d_group_process_views
 __attribute__((visibility("hidden"))) int sl3d_process_views_enqueue(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz,
                                                                      size_t xyz_view_stride, uint8_t *valid, size_t valid_view_stride, size_t out_width);

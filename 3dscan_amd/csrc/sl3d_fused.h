@@ -18,8 +18,10 @@
 // start stagger, un-split pixel loop, the single-pass look-back compaction, other block sizes / occupancies) is recorded in
 // DESIGN.md section 4 and profiles/README.md; git history has the code.
 #pragma once
+#include <stddef.h>
 #include <stdlib.h>
 #include "sl3d_device.h"
+#include "sl3d_maskbits.h"
 
 #define SL3D_BLOCK 256 /* threads per block: a block is a 1024-pixel tile of the scan, 4 waves = 4 segments of 256 pixels */
 #define SL3D_OCC 4     /* waves per SIMD the fused kernel is compiled for (128 VGPRs) */
@@ -199,9 +201,20 @@ struct Item {
 // the camera-table entries of the lane's 4 pixels: kind 1 = one double per pixel (factor of the last undistortion iteration of a
 // radial model), kind 2 = the normalised point itself (tangential terms).  Request and use are separate so that the small-launch
 // instantiation can put its plane requests in between.
-__device__ __forceinline__ void cam_table_request(const KParams &P, const Item &it, double (&t)[8])
+// F32 (the small-launch instantiations only: the large-launch kernels are instruction for instruction what they were): the launch
+// may ask for kind 3 instead of kind 1 (KParams::cam_tab_f32 == 2) -- ONE float per pixel, the residual of the radial factor
+// against the per-calibration cubic in r0^2 (cam_poly_eval): 4 B/px instead of 8 where nothing amortises the table (a one-view
+// launch moves 64 instead of 68 B/px).  Its four floats travel in `tf`, apart from t[] (a third way into the same array made the
+// optimiser merge the paths' stores into one with a run-time index: the array went to scratch).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool F32>
+__device__ __forceinline__ void cam_table_request(const KParams &P, const Item &it, double (&t)[8], f32x4_t &tf)
 {
     const size_t i0 = (size_t)it.row * P.pitch + (size_t)it.cq * 4;
+    if (F32 && P.cam_tab_f32 == 2) {
+        tf = *(const f32x4_t *)((const float *)(P.cam_tab + P.px_view_stride) + i0);
+        return;
+    }
     if (P.use_cam_table == 1) {
         const double2 *tp = (const double2 *)(P.cam_tab + i0);
         const double2 a = tp[0], b = tp[1];
@@ -216,10 +229,24 @@ __device__ __forceinline__ void cam_table_request(const KParams &P, const Item &
 // table entries -> the camera coordinates stage 7 uses (normalised for the camera-frame rigs, re-projected pixels for RIG 0), kept
 // in LDS so that the rolled pixel loops can index them (each lane reads back only what it wrote: no barrier).  The doubles are the
 // ones the in-kernel iteration produces.
-template <int RIG>
-__device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal *Cglobal, const Item &it, const double (&t)[8], double *my_cam)
+template <int RIG, bool F32>
+__device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal *Cglobal, const Item &it, const double (&t)[8], const f32x4_t &tf, double *my_cam)
 {
     const auto &I = opaque_const(Cglobal)->cam;
+    if (F32 && P.cam_tab_f32 == 2) {
+        const double y0 = ((double)it.gy - I.cy) * I.ify;
+        const float res[4] = {tf.x, tf.y, tf.z, tf.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double x0 = (((double)(it.gx0 + k)) - I.cx) * I.ifx;
+            const double icd = 1.0 + (cam_poly_eval(*opaque_const(Cglobal), x0, y0) + (double)res[k]);
+            double xn = x0 * icd, yn = y0 * icd;
+            if (RIG == 0) reproject(xn, yn, I, xn, yn);
+            my_cam[2 * k] = xn;
+            my_cam[2 * k + 1] = yn;
+        }
+        return;
+    }
     if (P.use_cam_table == 1) {
         const double y0 = ((double)it.gy - I.cy) * I.ify;
 #pragma unroll
@@ -245,9 +272,9 @@ __device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal 
 // view's plane loads right behind them and then calls cam_table_finish -- one round trip instead of two in front of the first
 // decode.  (Round 3 measured the other order for large launches -- set-up loads before the reciprocal-table fill, consumed behind
 // the plane loads: 16 views +-0, profiles/r03_prologue_ab.txt.)
-template <int RIG, bool SEG, bool EARLY, int BLK = SL3D_BLOCK>
+template <int RIG, bool SEG, bool EARLY, int BLK = SL3D_BLOCK, bool F32 = false, bool MASKIN = false>
 __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglobal, unsigned tile_, int group, int first_view, int n_views, int vpt, Item &it,
-                                           MaskQuad &mq_first, double (&camt)[8], double *my_cam)
+                                           MaskQuad &mq_first, double (&camt)[8], f32x4_t &camf, double *my_cam)
 {
     const unsigned qpr = (unsigned)P.pitch >> 2;  // quads per row, pitch padding included
     it.tile = tile_;
@@ -270,15 +297,17 @@ __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglob
     it.lane_off = (unsigned)it.row * (unsigned)P.pitch + (unsigned)it.cq * 4u;
     // the valid bits of the item's first view are requested now, so that they travel together with the camera table
     // entries below instead of after them (one round trip less before the first plane loads can leave)
-    mq_first = load_mask_quad(P, min(it.v_begin, first_view + n_views - 1), it.lane_off);
+    // (MASKIN: there is no valid-map dword yet -- the launch evaluates the selection itself, maskin_request / maskin_finish)
+    if (MASKIN) mq_first.band = 0u;
+    else mq_first = load_mask_quad(P, min(it.v_begin, first_view + n_views - 1), it.lane_off);
     if (EARLY && P.use_cam_table) {
-        cam_table_request(P, it, camt);
+        cam_table_request<F32>(P, it, camt, camf);
         return true;
     }
     if (P.use_cam_table) {
         double t[8];
-        cam_table_request(P, it, t);
-        cam_table_finish<RIG>(P, Cglobal, it, t, my_cam);
+        cam_table_request<F32>(P, it, t, camf);
+        cam_table_finish<RIG, F32>(P, Cglobal, it, t, camf, my_cam);
         return true;
     }
     // no table (a camera without distortion, or the parity mode): T1 of the camera evaluated here
@@ -755,6 +784,136 @@ __device__ __forceinline__ void store_segment(const KParams &P, const Item &it, 
     wave_lds_handoff();  // ... and read before the next view's phase A parks its correspondences in the same area
 }
 
+// ---- MASKIN (CMODE bit 4): H0 / S3b / S3d inside the fused launch -----------------------------------------------------------------
+// image_scissor produces a new selection every scan (m_tech_project_console.cpp:366) and the reference's loop runs ONE scan per
+// iteration: k_mask_prepare (5.5 us at 1080p, all of it launch latency and one load -> compute -> store chain) in front of a 25-us
+// one-view launch was a fifth of the per-scan path.  A MASKIN launch takes the views' RAW selection instead (the staging plane behind
+// sl3d_set_mask's copy, or the caller's own device-resident mask: KParams::mi_*) and evaluates the closed form of the boundary
+// removal (3/wrapped_phase.cpp:106-115, :253-279) itself, with the very bit-plane arithmetic of k_mask_prepare (sl3d_maskbits.h, one
+// row per lane: R = 1, OWN = 4) -- so "new mask + one view" is ONE kernel.
+//   * Nothing waits for it.  The planes of a view are requested as if every pixel of the window were selected (the small-launch
+//     kernels request them before they know the mask anyway); the lane asks for the 3 x 8 selection bytes around its quad (rows y-1 .. y+1, plane bytes own-2 ..
+//     own+5: neighbours' bytes are L2 hits; row y-2 matters to few lanes, which ask for it when they need it) AFTER the Gray decode, when the 40 plane registers are dead, runs
+//     stages 4 + 5 of its pixels under that request, and only then clears what the selection rejects.  No round trip is added in
+//     front of anything; the price is the arithmetic of unselected pixels -- so a launch over views KNOWN to be sparsely selected
+//     keeps the two-kernel route (sl3d_capi.cpp), whose plane requests wait for the valid bits.
+//   * It leaves everything k_mask_prepare would have left: the view's `band` dword (later launches over the view are ordinary ones),
+//     the normalised 0/1 plane with its 2-pixel halo (the lanes of the window's first / last row and column also write the halo
+//     rows / columns beside them), and per wave the number of quads that hold a valid pixel, as {seq << 8 | count} in host memory
+//     mapped into the device (what sparse_views reads).
+static_assert(SL3D_MASK_HALO == 2, "rows y-2 .. y+1 of the selection are plane rows row .. row + 3");
+// own pixels of the lane's quad that lie inside the window (the pitch padding is never selected)
+// (recomputed at every use from an opaque copy of the quad's column: kept in a register across the view loop it was one more to spill)
+__device__ __forceinline__ unsigned maskin_assumed(const KParams &P, const Item &it)
+{
+    int cq = it.cq;
+    asm volatile("" : "+v"(cq));
+    return it.alive ? mb_range_bits(0, P.W, cq * 4, 4) : 0u;
+}
+
+// The lane's place in the mask plane.  Everything below is a function of the pixel alone, i.e. invariant in the view loop: left to
+// itself the optimiser hoists all of it (addresses, column masks, a dozen predicates) in front of the loop and keeps it in registers
+// the pixel loop needs -- 250 bytes of scratch per lane.  The copies behind an empty asm are opaque, so the ~60 integer
+// instructions are redone per view instead.
+// The launch's MaskIn, read where it is used through an opaque pointer into the kernel-argument segment (KParams is the kernel's first
+// argument): as plain kernel arguments its 20 dwords were loaded once in front of the view loop and held in SGPRs the loop has not got.
+typedef const CONST_AS MaskIn *MaskInP;
+__device__ __forceinline__ MaskInP maskin_args()
+{
+    const CONST_AS char *ka = (const CONST_AS char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return (MaskInP)(ka + offsetof(KParams, mi));
+}
+
+struct MaskInLane {
+    int row, cq, delta;
+    MbCols c;
+};
+__device__ __forceinline__ MaskInLane maskin_lane(const KParams &P, const Item &it)
+{
+    const MaskInP M = maskin_args();
+    MaskInLane m;
+    m.row = it.row;
+    m.cq = it.cq;
+    asm volatile("" : "+v"(m.row), "+v"(m.cq));
+    const int own = SL3D_MASK_LPAD + m.cq * 4;
+    m.c = mb_cols(own, 4, P.col0, SL3D_MASK_LPAD, P.fullW, M->bx0, M->bx1);
+    m.delta = mb_quad_delta(own, M->lo, M->hi);
+    return m;
+}
+
+// the 8 selection bytes of plane row `pr` around the lane's quad (sl3d_maskbits.h: ONE 8-byte load; 0 for a row that holds no source pixels)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2_t maskin_row(const KParams &P, const GLOBAL_AS uint8_t *src, const MaskInLane &m, int pr)
+{
+    const MaskInP M = maskin_args();
+    u32x2_t w = {0u, 0u};
+    // (a lane whose own dword holds no source pixel -- the pitch padding beyond the region -- needs nothing: its pixels lie outside the
+    // window, and the dword beside it is farther out still; beyond the frame's last column its load would leave a caller's mask)
+    if (pr >= M->r0 && pr < M->r1 && (m.c.REG & 0x0f0u)) {
+        const unsigned off = (unsigned)pr * (unsigned)M->stride + (unsigned)(SL3D_MASK_LPAD + m.cq * 4 + m.delta);
+        asm volatile("" : "+s"(src));
+        typedef unsigned u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
+        w = *(const GLOBAL_AS u32x2_unaligned *)(src + (size_t)off);
+    }
+    return w;
+}
+
+// rows y-1, y, y+1 (row y-2 matters to few lanes: maskin_finish asks for it where it does)
+__device__ __forceinline__ void maskin_request(const KParams &P, const Item &it, int slot, u32x2_t (&mw)[3])
+{
+    const GLOBAL_AS uint8_t *src = opaque((const uint8_t *)maskin_args()->origin[slot]);
+    const MaskInLane m = maskin_lane(P, it);
+#pragma unroll
+    for (int a = 0; a < 3; a++) mw[a] = maskin_row(P, src, m, m.row + 1 + a);
+}
+
+// the normalised 0/1 bytes of plane row `pr`: the lane's own dword, and at the window's first / last quad the dword beside it
+__device__ __forceinline__ void maskin_emit(const KParams &P, uint8_t *mask_view, const MaskInLane &m, int pr, u32x2_t w)
+{
+    unsigned *q = (unsigned *)(mask_view + (size_t)pr * P.mpitch + SL3D_MASK_LPAD + m.cq * 4);
+    q[0] = mb_eq1_bytes(mb_quad_own(w.x, w.y, m.delta)) & (mb_expand_nibble(m.c.REG >> 4) * 0xffu);
+    if (m.cq == 0) q[-1] = mb_eq1_bytes(mb_quad_left(w.x, w.y, m.delta)) & (mb_expand_nibble(m.c.REG) * 0xffu);
+    if (m.cq == (P.pitch >> 2) - 1) q[1] = mb_eq1_bytes(mb_quad_right(w.x, w.y, m.delta)) & (mb_expand_nibble(m.c.REG >> 8) * 0xffu);
+}
+
+// -> the valid bits of the lane's 4 pixels (bit k = pixel k), exactly what k_mask_prepare leaves in the band plane
+__device__ __forceinline__ unsigned maskin_finish(const KParams &P, const Item &it, int view, int slot, const u32x2_t (&mw)[3])
+{
+    const MaskInP M = maskin_args();
+    const MaskInLane m = maskin_lane(P, it);
+    const int gy = P.row0 + m.row;
+    const bool first = m.row == 0, last = m.row == P.H - 1;
+    uint8_t *mask_view = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
+    unsigned Vtop = 0u;
+    if (first || mb_quad_top_needed(m.c, gy, P.fullH)) {  // (few lanes: the window's first row, frame row 2, the frame's first / last column)
+        const u32x2_t w = maskin_row(P, opaque((const uint8_t *)M->origin[slot]), m, m.row);
+        Vtop = mb_quad_word(w.x, w.y, m.delta) & m.c.REG;
+        if (first) maskin_emit(P, mask_view, m, m.row, w);  // the halo rows above the window ...
+    }
+    if (first) maskin_emit(P, mask_view, m, m.row + 1, mw[0]);
+    maskin_emit(P, mask_view, m, m.row + 2, mw[1]);
+    if (last) {  // ... and below it
+        maskin_emit(P, mask_view, m, m.row + 3, mw[2]);
+        maskin_emit(P, mask_view, m, m.row + 4, maskin_row(P, opaque((const uint8_t *)M->origin[slot]), m, m.row + 4));
+    }
+    const unsigned v = mb_quad_valid(Vtop, mb_quad_word(mw[0].x, mw[0].y, m.delta) & m.c.REG, mb_quad_word(mw[1].x, mw[1].y, m.delta) & m.c.REG,
+                                     mb_quad_word(mw[2].x, mw[2].y, m.delta) & m.c.REG, m.c, gy, P.fullH) &
+                       mb_range_bits(0, P.W, m.cq * 4, 4);
+    *(unsigned *)((uint8_t *)P.band + (size_t)view * P.px_view_stride + ((size_t)m.row * P.pitch + (size_t)m.cq * 4)) = mb_expand_nibble(v);
+    return v;
+}
+
+// per wave: {seq << 8 | quads with a valid pixel}; a wave whose first lane owns no pixel owns none at all and stores nothing (the
+// host expects one word per wave that owns pixels)
+__device__ __forceinline__ void maskin_count(const KParams &P, const Item &it, int view, unsigned v)
+{
+    const MaskInP M = maskin_args();
+    const unsigned cnt = (unsigned)__popcll(__ballot(v != 0u));
+    if ((threadIdx.x & 63u) == 0u && it.alive)
+        M->part[(size_t)view * M->part_stride + (size_t)it.tile * 4u + (threadIdx.x >> 6)] = (M->seq << 8) | cnt;
+}
+
 // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
 template <bool KEEP, bool FGEN, bool SEG>
 __device__ __forceinline__ unsigned valid_bits(const Item &it, int F, const MaskQuad &m)
@@ -782,7 +941,8 @@ struct RadialLds<3> {
 // NMAX / EXACT  unroll bound of the Gray planes / both axes have exactly NMAX planes
 // FGEN  false: 3-step fringes (the reference's configuration) with the F test folded at compile time
 // RIG   stage 7, see above
-// CMODE 0: dense xyz + valid planes; 2: segmented ordered clouds + the valid plane (sl3d_run_clouds)
+// CMODE 0: dense xyz + valid planes; 2: segmented ordered clouds + the valid plane (sl3d_run_clouds); + 4 (MASKIN, the pipelined
+//       small-launch instantiations only): the launch evaluates the views' raw selection itself -- see maskin_request
 // RCPT  true: 1/d of the atan2 quotient from an LDS table (6 KB per block, 768 IEEE divisions + a block barrier to fill it);
 //       false: the instantiation for SMALL launches (a handful of views: the reference's one scan per call) -- v_rcp_f64 + one
 //       Newton step instead of the table, whose fill nothing amortises when a block lives for one or two views, and the first
@@ -797,9 +957,12 @@ struct RadialLds<3> {
 template <bool KEEP, int NMAX, bool FGEN, bool EXACT, int RIG, int CMODE, bool RCPT, bool EARLY_>
 __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) void k_fused(const KParams P, const DevCal *__restrict__ Cglobal, int first_view, int n_views, int vpt)
 {
-    constexpr bool SEG = CMODE == 2;
+    constexpr bool SEG = (CMODE & 2) != 0;
+    constexpr bool MASKIN = (CMODE & 4) != 0;
     constexpr int BLK = RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK;
-    static_assert(CMODE == 0 || CMODE == 2, "0 = dense planes, 2 = segmented clouds (1 was round 2's look-back compaction)");
+    static_assert((CMODE & ~6) == 0, "0 = dense planes, 2 = segmented clouds (1 was round 2's look-back compaction), + 4 = MASKIN");
+    static_assert(!MASKIN || (!RCPT && EARLY_ && !KEEP && RIG != 0), "MASKIN: the pipelined small-launch instantiations");
+    constexpr bool F32TAB = !RCPT;  // camera table kind 3 (cam_table_request): the small-launch instantiations
     static_assert(!(KEEP && CMODE != 0), "the parity mode writes dense planes");
     static_assert(!(KEEP && RIG != 0), "the parity mode evaluates everything with the reference's operation order");
     __shared__ __attribute__((aligned(16))) float s_xyz[BLK * 12];  // staging area: correspondences, then xyz, of the lane's 4 pixels
@@ -852,12 +1015,13 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     Item it;
     MaskQuad mq;
     double camt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // EARLY: the lane's camera-table entries between their request and cam_table_finish
+    f32x4_t camf = {0.f, 0.f, 0.f, 0.f};         // (kind 3: the four residuals)
     unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     // gridDim.x is a multiple of 8 (launch_fused): consecutive tiles go round-robin over the 8 XCDs on purpose (the XCD-banded
     // order was measured at -4 %: DRAM locality across XCDs beats L2 locality for 2 % of shared bytes)
     // (false: a lane past the last row, or a block the grid was padded with.  REQ_FIRST: block-uniform, only the latter -- a lane past
     // the last row stays until the block's barrier, its requests go to the last row.)
-    if (!item_begin<RIG, SEG, REQ_FIRST, BLK>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam)) return;
+    if (!item_begin<RIG, SEG, REQ_FIRST, BLK, F32TAB, MASKIN>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, camf, my_cam)) return;
     if (REQ_FIRST) {
         // EARLY: planes of the first view right behind the set-up requests.  The block's LDS tables are filled while all of that
         // travels (the radial node requested at the very top is the oldest request: its store waits for nothing else); then the
@@ -870,17 +1034,19 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         if (RIG == 3) ((u32x4 *)s_rad)[threadIdx.x] = rad_node;
         if (RCPT || RIG == 3) __syncthreads();
         if (!SEG && !it.alive) return;
-        if (P.use_cam_table) cam_table_finish<RIG>(P, Cglobal, it, camt, my_cam);
+        if (P.use_cam_table) cam_table_finish<RIG, F32TAB>(P, Cglobal, it, camt, camf, my_cam);
     }
     SL3D_STAMP(2);
+    // MASKIN: until the selection has been evaluated (behind the Gray decode, maskin_request) every pixel of the window counts as valid
+#define SL3D_ASSUMED() (MASKIN ? maskin_assumed(P, it) : 0u)
     // The mask dword of the NEXT view is requested a view ahead, so a wave never waits a full memory round trip for it before it
     // can ask for its 11.5 KB of planes.  (gfx950 has one in-order vmcnt for loads and stores, and the wait-count pass is
     // conservative wherever a register a load is still writing is touched: round 4 removed, one by one, every s_waitcnt vmcnt(0)
     // of this loop except the decode's -- see the comments at the pipeline point, in phase_A / phase_B and at vb_pre.)
     unsigned vb_next = 0;
     if (PIPE) {
-        vb_next = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
-        if (it.v_begin + 1 < it.v_end) mq = load_mask_quad(P, it.v_begin + 1, it.lane_off);
+        vb_next = MASKIN ? SL3D_ASSUMED() : valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+        if (!MASKIN && it.v_begin + 1 < it.v_end) mq = load_mask_quad(P, it.v_begin + 1, it.lane_off);
         if (!EARLY && vb_next != 0) {  // (EARLY: they are in flight already)
             issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
             issue_gray<NMAX, PLANES>(P, it.v_begin, it.lane_off, F, Nv, Nh, g, iv);
@@ -924,12 +1090,18 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         }
         if (vbits != 0) decode_gray<NMAX, PLANES>(g, iv, Nv, Nh, code);  // waits for the planes of this view
         if (view == it.v_begin) SL3D_STAMP(4);
+        // MASKIN: the view's selection is asked for HERE -- the 40 Gray registers are dead, stages 4 + 5 below run under the request
+        u32x2_t mw[3];
+        if (MASKIN) {
+            __builtin_amdgcn_sched_barrier(0);  // (not hoisted in front of the decode, where the registers are not there)
+            if (it.alive) maskin_request(P, it, view - first_view, mw);
+        }
         // the NEXT view's valid bits, taken here -- its mask dword is older than the planes just decoded, so it has landed, and no
         // store of this view has been issued yet.  Taken at the pipeline point (where they are needed) they cost an s_waitcnt
         // vmcnt(0) there: one in-order counter, and by then the deferred stores are in it
         unsigned vb_pre = 0;
         if (PIPE) {
-            vb_pre = valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+            vb_pre = MASKIN ? SL3D_ASSUMED() : valid_bits<KEEP, FGEN, SEG>(it, F, mq);
             asm volatile("" : "+v"(vb_pre));  // (here, not sunk to its use)
         }
         if (DEFER) {
@@ -940,6 +1112,12 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             if (KEEP) vout = parity_pixels<RCPT>(P, Cglobal, PR, it, F, vbits, f, code, s_rcp, my_cam, my_xyz, px);
             else if (SPLIT) vout = correspond_quad(P, it, vbits, w, code, my_cp);
             else vout = phase_A<RCPT, UNROLL>(P, it, F, vbits, f, code, s_rcp, my_cp);
+        }
+        if (MASKIN) {  // the selection has arrived: what it rejects is cleared, what k_mask_prepare would have left is left
+            unsigned real = 0u;
+            if (it.alive) real = maskin_finish(P, it, view, view - first_view, mw);
+            maskin_count(P, it, view, real);
+            vout &= mb_expand_nibble(real);
         }
         if (view == it.v_begin) SL3D_STAMP(5);
         // (Round 3 read the ISA of the table rigs: their 4 projector-table entries are requested BEHIND the next view's 46 plane
@@ -952,7 +1130,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             // loaded value is a use: s_waitcnt vmcnt(0), i.e. stage 7 of this view waited for ALL of the next view's planes to land
             // (round 3 read this wait in the ISA and measured a schedule without it at +-0.3 %; with today's kernel: 4 views per
             // launch +5 %, 16 views +1 %, the table rig +1.5 %, profiles/r04_pipeline_point_ab.txt)
-            mq = load_mask_quad(P, min(view + 2, it.v_end - 1), it.lane_off);
+            if (!MASKIN) mq = load_mask_quad(P, min(view + 2, it.v_end - 1), it.lane_off);
             if (vb_next != 0) {
                 issue_fringe<FGEN>(P, view + 1, it.lane_off, F, Nv, f);
                 issue_gray<NMAX, PLANES>(P, view + 1, it.lane_off, F, Nv, Nh, g, iv);
@@ -1076,6 +1254,39 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
 #undef SL3D_LAUNCH
 }
 
+// MASKIN launches (CMODE | 4): the pipelined small-launch instantiation of every N, exact and padded, nothing else
+template <int RIG, int CMODE>
+static void launch_fused_maskin_n(int nv, int nh, dim3 grid, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
+{
+    static_assert(RIG != 0 && (CMODE == 4 || CMODE == 6), "MASKIN: rig classes 1..3, dense or segmented clouds");
+    const FusedChoice c = choose_fused(false, false, CMODE & 2, nv, nh, n_views, false, RIG);
+    const long quads_ = (long)(P.pitch >> 2) * P.H;
+    const dim3 small_grid((((unsigned)((quads_ + SL3D_SMALL_BLOCK - 1) / SL3D_SMALL_BLOCK)) + 7u) & ~7u, grid.y, 1);
+#define SL3D_LAUNCH_MI(NM, EX) hipLaunchKernelGGL((k_fused<false, NM, false, EX, RIG, CMODE, false, true>), small_grid, dim3(SL3D_SMALL_BLOCK), 0, st, P, C, first_view, n_views, vpt)
+    if (c.exact) {
+        switch (c.nmax) {
+        case 6: SL3D_LAUNCH_MI(6, true); break;
+        case 7: SL3D_LAUNCH_MI(7, true); break;
+        case 8: SL3D_LAUNCH_MI(8, true); break;
+        case 9: SL3D_LAUNCH_MI(9, true); break;
+        case 10: SL3D_LAUNCH_MI(10, true); break;
+        case 11: SL3D_LAUNCH_MI(11, true); break;
+        default: SL3D_LAUNCH_MI(12, true); break;
+        }
+        return;
+    }
+    switch (c.nmax) {
+    case 6: SL3D_LAUNCH_MI(6, false); break;
+    case 7: SL3D_LAUNCH_MI(7, false); break;
+    case 8: SL3D_LAUNCH_MI(8, false); break;
+    case 9: SL3D_LAUNCH_MI(9, false); break;
+    case 10: SL3D_LAUNCH_MI(10, false); break;
+    case 11: SL3D_LAUNCH_MI(11, false); break;
+    default: SL3D_LAUNCH_MI(12, false); break;
+    }
+#undef SL3D_LAUNCH_MI
+}
+
 // one family of instantiations per translation unit (sl3d_fused_*.hip; they compile in parallel): 3-step timed kernels per rig,
 // dense and segmented; the 4-/5-step timed kernels; the parity mode
 #define SL3D_FUSED_FAMILY_ARGS int nv, int nh, dim3 grid, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt
@@ -1087,6 +1298,9 @@ void fused_clouds_rig0(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig1(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig2(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig3(SL3D_FUSED_FAMILY_ARGS);
+void fused_maskin_rig1(int cmode, SL3D_FUSED_FAMILY_ARGS);  // MASKIN launches (cmode 4 / 6), one translation unit per rig class
+void fused_maskin_rig2(int cmode, SL3D_FUSED_FAMILY_ARGS);
+void fused_maskin_rig3(int cmode, SL3D_FUSED_FAMILY_ARGS);
 void fused_fgen(int rig, int cmode, SL3D_FUSED_FAMILY_ARGS);  // 4-step (and the all-invalid 5-step) fringes: the F test stays a run-time branch
 void fused_parity(bool fgen, SL3D_FUSED_FAMILY_ARGS);
 

@@ -48,10 +48,30 @@ static int timed_rig(const KParams &P, int rig)
 // rig: 0 / 1 / 2 / 3 (sl3d_fused.h; the host knows the calibration, the timed kernels fold it at compile time).
 // cmode: 0 = dense xyz + valid planes, 2 = segmented clouds (KParams::clouds / seg_counts must be set).
 // Returns the hipError_t of THIS launch.
-int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream, bool prefer_gated)
+bool fused_maskin_available(const KParams &P, int rig, int n_views, bool keep)
+{
+    if (keep || P.F != 3 || n_views > SL3D_SMALL_LAUNCH_VIEWS || timed_rig(P, rig) == 0) return false;
+    const FusedChoice c = choose_fused(false, false, 0, P.Nv, P.Nh, n_views, false, timed_rig(P, rig));
+    return c.small && c.early;
+}
+
+unsigned fused_maskin_part_stride(const KParams &P)
+{
+    const long quads = (long)(P.pitch >> 2) * P.H;
+    return 4u * (((unsigned)((quads + SL3D_SMALL_BLOCK - 1) / SL3D_SMALL_BLOCK) + 7u) & ~7u);
+}
+unsigned fused_maskin_part_words(const KParams &P) { return (unsigned)(((long)(P.pitch >> 2) * P.H + 63) / 64); }
+
+int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream, bool prefer_gated,
+                 const MaskIn *mi)
 {
     KParams P = P_;
     P.prefer_gated = prefer_gated ? 1 : 0;
+    if (mi) {
+        if (!fused_maskin_available(P, rig, n_views, keep)) return (int)hipErrorInvalidValue;
+        P.mi = *mi;
+        P.prefer_gated = 0;
+    }
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: consecutive tiles go round the 8 XCDs
     // (`small` is the SIZE of the launch, not the kernel it takes: a launch of up to 4 sparsely selected views runs the large-launch
@@ -64,13 +84,21 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     // costs nothing (1 B/px/view), with 1..4 it saves the iteration (+2..13 %), and a view's result does not depend on the
     // batch it was launched in
     P.use_cam_table = P.cam_tab != nullptr ? P.cam_tab_kind : 0;
+    const int r = timed_rig(P, rig);
+    // the small-launch instantiations read the 4-byte form of a radial camera table where the calibration offers it (kind 3:
+    // nothing amortises the table's bytes in a launch of a few views)
+    if (P.use_cam_table == 1 && P.cam_tab_f32 == 1 && !keep && P.F == 3 &&
+        choose_fused(false, false, cmode, P.Nv, P.Nh, n_views, P.prefer_gated != 0, r).small)
+        P.cam_tab_f32 = 2;
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 0) P.use_cam_table = 0;
+    if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 1 && P.cam_tab_f32 == 2) P.cam_tab_f32 = 1;
 #endif
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's
-    const int r = timed_rig(P, rig);
-    if (keep) {
+    if (mi) {
+        (r == 1 ? fused_maskin_rig1 : r == 2 ? fused_maskin_rig2 : fused_maskin_rig3)(cmode, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+    } else if (keep) {
         fused_parity(P.F != 3, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
     } else if (P.F != 3) {
         fused_fgen(r, cmode, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
@@ -84,11 +112,15 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
 
 // the instantiation launch_fused picks for such a launch, spelled as rocprofv3 prints it (bench.py names the kernel its roofline
 // figure is about; derived from the same choose_fused / timed_rig the launch uses, so it cannot go stale)
-int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap, bool prefer_gated)
+int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap, bool prefer_gated, bool maskin)
 {
     const bool fgen = P.F != 3;
     const int r = keep ? 0 : timed_rig(P, rig);
-    const FusedChoice c = choose_fused(keep, fgen, cmode, P.Nv, P.Nh, n_views, prefer_gated, r);
+    if (maskin) {
+        prefer_gated = false;
+        cmode |= 4;
+    }
+    const FusedChoice c = choose_fused(keep, fgen, cmode & 2, P.Nv, P.Nh, n_views, prefer_gated, r);
     auto b = [](bool v) { return v ? "true" : "false"; };
     return snprintf(buf, cap, "sl3d::k_fused<%s, %d, %s, %s, %d, %d, %s, %s>", b(keep), c.nmax, b(fgen), b(c.exact), r, keep ? 0 : cmode, b(!c.small), b(c.early));
 }

@@ -123,6 +123,9 @@ static int gfail(sl3d_group *g, int code, const std::string &msg)
     return code;
 }
 
+// the exception barrier of the group entry points (sl3d_ctx.h): the text goes to the group's own last error
+#define SL3D_GROUP_CATCH(g) catch (...) { sl3d_group *g_ = (g); return sl3d_caught(nullptr, g_ ? &g_->err : nullptr); }
+
 #define GHIP(g, call)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
@@ -146,7 +149,7 @@ extern "C" int sl3d_group_size(const sl3d_group *g) { return g ? (int)g->st.size
 extern "C" const char *sl3d_group_transport(const sl3d_group *g) { return g && g->use_rccl ? "rccl" : "copy"; }
 
 extern "C" void sl3d_group_destroy(sl3d_group *g)
-{
+try {
     if (!g) return;
     for (auto &s : g->st)
         if (s.ctx) {
@@ -175,9 +178,10 @@ extern "C" void sl3d_group_destroy(sl3d_group *g)
     }
     delete g;
 }
+SL3D_CATCH_VOID
 
 extern "C" int sl3d_group_create(const sl3d_config *cfg, const int *devices, int n, sl3d_group **out)
-{
+try {
     if (!cfg || !devices || !out || n < 1) return gfail(nullptr, SL3D_E_INVALID_ARG, "group_create: null argument or no stripes");
     *out = nullptr;
     if (cfg->height < n) return gfail(nullptr, SL3D_E_INVALID_ARG, "group_create: more stripes than rows");
@@ -271,9 +275,10 @@ extern "C" int sl3d_group_create(const sl3d_config *cfg, const int *devices, int
     *out = g;
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(nullptr)
 
 extern "C" int sl3d_group_stripe(sl3d_group *g, int i, int *row0, int *rows, int *device, sl3d_ctx **ctx)
-{
+try {
     if (!g || i < 0 || i >= (int)g->st.size()) return gfail(g, SL3D_E_INVALID_ARG, "group_stripe: index out of range");
     const Stripe &s = g->st[(size_t)i];
     if (row0) *row0 = s.row0;
@@ -282,24 +287,27 @@ extern "C" int sl3d_group_stripe(sl3d_group *g, int i, int *row0, int *rows, int
     if (ctx) *ctx = s.ctx;
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_set_calibration(sl3d_group *g, const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
                                           const double Kp[9], const double dp[5], const double rp[3], const double tp[3])
-{
+try {
     if (!g) return SL3D_E_INVALID_ARG;
     for (size_t s = 0; s < g->st.size(); s++) GCTX(g, s, sl3d_set_calibration(g->st[s].ctx, Kc, dc, rc, tc, Kp, dp, rp, tp));
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_set_mask(sl3d_group *g, int view, const uint8_t *m, size_t stride)
-{
+try {
     if (!g) return SL3D_E_INVALID_ARG;
     for (size_t s = 0; s < g->st.size(); s++) GCTX(g, s, sl3d_set_mask(g->st[s].ctx, view, m, stride));
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_set_frames(sl3d_group *g, int view, int axis, const uint8_t *const *planes, int n_planes, size_t stride)
-{
+try {
     if (!g || !planes || n_planes < 1) return gfail(g, SL3D_E_INVALID_ARG, "group_set_frames: null argument");
     std::vector<const uint8_t *> sub((size_t)n_planes);
     for (size_t s = 0; s < g->st.size(); s++) {
@@ -312,6 +320,7 @@ extern "C" int sl3d_group_set_frames(sl3d_group *g, int view, int axis, const ui
     }
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 static bool overlaps(const sl3d_group *g, int first, int n) { return g->comm_busy && first < g->busy_first + g->busy_n && g->busy_first < first + n; }
 
@@ -344,14 +353,16 @@ static int group_launch(sl3d_group *g, int first, int n, RunFn run)
 }
 
 extern "C" int sl3d_group_run(sl3d_group *g, int first, int n)
-{
+try {
     return group_launch(g, first, n, [&](sl3d_ctx *c) { return sl3d_run(c, first, n); });
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_run_clouds(sl3d_group *g, int first, int n)
-{
+try {
     return group_launch(g, first, n, [&](sl3d_ctx *c) { return sl3d_run_clouds(c, first, n); });
 }
+SL3D_GROUP_CATCH(g)
 
 namespace {
 struct Xfer {  // one contiguous message: stripe -> root
@@ -433,7 +444,7 @@ static void mark_busy(sl3d_group *g, int first, int n)
 }
 
 extern "C" int sl3d_group_gather(sl3d_group *g, int first, int n)
-{
+try {
     int rc = check_views(g, first, n);
     if (rc) return rc;
     std::vector<Xfer> xs;
@@ -453,6 +464,7 @@ extern "C" int sl3d_group_gather(sl3d_group *g, int first, int n)
     mark_busy(g, first, n);
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 static int root_sync(sl3d_group *g)
 {
@@ -462,7 +474,7 @@ static int root_sync(sl3d_group *g)
 }
 
 extern "C" int sl3d_group_get_points(sl3d_group *g, int view, float *xyz, uint8_t *valid)
-{
+try {
     int rc = check_views(g, view, 1);
     if (rc || (rc = root_sync(g))) return rc;
     DeviceGuard dg(g->gpus[0].device);
@@ -471,6 +483,7 @@ extern "C" int sl3d_group_get_points(sl3d_group *g, int view, float *xyz, uint8_
     if (valid) GHIP(g, hipMemcpy2D(valid, W, g->d_valid + (size_t)view * g->px_view_stride, pitch, W, H, hipMemcpyDeviceToHost));
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 // The reference's consumer is the HOST (its results are host globals / a host PCL cloud: common_variables.h:12-21,56-62,
 // 8/save_point_cloud.cpp:85-104).  Every stripe copies its rows of every view straight into the caller's dense images, on its
@@ -478,7 +491,7 @@ extern "C" int sl3d_group_get_points(sl3d_group *g, int view, float *xyz, uint8_
 // destination memory (sl3d_host_alloc) makes the copies concurrent DMA; pageable memory works, serialised by the runtime.
 // Waits for the stripes' kernels of those views (stream order) and for the copies.
 extern "C" int sl3d_group_download_points(sl3d_group *g, int first, int n, float *xyz, uint8_t *valid)
-{
+try {
     int rc = check_views(g, first, n);
     if (rc) return rc;
     const size_t W = (size_t)g->cfg.width, H = (size_t)g->cfg.height;
@@ -510,6 +523,7 @@ extern "C" int sl3d_group_download_points(sl3d_group *g, int first, int n, float
     if (sync_rc != SL3D_OK) return gfail(g, sync_rc, "stripe " + std::to_string(sync_s) + ": " + sl3d_last_error(g->st[sync_s].ctx));
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 // sl3d_process_views for a group: every stripe runs the three-stream pipeline (upload of its rows of view k+1, fused kernel of
 // view k, download of view k-1 into the caller's dense images) on its own GPU; all pipelines are enqueued before any is waited
@@ -517,7 +531,7 @@ extern "C" int sl3d_group_download_points(sl3d_group *g, int first, int n, float
 // planes: n_views * planes_per_view pointers to WINDOW-sized planes (`stride` bytes per row), view-major, plane order of
 // sl3d_device_buffers.  Masks and calibration must be set (every slot < max_views).
 extern "C" int sl3d_group_process_views(sl3d_group *g, int n_views, const uint8_t *const *planes, size_t stride, float *xyz, uint8_t *valid)
-{
+try {
     if (!g || n_views < 1 || !planes) return gfail(g, SL3D_E_INVALID_ARG, "group_process_views: null argument");
     const size_t W = (size_t)g->cfg.width, H = (size_t)g->cfg.height;
     const size_t ppv = (size_t)g->st[0].ctx->P.planes_per_view, np = (size_t)n_views * ppv;
@@ -563,9 +577,10 @@ extern "C" int sl3d_group_process_views(sl3d_group *g, int n_views, const uint8_
     if (first_rc != SL3D_OK) return gfail(g, first_rc, first_err);
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_get_device_buffers(sl3d_group *g, sl3d_device_buffers *o)
-{
+try {
     if (!g || !o) return gfail(g, SL3D_E_INVALID_ARG, "null argument");
     memset(o, 0, sizeof *o);
     o->frame_pitch = (size_t)g->pitch;
@@ -577,9 +592,10 @@ extern "C" int sl3d_group_get_device_buffers(sl3d_group *g, sl3d_device_buffers 
     o->valid_view_stride = g->px_view_stride;
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_gather_clouds(sl3d_group *g, int first, int n, int64_t *counts)
-{
+try {
     int rc = check_views(g, first, n);
     if (rc) return rc;
     if (!g->d_cloud) {
@@ -612,9 +628,10 @@ extern "C" int sl3d_group_gather_clouds(sl3d_group *g, int first, int n, int64_t
     }
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_get_cloud(sl3d_group *g, int view, float *xyz, int64_t capacity, int64_t *count)
-{
+try {
     int rc = check_views(g, view, 1);
     if (rc) return rc;
     if (!count) return gfail(g, SL3D_E_INVALID_ARG, "null argument");
@@ -628,9 +645,10 @@ extern "C" int sl3d_group_get_cloud(sl3d_group *g, int view, float *xyz, int64_t
     }
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)
 
 extern "C" int sl3d_group_synchronize(sl3d_group *g)
-{
+try {
     if (!g) return SL3D_E_INVALID_ARG;
     for (size_t s = 0; s < g->st.size(); s++) GCTX(g, s, sl3d_synchronize(g->st[s].ctx));
     for (auto &u : g->gpus) {
@@ -640,3 +658,4 @@ extern "C" int sl3d_group_synchronize(sl3d_group *g)
     g->comm_busy = false;
     return SL3D_OK;
 }
+SL3D_GROUP_CATCH(g)

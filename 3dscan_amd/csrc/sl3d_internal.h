@@ -12,6 +12,7 @@
 #define SL3D_ATAN_T2 1021       // t2 = 2*I1 - I0 - I2 in [-510, 510]
 #define SL3D_MAX_GRAY 16
 #define SL3D_SEG_POINTS 256     // pixels (point slots) per segment of the segmented clouds = one wave of the fused kernel
+#define SL3D_SMALL_LAUNCH_VIEWS 4  // launches of at most this many views take the small-launch instantiation (sl3d_fused.h)
 
 namespace sl3d {
 
@@ -52,6 +53,9 @@ struct DevCal {
     double Rct[9], tcn[3];  // X = Rct*Y + tcn  (Rct = Rc^T, tcn = -Rc^T tc)
     double fx2, fy2;      // Kc[0]^2, Kc[1]^2 + Kc[4]^2
     double fxs;           // Kc[0]*Kc[1]: the skew term (0 for the usual K); the camera-frame form holds for any upper-triangular affine K
+    // camera table kind 3 (small launches, radial camera model): the factor of the last undistortion iteration minus 1 as
+    // t*(cam_poly[0] + t*(cam_poly[1] + t*cam_poly[2])), t = r0^2, plus an f32 residual per pixel (cam_poly_eval, sl3d_device.h)
+    double cam_poly[3];
 };
 
 // Scene + camera model of the synthetic-capture generator (k_synth).
@@ -71,6 +75,19 @@ struct MaskSrc {
     size_t stride;         // bytes between rows
     size_t view_stride;    // bytes between the masks of consecutive views of one call (0: every view gets the same mask)
     int bx0, bx1, r0, r1;  // plane bytes [bx0, bx1) x plane rows [r0, r1) hold source pixels: window + 2-pixel halo, clipped to the frame
+};
+
+// A MASKIN launch (k_fused with CMODE bit 4: the valid bits come from the raw selection -- H0 / S3b / S3d inside the fused kernel):
+// where the selection of view first_view + k lies (MaskSrc::origin of that view), the region of the plane that holds source bytes,
+// what may be read at all, and where every wave leaves {seq << 8 | quads with a valid pixel}.
+struct MaskIn {
+    uintptr_t origin[SL3D_SMALL_LAUNCH_VIEWS];
+    size_t stride;
+    int bx0, bx1, r0, r1;  // as in MaskSrc
+    int lo, hi;            // plane bytes [lo, hi) of a row may be READ (the staging plane: the whole row; a caller's mask: the frame's columns)
+    unsigned *part;        // host memory mapped into the device: [view][part_stride] words, one per wave that owns pixels
+    unsigned part_stride;
+    unsigned seq;
 };
 
 // Everything a kernel needs to address one context's buffers.
@@ -123,15 +140,27 @@ struct KParams {
     uint8_t *dbg4[2];
     int64_t *cpmap;            // [view][row][pitch][2]
     double *ipoints;           // [view][row][pitch][3]
+    // (appended in round 6: the fields above keep their kernel-argument offsets)
+    int cam_tab_f32;           // kind-1 table only: 1 = an f32 residual table [H][pitch] follows the doubles (camera table kind 3);
+                               // set to 2 per launch: this (small) launch reads it instead of the doubles
+    MaskIn mi;                 // MASKIN launches only (read through the kernel-argument segment, sl3d_fused.h: maskin_args)
 };
+static_assert(SL3D_SMALL_LAUNCH_VIEWS == 4, "KParams::mi_origin holds one entry per view of a small launch");
 
 // launchers (sl3d_fused_launch.hip, sl3d_kernels.hip); `stream` is a hipStream_t
 // cmode: 0 = dense xyz + valid planes, 2 = segmented clouds
-#define SL3D_SMALL_LAUNCH_VIEWS 4  // launches of at most this many views take the small-launch instantiation (sl3d_fused.h)
 // prefer_gated: the views of a small launch are sparsely selected (sl3d_capi.cpp: sparse_views)
-int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream, bool prefer_gated = false);
+// mi != nullptr: a MASKIN launch (the views' valid bits from their raw selection; only where fused_maskin_available says so)
+int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream, bool prefer_gated = false,
+                 const MaskIn *mi = nullptr);
 // the k_fused instantiation such a launch runs, as rocprofv3 spells it; returns snprintf's value
-int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap, bool prefer_gated = false);
+int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmode, char *buf, size_t cap, bool prefer_gated = false, bool maskin = false);
+// can a launch of n_views views of this context evaluate the selection itself?  (3-step fringes, a pipelined rig class, at most
+// SL3D_SMALL_LAUNCH_VIEWS views, up to 12 Gray planes per axis; not the parity mode)
+bool fused_maskin_available(const KParams &P, int rig, int n_views, bool keep);
+// words per view in MaskIn::part (one per wave of the small-launch grid) / how many of them belong to waves that own pixels
+unsigned fused_maskin_part_stride(const KParams &P);
+unsigned fused_maskin_part_words(const KParams &P);
 // segmented clouds: offsets / totals of views [first_view, first_view + n_views) from the counts the fused kernel stored
 int launch_seg_scan(const KParams &P, int first_view, int n_views, void *stream);
 // segments -> contiguous: view first_view+k's points to dst + 3*k*dst_view_stride_points (dst: device memory or mapped host memory)
@@ -169,7 +198,6 @@ int launch_undistort(const uint8_t *src, size_t sstride, uint8_t *dst, size_t ds
 int launch_undistort_planes(const uint8_t *src, size_t spitch, size_t splane, uint8_t *dst, size_t dpitch, size_t dplane, int width, int height,
                             int n_planes, const double K[9], const double dist[5], short *m1, unsigned short *m2, bool build_map, void *stream);
 int launch_pattern(uint8_t *dst, size_t pitch, int PW, int PH, int axis, const uint8_t *profile, void *stream);
-int launch_spin(int blocks, unsigned long long ticks_100mhz, void *stream);  // sl3d_prewarm
 int launch_atan_selfcheck(const float *tab_phi, const float *tab_shift, unsigned *mismatches, void *stream);
 
 }  // namespace sl3d

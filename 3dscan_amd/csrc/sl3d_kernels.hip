@@ -158,29 +158,6 @@ int launch_mask_prepare(const KParams &P, int first_view, int n_views, const Mas
     return (int)hipGetLastError();
 }
 
-// sl3d_prewarm: one wave per CU that does nothing but watch the constant-rate clock (100 MHz) until `ticks` have passed.  A GPU
-// that has idled for a second -- the reference's loop spends seconds projecting and capturing between two scans -- sits at its
-// lowest shader clock and takes milliseconds of activity to leave it; this is that activity, started while the scan's frames are
-// still on their way, on a stream of its own (it never sits in front of a context's own work).  Bounded: it ends by itself.
-__global__ __launch_bounds__(64) void k_spin(unsigned long long ticks, unsigned *sink)
-{
-    const unsigned long long t0 = wall_clock64();
-    unsigned acc = 0;
-    while (wall_clock64() - t0 < ticks) {
-#pragma unroll
-        for (int i = 0; i < 64; i++) acc = acc * 1664525u + 1013904223u;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (acc == 0x12345u && sink) *sink = acc;  // (never true in practice: keeps the arithmetic alive)
-}
-
-int launch_spin(int blocks, unsigned long long ticks, void *stream)
-{
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_spin, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, ticks, (unsigned *)nullptr);
-    return (int)hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------
 // staged kernels: one pixel per lane, stage boundaries as in the reference
 // ------------------------------------------------------------------------------------------------
@@ -334,8 +311,14 @@ __global__ __launch_bounds__(256) void k_cam_table(const KParams P, const DevCal
     double u, v, icd;
     undistort_normalized((double)(P.col0 + x), (double)(P.row0 + y), C->cam, u, v, &icd);
     const size_t i = (size_t)y * P.pitch + x;
-    if (kind == 1) out[i] = icd;
-    else {
+    if (kind == 1) {
+        out[i] = icd;
+        if (P.cam_tab_f32) {  // kind 3 beside it: the f32 residual of the factor against the per-calibration cubic in r0^2 (cam_poly_eval)
+            const Intr &I = C->cam;
+            const double x0 = ((double)(P.col0 + x) - I.cx) * I.ifx, y0 = ((double)(P.row0 + y) - I.cy) * I.ify;
+            ((float *)(out + P.px_view_stride))[i] = (float)((icd - 1.0) - cam_poly_eval(*C, x0, y0));
+        }
+    } else {
         out[2 * i] = u;
         out[2 * i + 1] = v;
     }

@@ -92,3 +92,38 @@ SL3D_MB_FN unsigned mb_valid(const MbRow r, unsigned L, unsigned OK_above, unsig
     const unsigned ok3 = OK_above & (OK_above << 1) & (OK_above >> 1);
     return r.V & (~r.INT | (~L & ok3 & (OK_row << 1)));
 }
+
+// ---- one quad per lane, one row per lane: the fused kernel's MASKIN launches (sl3d_fused.h) --------------------------------------------
+// A result bit depends on nothing beyond 2 columns either side (the recurrences above shift by at most one column twice), so a lane
+// that owns ONE quad needs 8 selection bytes per row -- plane bytes own-2 .. own+5 -- which arrive as ONE 8-byte load at own + delta:
+// delta = -2, or 0 / -4 where that load would begin before / end behind the readable part [lo, hi) of the row (the frame's first /
+// last quad of a caller's own device-resident mask; hi - lo >= 8).  The bytes that are then missing lie outside the frame.
+SL3D_MB_FN int mb_quad_delta(int own_byte0, int lo, int hi) { return own_byte0 - 2 < lo ? 0 : (own_byte0 + 6 > hi ? -4 : -2); }
+// the two dwords of that load -> the 12-bit row word (bit i = plane byte own - 4 + i; bits the load does not cover: 0)
+SL3D_MB_FN unsigned mb_quad_word(unsigned w0, unsigned w1, int delta)
+{
+    const unsigned b = mb_pack_nibble(mb_eq1_bytes(w0)) | (mb_pack_nibble(mb_eq1_bytes(w1)) << 4);  // bit i = plane byte own + delta + i
+    return (b << (4 + delta)) & 0xfffu;
+}
+// the lane's own dword / the one to its left / to its right out of the same load, as far as it covers them (the rest lies outside
+// every region: see mb_quad_delta) -- what the normalised 0/1 plane stores
+SL3D_MB_FN unsigned mb_quad_own(unsigned w0, unsigned w1, int delta) { return delta == 0 ? w0 : delta == -4 ? w1 : (w0 >> 16) | (w1 << 16); }
+SL3D_MB_FN unsigned mb_quad_left(unsigned w0, unsigned w1, int delta) { return delta == 0 ? 0u : delta == -4 ? w0 : w0 << 16; }
+SL3D_MB_FN unsigned mb_quad_right(unsigned w0, unsigned w1, int delta) { return delta == 0 ? w1 : delta == -4 ? 0u : w1 >> 16; }
+// does frame row gy - 2 matter to the quad's results?  Only through unselected FRAME-BORDER pixels (bu): all of the frame's first row, else
+// the frame's first / last column
+SL3D_MB_FN int mb_quad_top_needed(const MbCols c, int gy, int fullH)
+{
+    const int ty = gy - 2, inframe = ty >= 0 && ty < fullH, interior = ty >= 1 && ty <= fullH - 2;
+    const unsigned rowm = !inframe ? 0u : (interior ? (c.INF & ~c.INTC) : c.INF);
+    return (rowm & 0x3fcu) != 0u;
+}
+// valid bits (bit k = pixel k of the quad) of frame row gy from the row words of gy-2 (0 if not needed), gy-1, gy, gy+1 (each already
+// limited to the staged region)
+SL3D_MB_FN unsigned mb_quad_valid(unsigned Vtop, unsigned Vm1, unsigned V0, unsigned Vp1, const MbCols c, int gy, int fullH)
+{
+    const MbRow r0 = mb_row(Vtop, c, gy - 2, fullH), r1 = mb_row(Vm1, c, gy - 1, fullH), r2 = mb_row(V0, c, gy, fullH), r3 = mb_row(Vp1, c, gy + 1, fullH);
+    const unsigned L1 = mb_L(r1, r2), L2 = mb_L(r2, r3);
+    const unsigned OK1 = mb_OK(r1, L1, r0), OK2 = mb_OK(r2, L2, r1);
+    return (mb_valid(r2, L2, OK1, OK2) >> 4) & 0xfu;
+}

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SL3D_LIB") or os.path.join(_HERE, "libsl3d.so")
 
 SL3D_FLAG_KEEP_STAGES = 1
 SL3D_FLAG_GROUP_FORCE_RCCL, SL3D_FLAG_GROUP_NO_RCCL, SL3D_FLAG_GROUP_DISTINCT_SIDES = 2, 4, 16
+SL3D_FLAG_EAGER_MASK = 32
 AXIS_VERTICAL, AXIS_HORIZONTAL = 0, 1
 PATTERN_FRINGE, PATTERN_GRAY, PATTERN_INVERSE_GRAY, PATTERN_BINARY = 0, 1, 2, 3
 VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
@@ -22,7 +23,7 @@ ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
     "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_masks", "sl3d_set_mask_colrow", "sl3d_set_frames_range", "sl3d_get_global_colrow", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
-    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_last_fused_kernel_name", "sl3d_prewarm", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
+    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_last_fused_kernel_name", "sl3d_camera_table_bytes_per_pixel", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
     "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
@@ -89,7 +90,7 @@ def load_library(path=None):
     try:
         L.sl3d_set_masks.argtypes = [vp, i, i, vp, C.c_size_t, C.c_size_t]
         L.sl3d_last_fused_kernel_name.argtypes = [vp, C.c_char_p, C.c_size_t]
-        L.sl3d_prewarm.argtypes = [vp, C.c_float]
+        L.sl3d_camera_table_bytes_per_pixel.argtypes = [vp, i]
     except AttributeError:   # an older build of the library under SL3D_LIB (A/B runs against a previous round)
         if not os.environ.get("SL3D_LIB"):
             raise
@@ -185,12 +186,14 @@ class Scanner:
 
     def __init__(self, width, height, proj_width, proj_height, n_gray_v, n_gray_h, fringe_width_v, fringe_width_h,
                  n_fringe=3, n_codes_v=0, n_codes_h=0, max_views=1, device=0, keep_stages=False,
-                 full_size=None, origin=(0, 0), stream=None):
+                 full_size=None, origin=(0, 0), stream=None, eager_mask=False):
+        """eager_mask: SL3D_FLAG_EAGER_MASK -- every mask is prepared by k_mask_prepare when it is set; by default a timed context
+        defers masks of up to 4 views to the next launch over them (the fused kernel evaluates the selection itself)."""
         self.L = load_library()
         fw, fh = full_size if full_size else (width, height)
         self.cfg = Config(width, height, fw, fh, origin[0], origin[1], proj_width, proj_height, n_fringe,
                           n_gray_v, n_gray_h, fringe_width_v, fringe_width_h, n_codes_v, n_codes_h,
-                          max_views, device, SL3D_FLAG_KEEP_STAGES if keep_stages else 0, stream)
+                          max_views, device, (SL3D_FLAG_KEEP_STAGES if keep_stages else 0) | (SL3D_FLAG_EAGER_MASK if eager_mask else 0), stream)
         self.W, self.H = width, height
         self._h = C.c_void_p()
         rc = self.L.sl3d_create(C.byref(self.cfg), C.byref(self._h))
@@ -415,6 +418,15 @@ class Scanner:
         self._chk(self.L.sl3d_fused_kernel_name(self._h, n_views, 1 if clouds else 0, buf, len(buf)), "sl3d_fused_kernel_name")
         return buf.value.decode()
 
+    def camera_table_bytes_per_pixel(self, n_views=1):
+        """Bytes per pixel a launch of n_views views reads from the camera-side table (once per launch); None with a build that cannot say."""
+        if not hasattr(self.L, "sl3d_camera_table_bytes_per_pixel"):
+            return None
+        n = self.L.sl3d_camera_table_bytes_per_pixel(self._h, n_views)
+        if n < 0:
+            self._chk(n, "sl3d_camera_table_bytes_per_pixel")
+        return n
+
     def last_fused_kernel_name(self):
         """The k_fused instantiation the last fused launch of this context ran."""
         if os.environ.get("SL3D_LIB") and not hasattr(self.L, "sl3d_last_fused_kernel_name"):
@@ -422,9 +434,6 @@ class Scanner:
         buf = C.create_string_buffer(256)
         self._chk(self.L.sl3d_last_fused_kernel_name(self._h, buf, len(buf)), "sl3d_last_fused_kernel_name")
         return buf.value.decode()
-
-    def prewarm(self, ms):
-        self._chk(self.L.sl3d_prewarm(self._h, ms), "sl3d_prewarm")
 
     def run_timed(self, first_view=0, n_views=1):
         ms = C.c_float(0)

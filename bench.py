@@ -265,7 +265,9 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
         alg = 20 + 4 * N
         # what this launch really moves: the camera-side table (8 B/px for the radial model of the reference rig, 16 with tangential
         # terms) is read once per LAUNCH, and nothing amortises it when a launch is one view
-        tab = 8 if args.rig in ("reference", "radial") else 16
+        tab = sc.camera_table_bytes_per_pixel(1)   # (4 since round 6: the small-launch form of a radial table; 16 with tangential terms)
+        if tab is None:
+            tab = 8 if args.rig in ("reference", "radial") else 16
         moved = alg + tab
         return {"value": round(W * H / ms / 1e3, 1), "unit": "Mpixels/s", "launch_us": round(ms * 1e3, 2), "kernel": sc.fused_kernel_name(1, clouds=clouds),
                 "frac": round(alg * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": alg,
@@ -275,12 +277,13 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
                         f"> 256 MiB Infinity Cache): the frames come from HBM"}
 
 
-def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=False):
+def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=False, eager=False):
     """What ONE iteration of the reference's scan loop costs on the device once the frames are resident (m_tech_project_console.cpp:
-    366-395): a NEW selection mask (image_scissor's result, here already in device memory: no PCIe in this figure) prepared by
-    k_mask_prepare (H0 / S3b / S3d: 3/wrapped_phase.cpp:106-115, :253-279) and then ONE one-view launch of the fused kernel, a
-    different resident view and a different mask every scan (frames from HBM, as in one_view_cold).  HIP events on the context's
-    stream around `scans` such pairs; mask_us = the same loop with the mask preparation alone."""
+    366-395): a NEW selection mask (image_scissor's result, here already in device memory: no PCIe in this figure) and ONE one-view
+    launch, a different resident view and a different mask every scan (frames from HBM, as in one_view_cold).  HIP events on the
+    context's stream around `scans` such scans.  Default route (since round 6): ONE launch -- the fused kernel evaluates the selection
+    itself (H0 / S3b / S3d: 3/wrapped_phase.cpp:106-115, :253-279 inside k_fused, a MASKIN launch).  eager: the two-kernel route of
+    SL3D_FLAG_EAGER_MASK (k_mask_prepare, then the fused kernel); mask_us = that loop with the mask preparation alone."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
     V = max(2, args.cold_views)
     rng = np.random.default_rng(5)
@@ -289,7 +292,7 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
         ys, xs = rng.integers(8, H - 8, 12), rng.integers(8, W - 8, 12)
         for y, x in zip(ys, xs):
             masks[v, y:y + 3, x:x + 5] = 0
-    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index) as sc:
+    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index, eager_mask=eager) as sc:
         sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
         d_masks = torch.from_numpy(masks).to(torch.device("cuda", dev_index))
         torch.cuda.synchronize()
@@ -315,6 +318,17 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
             scan(i)
         us = sc.timer_stop() / scans * 1e3
         kernel = sc.last_fused_kernel_name()
+        alg = 20 + 4 * N
+        out = {"scan_us": round(us, 2), "value": round(W * H / us, 1), "unit": "Mpixels/s",
+               "frac": round(alg * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernel": kernel, "resident_views": V, "scans": scans}
+        if not eager:
+            out["launches_per_scan"] = 1
+            out["note"] = ("per scan: sl3d_set_masks on a device-resident mask (recorded, nothing launched) + sl3d_run" + ("_clouds" if clouds else "") +
+                           " of ONE view, a different view and mask each scan: ONE kernel, which evaluates the selection (the boundary removal of "
+                           "stage 3 included) itself and leaves the band / 0-1 planes and the quad count k_mask_prepare would have left; frac = the "
+                           "launch's algorithmic bytes (60 B/px) over its time")
+            out["two_kernel_route"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=scans, clouds=clouds, eager=True)
+            return out
         sc.timer_start()
         for i in range(scans):
             sc.set_masks_device(ptr + ((i + 3) % V) * vs, W, 0, i % V, 1)
@@ -323,17 +337,14 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
         for i in range(scans // 8):
             sc.set_masks_device(ptr, W, vs, 0, V)
         batch_us = sc.timer_stop() / (scans // 8) * 1e3
-        alg = 20 + 4 * N
         mask_bytes = W * H + (W + 32) * (H + 4) + W * H      # read the mask, write the 0/1 plane with its halo and the valid-byte plane
-        return {"scan_us": round(us, 2), "mask_us": round(mask_us, 2), "masks_of_%d_views_one_launch_us" % V: round(batch_us, 2),
-                "value": round(W * H / us, 1), "unit": "Mpixels/s", "frac": round(alg * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                "mask_kernel": {"kernel": "sl3d::k_mask_prepare<4, 16, 64>" if ((W + 15) // 16 * 16) * H > (6 << 20) else "sl3d::k_mask_prepare<4, 4, 256>",
-                                "algorithmic_bytes": mask_bytes,
-                                "frac": round(mask_bytes / (mask_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
-                "kernel": kernel, "resident_views": V, "scans": scans,
-                "note": "per scan: sl3d_set_masks on a device-resident mask (no copy: the kernel reads the caller's buffer) + sl3d_run"
-                        + ("_clouds" if clouds else "") + " of ONE view, a different view and mask each scan; frac = the fused kernel's algorithmic "
-                        "bytes over the time of BOTH kernels"}
+        out.update({"launches_per_scan": 2, "mask_us": round(mask_us, 2), "masks_of_%d_views_one_launch_us" % V: round(batch_us, 2),
+                    "mask_kernel": {"kernel": "sl3d::k_mask_prepare<4, 16, 64>" if ((W + 15) // 16 * 16) * H > (6 << 20) else "sl3d::k_mask_prepare<4, 4, 256>",
+                                    "algorithmic_bytes": mask_bytes,
+                                    "frac": round(mask_bytes / (mask_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "note": "SL3D_FLAG_EAGER_MASK (the route up to round 5): k_mask_prepare + the fused kernel per scan; frac = the fused kernel's "
+                            "algorithmic bytes over the time of BOTH kernels"})
+        return out
 
 
 def one_scan_from_idle(args, scm, syn, np, dev_index):
@@ -343,7 +354,6 @@ def one_scan_from_idle(args, scm, syn, np, dev_index):
       resident     : a new pinned mask (sl3d_set_mask) + one one-view launch on frames that are already in HBM
       with_upload  : the Level-2 call as a caller of sl3d.h makes it -- the view's 46 frames from pinned memory (2 x sl3d_set_frames),
                      the mask, the launch
-      ..._prewarm  : the same with sl3d_prewarm(3 ms) in front: the clocks rise under the upload
     median and p90 over `--idle-samples` samples each; `steady` = the same calls back to back (no sleep)."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
     n, nap = max(3, args.idle_samples), args.idle_sleep
@@ -361,10 +371,8 @@ def one_scan_from_idle(args, scm, syn, np, dev_index):
         pv[:], ph[:] = np.stack(fv), np.stack(fh)
         lv, lh = list(pv), list(ph)
 
-        def scan(upload, clouds, warm):
+        def scan(upload, clouds):
             t0 = time.perf_counter()
-            if warm:
-                sc.prewarm(3.0)
             sc.timer_start()
             if upload:
                 sc.set_frames(0, lv, view=0)
@@ -374,24 +382,23 @@ def one_scan_from_idle(args, scm, syn, np, dev_index):
             dev_ms = sc.timer_stop()
             return dev_ms * 1e3, (time.perf_counter() - t0) * 1e6
 
-        def series(upload, clouds, warm, pause):
+        def series(upload, clouds, pause):
             dev, host = [], []
             for _ in range(n):
                 if pause:
                     sc.synchronize()
                     time.sleep(pause)
-                d, h = scan(upload, clouds, warm)
+                d, h = scan(upload, clouds)
                 dev.append(d)
                 host.append(h)
             dev.sort(); host.sort()
             return {"device_us": {"median": round(dev[n // 2], 1), "p90": round(dev[(9 * n) // 10], 1)},
                     "host_us": {"median": round(host[n // 2], 1), "p90": round(host[(9 * n) // 10], 1)}}
 
-        for key, (upload, clouds, warm) in (("resident", (False, False, False)), ("resident_clouds", (False, True, False)),
-                                            ("with_upload", (True, False, False)), ("with_upload_prewarm", (True, False, True))):
+        for key, (upload, clouds) in (("resident", (False, False)), ("resident_clouds", (False, True)), ("with_upload", (True, False))):
             for _ in range(3):
-                scan(upload, clouds, False)
-            out[key] = {"steady": series(upload, clouds, False, 0.0), "from_idle": series(upload, clouds, warm, nap)}
+                scan(upload, clouds)
+            out[key] = {"steady": series(upload, clouds, 0.0), "from_idle": series(upload, clouds, nap)}
             s, i = out[key]["steady"]["device_us"]["median"], out[key]["from_idle"]["device_us"]["median"]
             out[key]["idle_penalty"] = round(i / s, 2) if s > 0 else None
     return out

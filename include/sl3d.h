@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL3D_VERSION_STRING "0.4.0"
+#define SL3D_VERSION_STRING "0.5.0"
 
 typedef struct sl3d_ctx sl3d_ctx;
 
@@ -41,7 +41,8 @@ enum sl3d_status {
     SL3D_E_HIP = -3,         /* a HIP runtime call failed; see sl3d_last_error() */
     SL3D_E_STATE = -4,       /* call order violated (e.g. triangulate before set_calibration) */
     SL3D_E_UNSUPPORTED = -5,
-    SL3D_E_NOMEM = -6
+    SL3D_E_NOMEM = -6,       /* device or host memory exhausted */
+    SL3D_E_INTERNAL = -7     /* a C++ exception was stopped at the boundary (no exception ever crosses this C ABI); see sl3d_last_error() */
 };
 
 /* pattern_type of the reference: 0 = vertical stripes (encode the projector COLUMN),
@@ -65,7 +66,12 @@ enum sl3d_flags {
      * (stream, event, communicator rank) even where devices repeat, so that the code paths of a stripe on ANOTHER GPU than the
      * root's -- peer copies, the waits between the sides' streams, an N-rank exchange -- run with all stripes on one device.
      * With RCCL this needs a communicator that accepts repeated devices (the test double bound through SL3D_RCCL_LIB). */
-    SL3D_FLAG_GROUP_DISTINCT_SIDES = 16u
+    SL3D_FLAG_GROUP_DISTINCT_SIDES = 16u,
+    /* A context without KEEP_STAGES normally DEFERS the preparation of a selection mask handed over for at most 4 views: the next
+     * sl3d_run / sl3d_run_clouds over exactly such views evaluates the selection inside the fused kernel itself (new mask + one view
+     * = ONE launch, the reference's per-scan call shape), any other consumer prepares it first.  With this flag every mask is prepared
+     * by its own kernel when it is set (the behaviour up to 0.4; A/B measurements). */
+    SL3D_FLAG_EAGER_MASK = 32u
     /* (8u was SL3D_FLAG_CLOUDS_LOOKBACK until 0.3: contiguous clouds in one pass by a decoupled look-back between tiles.  Removed
      * in 0.4 -- every tile waited for its predecessors, 0.53 of the roofline against 0.67 for the segmented clouds; a consumer
      * that wants one contiguous device array asks sl3d_get_cloud_counts for it.) */
@@ -159,9 +165,10 @@ int sl3d_set_mask(sl3d_ctx *ctx, int view, const uint8_t *full_frame_mask, size_
 /* The same for n_views views [first_view, first_view + n_views) with ONE kernel launch: the mask of view first_view + k starts at
  * full_frame_masks + k * view_stride; view_stride == 0 hands every view the same mask (one copy, one launch).
  * The masks may also live in DEVICE memory of the context's GPU (an acquisition stage that segments on the GPU, a benchmark): with
- * 4-byte aligned rows (pointer, stride, view_stride, col0 and full_width multiples of 4) nothing is copied -- the kernel reads the
- * caller's buffer, which must stay unchanged until the stream has passed the call; otherwise the rows go through the staging
- * plane by a device copy.  This is the per-scan device cost of image_scissor()'s result (m_tech_project_console.cpp:366) + stage
+ * 4-byte aligned rows (pointer, stride, view_stride, col0 and full_width multiples of 4) nothing is copied -- the kernels read the
+ * caller's buffer, which must stay unchanged until the next synchronising call on the context (any getter, sl3d_synchronize),
+ * like pinned host memory: with at most 4 views per call the selection is evaluated by the next launch over those views
+ * (SL3D_FLAG_EAGER_MASK); otherwise the rows go through the staging plane by a device copy.  This is the per-scan device cost of image_scissor()'s result (m_tech_project_console.cpp:366) + stage
  * 3's boundary removal (3/wrapped_phase.cpp:253-279): bench.py `side.per_scan_device`. */
 int sl3d_set_masks(sl3d_ctx *ctx, int first_view, int n_views, const uint8_t *full_frame_masks, size_t stride, size_t view_stride);
 
@@ -262,12 +269,11 @@ int sl3d_fused_kernel_name(sl3d_ctx *ctx, int n_views, int clouds, char *buf, si
  * choice is recorded when the launch is made -- it depends on what was known about the views' masks at that moment (a small
  * launch over sparsely selected views takes another kernel), so a later prediction could name a different one. */
 int sl3d_last_fused_kernel_name(sl3d_ctx *ctx, char *buf, size_t capacity);
-/* Wake the GPU up ahead of a scan.  The reference's loop projects and captures ~46 frames between two scans
- * (m_tech_project_console.cpp:331-401): seconds in which the GPU drops to its idle clocks, and the first launches after that run
- * several times slower than the steady-state figures.  sl3d_prewarm starts `ms` milliseconds (at most 20) of trivial activity on a
- * stream of its own and returns at once; called when a scan's frames start to arrive (the upload of 46 frames takes ~2 ms), the
- * clocks are up by the time the fused kernel is launched.  Nothing of the context waits for it. */
-int sl3d_prewarm(sl3d_ctx *ctx, float ms);
+/* Bytes per camera pixel a fused launch of n_views views reads from the camera-side table of sl3d_set_calibration (T1 per window pixel,
+ * 7/triangulation.cpp:252-307), once per LAUNCH whatever the number of views: 0 = no table (no camera distortion, parity mode),
+ * 8 = the radial factor as a double, 4 = its small-launch form (a per-calibration cubic in r0^2 + one float per pixel), 16 = the
+ * normalised point (tangential terms).  Benchmarks state the bytes a launch moves beside the algorithmic ones with it.  < 0: error. */
+int sl3d_camera_table_bytes_per_pixel(sl3d_ctx *ctx, int n_views);
 /* sl3d_run bracketed by HIP events on the context's stream; returns the kernel time of this launch */
 int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);
 int sl3d_synchronize(sl3d_ctx *ctx);

@@ -104,3 +104,70 @@ int emul_check_byte_helpers(void)
             }
     return 0;
 }
+
+/* CPU emulation of a MASKIN launch's mask evaluation (3dscan_amd/csrc/sl3d_fused.h: maskin_lane / maskin_request / maskin_finish): one
+ * lane per quad and window row, the 8-byte row loads with their delta, the rows y-2 / y+2 asked for only where they matter, the halo
+ * duties of the window's first / last row and quad -- through the shared header's mb_quad_* functions.  direct = 0: the source is the
+ * staging plane (as emul_mask_prepare builds it); direct = 1: the caller's own full-frame mask is read in place (needs col0, fullW and
+ * stride multiples of 4, fullW >= 8), and every byte read must lie inside the mask (returns -1 - <count of bytes read outside>).
+ * Outputs as emul_mask_prepare; returns the quads with a valid pixel. */
+static long g_oob;
+static void load8(const uint8_t *base, long off, const uint8_t *lo, const uint8_t *hi, unsigned *w0, unsigned *w1)
+{
+    const uint8_t *p = base + off;
+    if (p < lo || p + 8 > hi) { g_oob += 1; *w0 = *w1 = 0; return; }
+    memcpy(w0, p, 4);
+    memcpy(w1, p + 4, 4);
+}
+
+long emul_maskin(const uint8_t *mask, size_t stride, int fullW, int fullH, int col0, int row0, int W, int H, int direct, uint8_t *norm, uint8_t *band)
+{
+    const int pitch = (W + 15) & ~15, mpitch = pitch + 2 * LPAD, rows = H + 2 * HALO;
+    uint8_t *raw = (uint8_t *)calloc((size_t)mpitch * rows + 32, 1);
+    const int gy0 = row0 - HALO < 0 ? 0 : row0 - HALO, gy1 = row0 + H + HALO > fullH ? fullH : row0 + H + HALO;
+    const int gx0 = col0 - HALO < 0 ? 0 : col0 - HALO, gx1 = col0 + W + HALO > fullW ? fullW : col0 + W + HALO;
+    const int bx0 = LPAD + gx0 - col0, bx1 = LPAD + gx1 - col0, r0 = gy0 - row0 + HALO, r1 = gy1 - row0 + HALO;
+    for (int gy = gy0; gy < gy1; gy++) memcpy(raw + (size_t)(gy - row0 + HALO) * mpitch + bx0, mask + (size_t)gy * stride + gx0, (size_t)(gx1 - gx0));
+    /* the kernel's view of the source: origin = address of plane row 0, byte 0 */
+    const uint8_t *origin = direct ? mask + ((long)row0 - HALO) * (long)stride + col0 - LPAD : raw;
+    const long sstride = direct ? (long)stride : mpitch;
+    const int lo = direct ? LPAD - col0 : 0, hi = direct ? LPAD - col0 + fullW : mpitch;
+    const uint8_t *mem_lo = direct ? mask : raw, *mem_hi = direct ? mask + (size_t)(fullH - 1) * stride + fullW : raw + (size_t)mpitch * rows;
+    g_oob = 0;
+    long quads = 0;
+    /* planes the kernel never writes stay what the context's creation left them: zero */
+    memset(norm, 0, (size_t)mpitch * rows);
+    for (int row = 0; row < H; row++)
+        for (int cq = 0; cq < pitch / 4; cq++) {
+            const int own = LPAD + cq * 4;
+            const MbCols c = mb_cols(own, 4, col0, LPAD, fullW, bx0, bx1);
+            const int delta = mb_quad_delta(own, lo, hi), gy = row0 + row;
+            unsigned w[5][2];   /* plane rows row .. row + 4 (window rows y-2 .. y+2) */
+            int have[5] = {0, 1, 1, 1, 0};
+            const int first = row == 0, last = row == H - 1;
+            if (first || mb_quad_top_needed(c, gy, fullH)) have[0] = 1;
+            if (last) have[4] = 1;
+            for (int a = 0; a < 5; a++) {
+                w[a][0] = w[a][1] = 0;
+                const int pr = row + a;
+                if (have[a] && pr >= r0 && pr < r1 && (c.REG & 0x0f0u)) load8(origin, (long)pr * sstride + own + delta, mem_lo, mem_hi, &w[a][0], &w[a][1]);
+            }
+            unsigned V[4];
+            for (int a = 0; a < 4; a++) V[a] = (a == 0 && !have[0]) ? 0u : (mb_quad_word(w[a][0], w[a][1], delta) & c.REG);
+            unsigned outw = mb_range_bits(0, W, cq * 4, 4);
+            const unsigned v = mb_quad_valid(V[0], V[1], V[2], V[3], c, gy, fullH) & outw;
+            const unsigned vb = mb_expand_nibble(v);
+            memcpy(band + (size_t)row * pitch + (size_t)cq * 4, &vb, 4);
+            quads += v != 0;
+            for (int a = 0; a < 5; a++) {
+                if (!(a == 2 || (first && a < 2) || (last && a > 2))) continue;
+                uint8_t *q = norm + (size_t)(row + a) * mpitch + own;
+                unsigned o = mb_eq1_bytes(mb_quad_own(w[a][0], w[a][1], delta)) & (mb_expand_nibble(c.REG >> 4) * 0xffu);
+                memcpy(q, &o, 4);
+                if (cq == 0) { o = mb_eq1_bytes(mb_quad_left(w[a][0], w[a][1], delta)) & (mb_expand_nibble(c.REG) * 0xffu); memcpy(q - 4, &o, 4); }
+                if (cq == pitch / 4 - 1) { o = mb_eq1_bytes(mb_quad_right(w[a][0], w[a][1], delta)) & (mb_expand_nibble(c.REG >> 8) * 0xffu); memcpy(q + 4, &o, 4); }
+            }
+        }
+    free(raw);
+    return g_oob ? -1 - g_oob : quads;
+}
