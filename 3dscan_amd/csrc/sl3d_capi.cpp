@@ -357,58 +357,6 @@ static void fill_intr(Intr &I, const double K[9], const double d[5])
     I.identity = (I.plain && !I.has_dist) ? 1 : 0;
 }
 
-// Camera table kind 3 (cam_poly_eval, sl3d_device.h): the cubic t*(c0 + t*(c1 + t*c2)) closest to s(t) = (factor of the last of
-// cvUndistortPoints' 5 iterations) - 1 of a purely radial model over t = r0^2 in [0, tmax] -- least squares on Chebyshev nodes, in
-// the scaled variable u = t / tmax.  Returns the largest |s - cubic| seen on a 4x finer grid: what the f32 residual table will hold.
-static double fit_cam_poly(const Intr &I, double tmax, double c[3])
-{
-    auto s_of = [&](double t0) {
-        double r2 = t0, icd = 1.0;
-        for (int j = 0; j < 5; j++) {
-            icd = 1.0 / (1.0 + ((I.k3 * r2 + I.k2) * r2 + I.k1) * r2);
-            r2 = t0 * icd * icd;
-        }
-        return icd - 1.0;
-    };
-    const int M = 64;
-    double A[3][3] = {{0}}, b[3] = {0};
-    for (int i = 0; i < M; i++) {
-        const double u = 0.5 - 0.5 * std::cos(M_PI * (i + 0.5) / M), y = s_of(u * tmax);
-        const double phi[3] = {u, u * u, u * u * u};
-        for (int r = 0; r < 3; r++) {
-            for (int q = 0; q < 3; q++) A[r][q] += phi[r] * phi[q];
-            b[r] += phi[r] * y;
-        }
-    }
-    for (int k = 0; k < 3; k++) {  // 3x3 Gauss elimination with partial pivoting
-        int piv = k;
-        for (int r = k + 1; r < 3; r++)
-            if (std::fabs(A[r][k]) > std::fabs(A[piv][k])) piv = r;
-        std::swap(b[k], b[piv]);
-        for (int q = 0; q < 3; q++) std::swap(A[k][q], A[piv][q]);
-        if (A[k][k] == 0.0) return HUGE_VAL;
-        for (int r = k + 1; r < 3; r++) {
-            const double f = A[r][k] / A[k][k];
-            for (int q = k; q < 3; q++) A[r][q] -= f * A[k][q];
-            b[r] -= f * b[k];
-        }
-    }
-    double a[3];
-    for (int k = 2; k >= 0; k--) {
-        double acc = b[k];
-        for (int q = k + 1; q < 3; q++) acc -= A[k][q] * a[q];
-        a[k] = acc / A[k][k];
-    }
-    c[0] = a[0] / tmax; c[1] = a[1] / (tmax * tmax); c[2] = a[2] / (tmax * tmax * tmax);
-    double worst = 0.0;
-    for (int i = 0; i <= 4 * M; i++) {
-        const double t = tmax * i / (4.0 * M);
-        const double r = s_of(t) - t * ((c[2] * t + c[1]) * t + c[0]);
-        if (!(std::fabs(r) <= worst)) worst = std::fabs(r);  // (NaN counts as infinitely bad)
-    }
-    return worst;
-}
-
 extern "C" int sl3d_set_calibration(sl3d_ctx *x, const double Kc[9], const double dc[5], const double rc[3], const double tc[3],
                                     const double Kp[9], const double dp[5], const double rp[3], const double tp[3])
 try {
@@ -465,28 +413,9 @@ try {
     x->P.proj_rad = nullptr;
     x->P.cam_tab = nullptr;
     x->P.cam_tab_kind = 0;
-    x->P.cam_tab_f32 = 0;
     if (!x->keep && x->C.cam.has_dist) {  // timed mode: T1 of the camera per window pixel (k_cam_table)
         const int kind = x->C.cam.has_tan ? 2 : 1;
-        // kind 1: px_view_stride doubles, and behind them as many floats (kind 3, the table of small launches)
-        const size_t want = (size_t)kind * x->P.px_view_stride + (kind == 1 ? (x->P.px_view_stride + 1) / 2 : 0);
-        if (kind == 1 && x->P.F == 3) {
-            // r0^2 is convex in the pixel: its maximum over the window is at a corner
-            const Intr &I = x->C.cam;
-            double tmax = 0.0;
-            for (int k = 0; k < 4; k++) {
-                const double x0 = ((double)(x->P.col0 + (k & 1 ? x->P.pitch - 1 : 0)) - I.cx) * I.ifx;
-                const double y0 = ((double)(x->P.row0 + (k & 2 ? x->P.H - 1 : 0)) - I.cy) * I.ify;
-                tmax = std::max(tmax, x0 * x0 + y0 * y0);
-            }
-            double c[3] = {0, 0, 0};
-            const double worst = tmax > 0.0 ? fit_cam_poly(I, tmax, c) : HUGE_VAL;
-            if (worst <= 1.0 / 1024.0) {  // an f32 residual of at most 2^-10 is rounded by at most 2^-35
-                memcpy(x->C.cam_poly, c, sizeof c);
-                x->P.cam_tab_f32 = 1;
-                HIPCHK(x, hipMemcpy(x->d_cal, &x->C, sizeof(DevCal), hipMemcpyHostToDevice));
-            }
-        }
+        const size_t want = (size_t)kind * x->P.px_view_stride;
         if (!x->d_cam_tab || x->cam_tab_doubles < want) {
             if (x->d_cam_tab) {  // a radial-only table that has to grow into a two-double one (no launch reads it: synchronised above)
                 (void)hipFree(x->d_cam_tab);
@@ -659,6 +588,7 @@ static int prepare_masks(sl3d_ctx *x, int first_view, int n_views, const MaskSrc
     for (int v = first_view; v < first_view + n_views; v++) {
         x->quad_seq[v] = seq;
         x->quad_src[v] = v;
+        x->quad_kind[v] = 0;
     }
     return launched(x, launch_mask_prepare(x->P, first_view, n_views, S, x->d_quad_part, seq, x->stream));
 }
@@ -763,7 +693,9 @@ try {
     MaskSrc S;
     const MaskRegion g = mask_region(P, S);
     int dev = -1;
-    const int kind = memory_kind(m, &dev);
+    // (what kind of memory: asked at the first byte that is READ -- of a window below the frame's first rows the mask's nominal
+    // origin `m` may lie in front of the caller's allocation, in somebody else's or in none)
+    const int kind = memory_kind(m + (size_t)g.gy0 * stride + (size_t)g.gx0, &dev);
     const int distinct = view_stride ? n_views : 1;
     // dwords of a row must neither straddle the row's end nor start off a 4-byte boundary
     const bool direct = kind == 2 && dev == x->cfg.device && ((uintptr_t)m & 3u) == 0 && (stride & 3u) == 0 && (view_stride & 3u) == 0 && (P.col0 & 3) == 0 &&
@@ -1165,12 +1097,8 @@ try {
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     if (!x->P.cam_tab) return 0;
     if (x->P.cam_tab_kind == 2) return 16;
-    char name[256];
-    const bool gated = n_views <= x->cfg.max_views && sparse_views(x, 0, n_views);
-    (void)fused_kernel_name(x->P, x->rig, n_views, x->keep, 0, name, sizeof name, gated);
-    // (kind 3 is read by the small-launch instantiations -- k_fused<..., false, EARLY> -- where the calibration offers it: launch_fused)
-    const bool small = strstr(name, ", false, true>") || strstr(name, ", false, false>");
-    return small && x->P.cam_tab_f32 ? 4 : 8;
+    (void)n_views;
+    return 8;
 }
 SL3D_CATCH(x)
 

@@ -305,23 +305,6 @@ __device__ __forceinline__ double radial_factor_m1(double r0sq, const IntrT &I)
     return icd - 1.0;
 }
 
-// Camera table kind 3 (small launches): for a purely radial model the factor of the last undistortion iteration is a smooth function
-// of t = r0^2 alone; s(t) = factor - 1 = t*(c0 + t*(c1 + t*c2)) + residual, the cubic fitted per calibration on the host
-// (sl3d_set_calibration), the residual (<= 2^-10, else the kind is not offered) tabulated per pixel as ONE float by k_cam_table --
-// 4 B/px instead of the 8 of the factor itself, and its f32 rounding (<= 2^-35) is 2e-11 of the normalised coordinate where a plain
-// f32 factor (or f32 factor - 1: 2e-9) showed up as 2.7e-6 on ill-conditioned pixels (round 2).  Builder and kernel share this
-// function, so the kernel adds the residual to the very double it was taken from.
-template <typename CalT>
-__device__ __forceinline__ double cam_poly_eval(const CalT &C, double x0, double y0)
-{
-#ifdef SL3D_CAMF32_PLAIN /* (A/B only: the residual table holds factor - 1 itself, no cubic -- the cheapest 4-byte form, 2e-9 of rounding) */
-    return 0.0;
-#else
-    const double t = fma(x0, x0, y0 * y0);
-    return t * fma(fma(C.cam_poly[2], t, C.cam_poly[1]), t, C.cam_poly[0]);
-#endif
-}
-
 // s(r0^2) from a radial table (RadEntry, here in LDS): the node nearest to r0^2 * scale, one 16-byte read, one float FMA + multiply,
 // one double add.  The node coordinate t and the distance w to the node are formed in fp64 (r0^2 is a double anyway): in fp32, t up
 // to 255 carries 1.5e-5 node spacings of rounding error into w, i.e. ~1e-9 |k1| into s -- several times the interpolation remainder

@@ -201,21 +201,13 @@ struct Item {
 // the camera-table entries of the lane's 4 pixels: kind 1 = one double per pixel (factor of the last undistortion iteration of a
 // radial model), kind 2 = the normalised point itself (tangential terms).  Request and use are separate so that the small-launch
 // instantiation can put its plane requests in between.
-// F32 (the small-launch instantiations only: the large-launch kernels are instruction for instruction what they were): the launch
-// may ask for kind 3 instead of kind 1 (KParams::cam_tab_f32 == 2) -- ONE float per pixel, the residual of the radial factor
-// against the per-calibration cubic in r0^2 (cam_poly_eval): 4 B/px instead of 8 where nothing amortises the table (a one-view
-// launch moves 64 instead of 68 B/px).  Its four floats travel in `tf`, apart from t[] (a third way into the same array made the
-// optimiser merge the paths' stores into one with a run-time index: the array went to scratch).
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <bool F32>
-__device__ __forceinline__ void cam_table_request(const KParams &P, const Item &it, double (&t)[8], f32x4_t &tf)
+// KIND2 = false (the MASKIN instantiations): the two-double kind is not compiled in -- its 16 registers between request and use are
+// what the launch's mask words live in; a calibration with tangential camera terms keeps the two-kernel route (fused_maskin_available).
+template <bool KIND2 = true>
+__device__ __forceinline__ void cam_table_request(const KParams &P, const Item &it, double (&t)[8])
 {
     const size_t i0 = (size_t)it.row * P.pitch + (size_t)it.cq * 4;
-    if (F32 && P.cam_tab_f32 == 2) {
-        tf = *(const f32x4_t *)((const float *)(P.cam_tab + P.px_view_stride) + i0);
-        return;
-    }
-    if (P.use_cam_table == 1) {
+    if (!KIND2 || P.use_cam_table == 1) {
         const double2 *tp = (const double2 *)(P.cam_tab + i0);
         const double2 a = tp[0], b = tp[1];
         t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
@@ -229,25 +221,11 @@ __device__ __forceinline__ void cam_table_request(const KParams &P, const Item &
 // table entries -> the camera coordinates stage 7 uses (normalised for the camera-frame rigs, re-projected pixels for RIG 0), kept
 // in LDS so that the rolled pixel loops can index them (each lane reads back only what it wrote: no barrier).  The doubles are the
 // ones the in-kernel iteration produces.
-template <int RIG, bool F32>
-__device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal *Cglobal, const Item &it, const double (&t)[8], const f32x4_t &tf, double *my_cam)
+template <int RIG, bool KIND2 = true>
+__device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal *Cglobal, const Item &it, const double (&t)[8], double *my_cam)
 {
     const auto &I = opaque_const(Cglobal)->cam;
-    if (F32 && P.cam_tab_f32 == 2) {
-        const double y0 = ((double)it.gy - I.cy) * I.ify;
-        const float res[4] = {tf.x, tf.y, tf.z, tf.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double x0 = (((double)(it.gx0 + k)) - I.cx) * I.ifx;
-            const double icd = 1.0 + (cam_poly_eval(*opaque_const(Cglobal), x0, y0) + (double)res[k]);
-            double xn = x0 * icd, yn = y0 * icd;
-            if (RIG == 0) reproject(xn, yn, I, xn, yn);
-            my_cam[2 * k] = xn;
-            my_cam[2 * k + 1] = yn;
-        }
-        return;
-    }
-    if (P.use_cam_table == 1) {
+    if (!KIND2 || P.use_cam_table == 1) {
         const double y0 = ((double)it.gy - I.cy) * I.ify;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -267,14 +245,200 @@ __device__ __forceinline__ void cam_table_finish(const KParams &P, const DevCal 
     }
 }
 
+// ---- MASKIN (CMODE bit 4): H0 / S3b / S3d inside the fused launch -----------------------------------------------------------------
+// image_scissor produces a new selection every scan (m_tech_project_console.cpp:366) and the reference's loop runs ONE scan per
+// iteration: k_mask_prepare (5.5 us at 1080p, all of it launch latency and one load -> compute -> store chain) in front of a 25-us
+// one-view launch was a fifth of the per-scan path.  A MASKIN launch takes the views' RAW selection instead (the staging plane behind
+// sl3d_set_mask's copy, or the caller's own device-resident mask: KParams::mi) and evaluates the closed form of the boundary
+// removal (3/wrapped_phase.cpp:106-115, :253-279) itself, with the very bit-plane arithmetic of k_mask_prepare (sl3d_maskbits.h, one
+// row and one quad per lane) -- so "new mask + one view" is ONE kernel.
+//   * Nothing waits for it.  The 3 x 8 selection bytes around the lane's quad (rows y-1 .. y+1, plane bytes own-2 .. own+5; the
+//     neighbours' bytes are L2 hits; row y-2 matters to few lanes, which ask for it when they need it) are the wave's FIRST requests,
+//     in front of its camera-table entries and of the 46 planes the small-launch kernels request before they know the mask anyway:
+//     loads return in order, so the selection is there before anything else is, and it is evaluated while the planes travel.
+//     (Round 6's first build asked for it behind the Gray decode, where 40 registers are free: one more exposed round trip per wave,
+//     30.8 us per scan against 30.4 for the two kernels.)  The six registers come from the camera table: a MASKIN kernel compiles
+//     only the one-double kind (KIND2 = false); one view per item, so that nothing of a next view is in flight beside them.
+//   * It leaves everything k_mask_prepare would have left: the view's `band` dword (later launches over the view are ordinary ones),
+//     the normalised 0/1 plane with its 2-pixel halo (the lanes of the window's first / last row and column also write the halo
+//     rows / columns beside them), and per wave the number of quads that hold a valid pixel, as {seq << 8 | count} in host memory
+//     mapped into the device (what sparse_views reads).
+static_assert(SL3D_MASK_HALO == 2, "rows y-2 .. y+2 of the selection are plane rows row .. row + 4");
+// The launch's MaskIn, read through an opaque pointer into the kernel-argument segment (KParams is the kernel's first argument): as plain
+// kernel arguments its 20 dwords would be loaded once and held in SGPRs the pixel loop has not got.  ONE read per use site (a burst of
+// scalar loads, one wait): the first build re-read field by field -- two dozen dependent scalar round trips in front of the wave's first
+// plane request (read in the ISA; ~2 us per one-view launch).
+typedef const CONST_AS MaskIn *MaskInP;
+__device__ __forceinline__ MaskInP maskin_args()
+{
+    const CONST_AS char *ka = (const CONST_AS char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return (MaskInP)(ka + offsetof(KParams, mi));
+}
+struct MaskInArgs {
+    const GLOBAL_AS uint8_t *src;  // the selection of this view: plane row 0, byte 0
+    unsigned stride;
+    int bx0, bx1, r0, r1, lo, hi;
+};
+__device__ __forceinline__ MaskInArgs maskin_read_args(int slot)
+{
+    const MaskInP M = maskin_args();
+    MaskInArgs A;
+    A.src = (const GLOBAL_AS uint8_t *)M->origin[slot];
+    A.stride = (unsigned)M->stride;
+    A.bx0 = M->bx0; A.bx1 = M->bx1; A.r0 = M->r0; A.r1 = M->r1; A.lo = M->lo; A.hi = M->hi;
+    return A;
+}
+
+// the lane's place in the mask plane
+struct MaskInLane {
+    int row, cq, delta;
+    bool plain;  // mb_quad_plain: the quad's neighbourhood is interior to frame and region
+    MbCols c;    // (column constants: the lanes that are not plain)
+};
+template <bool COLS>
+__device__ __forceinline__ MaskInLane maskin_lane(const KParams &P, const MaskInArgs &A, const Item &it)
+{
+    MaskInLane m;
+    m.row = it.row;
+    m.cq = it.cq;
+    asm volatile("" : "+v"(m.row), "+v"(m.cq));  // (recomputed where it is used, not kept from the request to the evaluation)
+    const int own = SL3D_MASK_LPAD + m.cq * 4;
+    m.plain = mb_quad_plain(P.col0 + m.cq * 4, P.row0 + m.row, P.fullW, P.fullH, P.col0 + A.bx0 - SL3D_MASK_LPAD, P.col0 + A.bx1 - SL3D_MASK_LPAD) &&
+              own - 2 >= A.lo && own + 6 <= A.hi;
+    if (COLS) {
+        m.c = mb_cols(own, 4, P.col0, SL3D_MASK_LPAD, P.fullW, A.bx0, A.bx1);
+        m.delta = mb_quad_delta(own, A.lo, A.hi);
+    } else {
+        m.c.REG = m.c.INF = m.c.INTC = 0xfffu;
+        m.delta = -2;
+    }
+    return m;
+}
+
+// The 8 selection bytes of a plane row around the lane's quad: ONE 8-byte load at own + delta (sl3d_maskbits.h: mb_quad_delta).  (Three
+// aligned dwords -- left, own, right -- were measured: 0.4 us per one-view launch slower.)
+typedef unsigned mrow_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mrow_t maskin_load8(const GLOBAL_AS uint8_t *src, unsigned off)
+{
+    asm volatile("" : "+s"(src));
+    typedef unsigned u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
+    return *(const GLOBAL_AS u32x2_unaligned *)(src + (size_t)off);
+}
+// ... of any lane: 0 for a row that holds no source pixels, and for a lane whose own dword holds none (the pitch padding beyond the
+// region needs nothing -- its pixels lie outside the window, the dword beside it farther out still -- and beyond the frame's last column
+// its load would leave a caller's mask)
+__device__ __forceinline__ mrow_t maskin_row(const MaskInArgs &A, const MaskInLane &m, int pr)
+{
+    mrow_t w = {0u, 0u};
+    if (pr >= A.r0 && pr < A.r1 && (m.c.REG & 0x0f0u)) w = maskin_load8(A.src, (unsigned)pr * A.stride + (unsigned)(SL3D_MASK_LPAD + m.cq * 4 + m.delta));
+    return w;
+}
+__device__ __forceinline__ unsigned mrow_word(const MaskInLane &m, mrow_t w) { return mb_quad_word(w.x, w.y, m.delta) & m.c.REG; }
+__device__ __forceinline__ unsigned mrow_own(const MaskInLane &m, mrow_t w) { return mb_quad_own(w.x, w.y, m.delta); }
+__device__ __forceinline__ unsigned mrow_left(const MaskInLane &m, mrow_t w) { return mb_quad_left(w.x, w.y, m.delta); }
+__device__ __forceinline__ unsigned mrow_right(const MaskInLane &m, mrow_t w) { return mb_quad_right(w.x, w.y, m.delta); }
+
+// The selection bytes the lane needs of view slot `slot` of the launch: rows y-1, y, y+1 in w1..w3; row y-2 (w0) and row y+2 (w4)
+// only where they matter -- the window's first / last row (halo duties), frame row 2 and the frame's first / last column (mb_quad_top_needed).
+// Everything is asked for HERE, in front of the planes: a load behind them would have to wait for all 46.  Returns true (wave-uniform) if
+// every lane of the wave is plain and without halo duties: such a wave asked without a predicate (every byte is a source pixel) and
+// evaluates the short form (maskin_finish).
+__device__ __forceinline__ bool maskin_request(const KParams &P, const Item &it, int slot, mrow_t &w0, mrow_t &w1, mrow_t &w2, mrow_t &w3, mrow_t &w4)
+{
+    const MaskInArgs A = maskin_read_args(slot);
+    {
+        const MaskInLane m = maskin_lane<false>(P, A, it);
+        const bool own_duty = m.row == 0 || m.row == P.H - 1 || m.cq == 0 || m.cq == (P.pitch >> 2) - 1;
+        if (__ballot(!m.plain || own_duty) == 0ull) {
+            const unsigned off = (unsigned)(m.row + 1) * A.stride + (unsigned)(SL3D_MASK_LPAD + m.cq * 4 - 2);
+            w1 = maskin_load8(A.src, off);
+            w2 = maskin_load8(A.src + A.stride, off);
+            w3 = maskin_load8(A.src + 2 * (size_t)A.stride, off);
+            return true;
+        }
+    }
+    const MaskInLane m = maskin_lane<true>(P, A, it);
+    if (m.row == 0 || mb_quad_top_needed(m.c, P.row0 + m.row, P.fullH)) w0 = maskin_row(A, m, m.row);
+    w1 = maskin_row(A, m, m.row + 1);
+    w2 = maskin_row(A, m, m.row + 2);
+    w3 = maskin_row(A, m, m.row + 3);
+    if (m.row == P.H - 1) w4 = maskin_row(A, m, m.row + 4);
+    return false;
+}
+
+// the normalised 0/1 bytes of plane row `pr` beside the lane's own dword: at the window's first / last quad the dword to its left / right
+__device__ __forceinline__ void maskin_emit_sides(const KParams &P, uint8_t *mask_view, const MaskInLane &m, int pr, mrow_t w)
+{
+    unsigned *q = (unsigned *)(mask_view + (size_t)pr * P.mpitch + SL3D_MASK_LPAD + m.cq * 4);
+    if (m.cq == 0) q[-1] = mb_eq1_bytes(mrow_left(m, w)) & (mb_expand_nibble(m.c.REG) * 0xffu);
+    if (m.cq == (P.pitch >> 2) - 1) q[1] = mb_eq1_bytes(mrow_right(m, w)) & (mb_expand_nibble(m.c.REG >> 8) * 0xffu);
+}
+__device__ __forceinline__ unsigned maskin_own(const MaskInLane &m, mrow_t w) { return mb_eq1_bytes(mrow_own(m, w)) & (mb_expand_nibble(m.c.REG >> 4) * 0xffu); }
+__device__ __forceinline__ void maskin_emit(const KParams &P, uint8_t *mask_view, const MaskInLane &m, int pr, mrow_t w)
+{
+    *(unsigned *)(mask_view + (size_t)pr * P.mpitch + SL3D_MASK_LPAD + m.cq * 4) = maskin_own(m, w);
+    maskin_emit_sides(P, mask_view, m, pr, w);
+}
+
+// -> bits 0..3: the valid bits of the lane's 4 pixels (bit k = pixel k), exactly what k_mask_prepare leaves in the band plane;
+// bits 4..7: the lane's own selection bits (byte == 1).  The halo rows / columns of the 0/1 plane beside the lane's own dword are
+// written here (few lanes); the band dword and the own dword of the 0/1 plane leave with the view's results (maskin_store).
+// fast: maskin_request's verdict on the wave -- the short form of the plain interior (sl3d_maskbits.h): ~70 instead of ~250 integer
+// instructions per quad.  (The fused kernel is as much VALU- as memory-bound: the general form for every lane cost a one-view launch ~1 us.
+// The same form on 64-bit lane masks -- 4 ballots per row, the recurrences on the scalar unit -- was built too, bit-identical and 1.4 us
+// SLOWER: all 16 waves of a CU run this prologue at the same time and share ONE scalar unit for ~140 dependent instructions each,
+// where the vector form spreads over four SIMDs; profiles/r06_fused_mask_ab.txt.)
+__device__ __forceinline__ unsigned maskin_finish(const KParams &P, const Item &it, int view, int slot, mrow_t w0, mrow_t w1, mrow_t w2, mrow_t w3, mrow_t w4, bool fast)
+{
+    if (fast) {
+        const unsigned v = mb_quad_valid_plain(mb_quad_word(w1.x, w1.y, -2), mb_quad_word(w2.x, w2.y, -2), mb_quad_word(w3.x, w3.y, -2));
+        return v | (mb_pack_nibble(mb_eq1_bytes(mb_quad_own(w2.x, w2.y, -2))) << 4);
+    }
+    const MaskInArgs A = maskin_read_args(slot);
+    const MaskInLane m = maskin_lane<true>(P, A, it);
+    const int gy = P.row0 + m.row;
+    const bool first = m.row == 0, last = m.row == P.H - 1;
+    uint8_t *mask_view = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
+    if (first) {  // the halo rows above the window ...
+        maskin_emit(P, mask_view, m, m.row, w0);
+        maskin_emit(P, mask_view, m, m.row + 1, w1);
+    }
+    maskin_emit_sides(P, mask_view, m, m.row + 2, w2);
+    if (last) {  // ... and below it
+        maskin_emit(P, mask_view, m, m.row + 3, w3);
+        maskin_emit(P, mask_view, m, m.row + 4, w4);
+    }
+    const unsigned v = mb_quad_valid(mrow_word(m, w0), mrow_word(m, w1), mrow_word(m, w2), mrow_word(m, w3), m.c, gy, P.fullH) & mb_range_bits(0, P.W, m.cq * 4, 4);
+    return v | (mb_pack_nibble(maskin_own(m, w2)) << 4);
+}
+
+// the view's band dword and the lane's own dword of the 0/1 plane (with the view's results: nothing of the launch waits for them)
+__device__ __forceinline__ void maskin_store(const KParams &P, const Item &it, int view, unsigned bits)
+{
+    stg_nt(opaque_out((uint8_t *)P.band + (size_t)view * P.px_view_stride), it.lane_off, mb_expand_nibble(bits));
+    stg_nt(opaque_out((uint8_t *)P.mask + (size_t)view * P.mask_view_stride), (unsigned)(it.row + SL3D_MASK_HALO) * (unsigned)P.mpitch + (unsigned)(SL3D_MASK_LPAD + it.cq * 4),
+           mb_expand_nibble(bits >> 4));
+}
+
+// per wave: {seq << 8 | quads with a valid pixel}; a wave whose first lane owns no pixel owns none at all and stores nothing (the
+// host expects one word per wave that owns pixels)
+__device__ __forceinline__ void maskin_count(const KParams &P, const Item &it, int view, unsigned v)
+{
+    const MaskInP M = maskin_args();
+    const unsigned cnt = (unsigned)__popcll(__ballot((v & 0xfu) != 0u));
+    if ((threadIdx.x & 63u) == 0u && it.alive)
+        M->part[(size_t)view * M->part_stride + (size_t)it.tile * 4u + (threadIdx.x >> 6)] = (M->seq << 8) | cnt;
+}
+
 // Everything of an item that depends on the pixel only; false if this lane has nothing to do.
 // EARLY (the small-launch instantiation): the camera-table entries are only REQUESTED here (camt); the caller issues the first
 // view's plane loads right behind them and then calls cam_table_finish -- one round trip instead of two in front of the first
 // decode.  (Round 3 measured the other order for large launches -- set-up loads before the reciprocal-table fill, consumed behind
 // the plane loads: 16 views +-0, profiles/r03_prologue_ab.txt.)
-template <int RIG, bool SEG, bool EARLY, int BLK = SL3D_BLOCK, bool F32 = false, bool MASKIN = false>
+template <int RIG, bool SEG, bool EARLY, int BLK = SL3D_BLOCK, bool MASKIN = false>
 __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglobal, unsigned tile_, int group, int first_view, int n_views, int vpt, Item &it,
-                                           MaskQuad &mq_first, double (&camt)[8], f32x4_t &camf, double *my_cam)
+                                           MaskQuad &mq_first, double (&camt)[8], double *my_cam, mrow_t &w0, mrow_t &w1, mrow_t &w2, mrow_t &w3, mrow_t &w4, bool &mfast)
 {
     const unsigned qpr = (unsigned)P.pitch >> 2;  // quads per row, pitch padding included
     it.tile = tile_;
@@ -297,17 +461,23 @@ __device__ __forceinline__ bool item_begin(const KParams &P, const DevCal *Cglob
     it.lane_off = (unsigned)it.row * (unsigned)P.pitch + (unsigned)it.cq * 4u;
     // the valid bits of the item's first view are requested now, so that they travel together with the camera table
     // entries below instead of after them (one round trip less before the first plane loads can leave)
-    // (MASKIN: there is no valid-map dword yet -- the launch evaluates the selection itself, maskin_request / maskin_finish)
-    if (MASKIN) mq_first.band = 0u;
-    else mq_first = load_mask_quad(P, min(it.v_begin, first_view + n_views - 1), it.lane_off);
+    // (MASKIN: there is no valid-map dword yet -- the selection bytes around the quad are the wave's first requests instead)
+    if (MASKIN) {
+        mq_first.band = 0u;
+        bool f = false;
+        if (it.alive) f = maskin_request(P, it, min(it.v_begin, first_view + n_views - 1) - first_view, w0, w1, w2, w3, w4);
+        mfast = __ballot(f) != 0ull;  // (wave-uniform by construction: a wave with a lane past the last row is never fast)
+    } else {
+        mq_first = load_mask_quad(P, min(it.v_begin, first_view + n_views - 1), it.lane_off);
+    }
     if (EARLY && P.use_cam_table) {
-        cam_table_request<F32>(P, it, camt, camf);
+        cam_table_request<!MASKIN>(P, it, camt);
         return true;
     }
     if (P.use_cam_table) {
         double t[8];
-        cam_table_request<F32>(P, it, t, camf);
-        cam_table_finish<RIG, F32>(P, Cglobal, it, t, camf, my_cam);
+        cam_table_request<!MASKIN>(P, it, t);
+        cam_table_finish<RIG, !MASKIN>(P, Cglobal, it, t, my_cam);
         return true;
     }
     // no table (a camera without distortion, or the parity mode): T1 of the camera evaluated here
@@ -784,136 +954,6 @@ __device__ __forceinline__ void store_segment(const KParams &P, const Item &it, 
     wave_lds_handoff();  // ... and read before the next view's phase A parks its correspondences in the same area
 }
 
-// ---- MASKIN (CMODE bit 4): H0 / S3b / S3d inside the fused launch -----------------------------------------------------------------
-// image_scissor produces a new selection every scan (m_tech_project_console.cpp:366) and the reference's loop runs ONE scan per
-// iteration: k_mask_prepare (5.5 us at 1080p, all of it launch latency and one load -> compute -> store chain) in front of a 25-us
-// one-view launch was a fifth of the per-scan path.  A MASKIN launch takes the views' RAW selection instead (the staging plane behind
-// sl3d_set_mask's copy, or the caller's own device-resident mask: KParams::mi_*) and evaluates the closed form of the boundary
-// removal (3/wrapped_phase.cpp:106-115, :253-279) itself, with the very bit-plane arithmetic of k_mask_prepare (sl3d_maskbits.h, one
-// row per lane: R = 1, OWN = 4) -- so "new mask + one view" is ONE kernel.
-//   * Nothing waits for it.  The planes of a view are requested as if every pixel of the window were selected (the small-launch
-//     kernels request them before they know the mask anyway); the lane asks for the 3 x 8 selection bytes around its quad (rows y-1 .. y+1, plane bytes own-2 ..
-//     own+5: neighbours' bytes are L2 hits; row y-2 matters to few lanes, which ask for it when they need it) AFTER the Gray decode, when the 40 plane registers are dead, runs
-//     stages 4 + 5 of its pixels under that request, and only then clears what the selection rejects.  No round trip is added in
-//     front of anything; the price is the arithmetic of unselected pixels -- so a launch over views KNOWN to be sparsely selected
-//     keeps the two-kernel route (sl3d_capi.cpp), whose plane requests wait for the valid bits.
-//   * It leaves everything k_mask_prepare would have left: the view's `band` dword (later launches over the view are ordinary ones),
-//     the normalised 0/1 plane with its 2-pixel halo (the lanes of the window's first / last row and column also write the halo
-//     rows / columns beside them), and per wave the number of quads that hold a valid pixel, as {seq << 8 | count} in host memory
-//     mapped into the device (what sparse_views reads).
-static_assert(SL3D_MASK_HALO == 2, "rows y-2 .. y+1 of the selection are plane rows row .. row + 3");
-// own pixels of the lane's quad that lie inside the window (the pitch padding is never selected)
-// (recomputed at every use from an opaque copy of the quad's column: kept in a register across the view loop it was one more to spill)
-__device__ __forceinline__ unsigned maskin_assumed(const KParams &P, const Item &it)
-{
-    int cq = it.cq;
-    asm volatile("" : "+v"(cq));
-    return it.alive ? mb_range_bits(0, P.W, cq * 4, 4) : 0u;
-}
-
-// The lane's place in the mask plane.  Everything below is a function of the pixel alone, i.e. invariant in the view loop: left to
-// itself the optimiser hoists all of it (addresses, column masks, a dozen predicates) in front of the loop and keeps it in registers
-// the pixel loop needs -- 250 bytes of scratch per lane.  The copies behind an empty asm are opaque, so the ~60 integer
-// instructions are redone per view instead.
-// The launch's MaskIn, read where it is used through an opaque pointer into the kernel-argument segment (KParams is the kernel's first
-// argument): as plain kernel arguments its 20 dwords were loaded once in front of the view loop and held in SGPRs the loop has not got.
-typedef const CONST_AS MaskIn *MaskInP;
-__device__ __forceinline__ MaskInP maskin_args()
-{
-    const CONST_AS char *ka = (const CONST_AS char *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    return (MaskInP)(ka + offsetof(KParams, mi));
-}
-
-struct MaskInLane {
-    int row, cq, delta;
-    MbCols c;
-};
-__device__ __forceinline__ MaskInLane maskin_lane(const KParams &P, const Item &it)
-{
-    const MaskInP M = maskin_args();
-    MaskInLane m;
-    m.row = it.row;
-    m.cq = it.cq;
-    asm volatile("" : "+v"(m.row), "+v"(m.cq));
-    const int own = SL3D_MASK_LPAD + m.cq * 4;
-    m.c = mb_cols(own, 4, P.col0, SL3D_MASK_LPAD, P.fullW, M->bx0, M->bx1);
-    m.delta = mb_quad_delta(own, M->lo, M->hi);
-    return m;
-}
-
-// the 8 selection bytes of plane row `pr` around the lane's quad (sl3d_maskbits.h: ONE 8-byte load; 0 for a row that holds no source pixels)
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x2_t maskin_row(const KParams &P, const GLOBAL_AS uint8_t *src, const MaskInLane &m, int pr)
-{
-    const MaskInP M = maskin_args();
-    u32x2_t w = {0u, 0u};
-    // (a lane whose own dword holds no source pixel -- the pitch padding beyond the region -- needs nothing: its pixels lie outside the
-    // window, and the dword beside it is farther out still; beyond the frame's last column its load would leave a caller's mask)
-    if (pr >= M->r0 && pr < M->r1 && (m.c.REG & 0x0f0u)) {
-        const unsigned off = (unsigned)pr * (unsigned)M->stride + (unsigned)(SL3D_MASK_LPAD + m.cq * 4 + m.delta);
-        asm volatile("" : "+s"(src));
-        typedef unsigned u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
-        w = *(const GLOBAL_AS u32x2_unaligned *)(src + (size_t)off);
-    }
-    return w;
-}
-
-// rows y-1, y, y+1 (row y-2 matters to few lanes: maskin_finish asks for it where it does)
-__device__ __forceinline__ void maskin_request(const KParams &P, const Item &it, int slot, u32x2_t (&mw)[3])
-{
-    const GLOBAL_AS uint8_t *src = opaque((const uint8_t *)maskin_args()->origin[slot]);
-    const MaskInLane m = maskin_lane(P, it);
-#pragma unroll
-    for (int a = 0; a < 3; a++) mw[a] = maskin_row(P, src, m, m.row + 1 + a);
-}
-
-// the normalised 0/1 bytes of plane row `pr`: the lane's own dword, and at the window's first / last quad the dword beside it
-__device__ __forceinline__ void maskin_emit(const KParams &P, uint8_t *mask_view, const MaskInLane &m, int pr, u32x2_t w)
-{
-    unsigned *q = (unsigned *)(mask_view + (size_t)pr * P.mpitch + SL3D_MASK_LPAD + m.cq * 4);
-    q[0] = mb_eq1_bytes(mb_quad_own(w.x, w.y, m.delta)) & (mb_expand_nibble(m.c.REG >> 4) * 0xffu);
-    if (m.cq == 0) q[-1] = mb_eq1_bytes(mb_quad_left(w.x, w.y, m.delta)) & (mb_expand_nibble(m.c.REG) * 0xffu);
-    if (m.cq == (P.pitch >> 2) - 1) q[1] = mb_eq1_bytes(mb_quad_right(w.x, w.y, m.delta)) & (mb_expand_nibble(m.c.REG >> 8) * 0xffu);
-}
-
-// -> the valid bits of the lane's 4 pixels (bit k = pixel k), exactly what k_mask_prepare leaves in the band plane
-__device__ __forceinline__ unsigned maskin_finish(const KParams &P, const Item &it, int view, int slot, const u32x2_t (&mw)[3])
-{
-    const MaskInP M = maskin_args();
-    const MaskInLane m = maskin_lane(P, it);
-    const int gy = P.row0 + m.row;
-    const bool first = m.row == 0, last = m.row == P.H - 1;
-    uint8_t *mask_view = (uint8_t *)P.mask + (size_t)view * P.mask_view_stride;
-    unsigned Vtop = 0u;
-    if (first || mb_quad_top_needed(m.c, gy, P.fullH)) {  // (few lanes: the window's first row, frame row 2, the frame's first / last column)
-        const u32x2_t w = maskin_row(P, opaque((const uint8_t *)M->origin[slot]), m, m.row);
-        Vtop = mb_quad_word(w.x, w.y, m.delta) & m.c.REG;
-        if (first) maskin_emit(P, mask_view, m, m.row, w);  // the halo rows above the window ...
-    }
-    if (first) maskin_emit(P, mask_view, m, m.row + 1, mw[0]);
-    maskin_emit(P, mask_view, m, m.row + 2, mw[1]);
-    if (last) {  // ... and below it
-        maskin_emit(P, mask_view, m, m.row + 3, mw[2]);
-        maskin_emit(P, mask_view, m, m.row + 4, maskin_row(P, opaque((const uint8_t *)M->origin[slot]), m, m.row + 4));
-    }
-    const unsigned v = mb_quad_valid(Vtop, mb_quad_word(mw[0].x, mw[0].y, m.delta) & m.c.REG, mb_quad_word(mw[1].x, mw[1].y, m.delta) & m.c.REG,
-                                     mb_quad_word(mw[2].x, mw[2].y, m.delta) & m.c.REG, m.c, gy, P.fullH) &
-                       mb_range_bits(0, P.W, m.cq * 4, 4);
-    *(unsigned *)((uint8_t *)P.band + (size_t)view * P.px_view_stride + ((size_t)m.row * P.pitch + (size_t)m.cq * 4)) = mb_expand_nibble(v);
-    return v;
-}
-
-// per wave: {seq << 8 | quads with a valid pixel}; a wave whose first lane owns no pixel owns none at all and stores nothing (the
-// host expects one word per wave that owns pixels)
-__device__ __forceinline__ void maskin_count(const KParams &P, const Item &it, int view, unsigned v)
-{
-    const MaskInP M = maskin_args();
-    const unsigned cnt = (unsigned)__popcll(__ballot(v != 0u));
-    if ((threadIdx.x & 63u) == 0u && it.alive)
-        M->part[(size_t)view * M->part_stride + (size_t)it.tile * 4u + (threadIdx.x >> 6)] = (M->seq << 8) | cnt;
-}
-
 // F == 5: check_I_mod_criteria's assignment is commented out (3/wrapped_phase.cpp:117-129): nothing is valid
 template <bool KEEP, bool FGEN, bool SEG>
 __device__ __forceinline__ unsigned valid_bits(const Item &it, int F, const MaskQuad &m)
@@ -962,7 +1002,6 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     constexpr int BLK = RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK;
     static_assert((CMODE & ~6) == 0, "0 = dense planes, 2 = segmented clouds (1 was round 2's look-back compaction), + 4 = MASKIN");
     static_assert(!MASKIN || (!RCPT && EARLY_ && !KEEP && RIG != 0), "MASKIN: the pipelined small-launch instantiations");
-    constexpr bool F32TAB = !RCPT;  // camera table kind 3 (cam_table_request): the small-launch instantiations
     static_assert(!(KEEP && CMODE != 0), "the parity mode writes dense planes");
     static_assert(!(KEEP && RIG != 0), "the parity mode evaluates everything with the reference's operation order");
     __shared__ __attribute__((aligned(16))) float s_xyz[BLK * 12];  // staging area: correspondences, then xyz, of the lane's 4 pixels
@@ -1015,13 +1054,16 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     Item it;
     MaskQuad mq;
     double camt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // EARLY: the lane's camera-table entries between their request and cam_table_finish
-    f32x4_t camf = {0.f, 0.f, 0.f, 0.f};         // (kind 3: the four residuals)
+    unsigned mbits = 0u;                         // MASKIN: valid bits (0..3) and own selection bits (4..7) of the quad
+    mrow_t mw0 = {0u, 0u}, mw1 = mw0, mw2 = mw0, mw3 = mw0, mw4 = mw0;  // MASKIN: the selection bytes around the quad (maskin_request)
+    bool mfast = false;                          // MASKIN: the wave evaluates the short form (maskin_request)  // MASKIN: the selection bytes around the quad between their request and maskin_finish
     unsigned f[2][4], g[2][NMAX], iv[2][NMAX], code[2][2];
     // gridDim.x is a multiple of 8 (launch_fused): consecutive tiles go round-robin over the 8 XCDs on purpose (the XCD-banded
     // order was measured at -4 %: DRAM locality across XCDs beats L2 locality for 2 % of shared bytes)
     // (false: a lane past the last row, or a block the grid was padded with.  REQ_FIRST: block-uniform, only the latter -- a lane past
     // the last row stays until the block's barrier, its requests go to the last row.)
-    if (!item_begin<RIG, SEG, REQ_FIRST, BLK, F32TAB, MASKIN>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, camf, my_cam)) return;
+    if (!item_begin<RIG, SEG, REQ_FIRST, BLK, MASKIN>(P, Cglobal, blockIdx.x, (int)blockIdx.y, first_view, n_views, vpt, it, mq, camt, my_cam, mw0, mw1, mw2, mw3, mw4, mfast)) return;
+    if (MASKIN) it.v_end = it.v_begin + 1;  // (one view per item: launch_fused makes the grid so; a compile-time trip count of the loop below)
     if (REQ_FIRST) {
         // EARLY: planes of the first view right behind the set-up requests.  The block's LDS tables are filled while all of that
         // travels (the radial node requested at the very top is the oldest request: its store waits for nothing else); then the
@@ -1034,18 +1076,21 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         if (RIG == 3) ((u32x4 *)s_rad)[threadIdx.x] = rad_node;
         if (RCPT || RIG == 3) __syncthreads();
         if (!SEG && !it.alive) return;
-        if (P.use_cam_table) cam_table_finish<RIG, F32TAB>(P, Cglobal, it, camt, camf, my_cam);
+        // MASKIN: the selection bytes were requested first, so they are here first: evaluated while the planes travel
+        if (MASKIN) {
+            if (it.alive) mbits = maskin_finish(P, it, it.v_begin, it.v_begin - first_view, mw0, mw1, mw2, mw3, mw4, mfast);
+            maskin_count(P, it, it.v_begin, mbits);
+        }
+        if (P.use_cam_table) cam_table_finish<RIG, !MASKIN>(P, Cglobal, it, camt, my_cam);
     }
     SL3D_STAMP(2);
-    // MASKIN: until the selection has been evaluated (behind the Gray decode, maskin_request) every pixel of the window counts as valid
-#define SL3D_ASSUMED() (MASKIN ? maskin_assumed(P, it) : 0u)
     // The mask dword of the NEXT view is requested a view ahead, so a wave never waits a full memory round trip for it before it
     // can ask for its 11.5 KB of planes.  (gfx950 has one in-order vmcnt for loads and stores, and the wait-count pass is
     // conservative wherever a register a load is still writing is touched: round 4 removed, one by one, every s_waitcnt vmcnt(0)
     // of this loop except the decode's -- see the comments at the pipeline point, in phase_A / phase_B and at vb_pre.)
     unsigned vb_next = 0;
     if (PIPE) {
-        vb_next = MASKIN ? SL3D_ASSUMED() : valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+        vb_next = MASKIN ? (mbits & 0xfu) : valid_bits<KEEP, FGEN, SEG>(it, F, mq);
         if (!MASKIN && it.v_begin + 1 < it.v_end) mq = load_mask_quad(P, it.v_begin + 1, it.lane_off);
         if (!EARLY && vb_next != 0) {  // (EARLY: they are in flight already)
             issue_fringe<FGEN>(P, it.v_begin, it.lane_off, F, Nv, f);
@@ -1063,6 +1108,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     unsigned pvout = 0;
     auto store_view = [&](int v, unsigned vo) {
         const size_t p = (size_t)v * P.px_view_stride + (size_t)it.lane_off;
+        if (MASKIN && it.alive) maskin_store(P, it, v, mbits);
         if (SEG) store_segment(P, it, v, vo, s_xyz, my_xyz);
         else store_quad<KEEP>(P, s_xyz, my_xyz, p, vo);
     };
@@ -1090,18 +1136,12 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
         }
         if (vbits != 0) decode_gray<NMAX, PLANES>(g, iv, Nv, Nh, code);  // waits for the planes of this view
         if (view == it.v_begin) SL3D_STAMP(4);
-        // MASKIN: the view's selection is asked for HERE -- the 40 Gray registers are dead, stages 4 + 5 below run under the request
-        u32x2_t mw[3];
-        if (MASKIN) {
-            __builtin_amdgcn_sched_barrier(0);  // (not hoisted in front of the decode, where the registers are not there)
-            if (it.alive) maskin_request(P, it, view - first_view, mw);
-        }
         // the NEXT view's valid bits, taken here -- its mask dword is older than the planes just decoded, so it has landed, and no
         // store of this view has been issued yet.  Taken at the pipeline point (where they are needed) they cost an s_waitcnt
         // vmcnt(0) there: one in-order counter, and by then the deferred stores are in it
         unsigned vb_pre = 0;
         if (PIPE) {
-            vb_pre = MASKIN ? SL3D_ASSUMED() : valid_bits<KEEP, FGEN, SEG>(it, F, mq);
+            vb_pre = MASKIN ? 0u : valid_bits<KEEP, FGEN, SEG>(it, F, mq);
             asm volatile("" : "+v"(vb_pre));  // (here, not sunk to its use)
         }
         if (DEFER) {
@@ -1112,12 +1152,6 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
             if (KEEP) vout = parity_pixels<RCPT>(P, Cglobal, PR, it, F, vbits, f, code, s_rcp, my_cam, my_xyz, px);
             else if (SPLIT) vout = correspond_quad(P, it, vbits, w, code, my_cp);
             else vout = phase_A<RCPT, UNROLL>(P, it, F, vbits, f, code, s_rcp, my_cp);
-        }
-        if (MASKIN) {  // the selection has arrived: what it rejects is cleared, what k_mask_prepare would have left is left
-            unsigned real = 0u;
-            if (it.alive) real = maskin_finish(P, it, view, view - first_view, mw);
-            maskin_count(P, it, view, real);
-            vout &= mb_expand_nibble(real);
         }
         if (view == it.v_begin) SL3D_STAMP(5);
         // (Round 3 read the ISA of the table rigs: their 4 projector-table entries are requested BEHIND the next view's 46 plane

@@ -50,7 +50,8 @@ static int timed_rig(const KParams &P, int rig)
 // Returns the hipError_t of THIS launch.
 bool fused_maskin_available(const KParams &P, int rig, int n_views, bool keep)
 {
-    if (keep || P.F != 3 || n_views > SL3D_SMALL_LAUNCH_VIEWS || timed_rig(P, rig) == 0) return false;
+    // (a MASKIN kernel compiles the one-double camera table only: its mask words live in the registers of the two-double kind)
+    if (keep || P.F != 3 || n_views > SL3D_SMALL_LAUNCH_VIEWS || timed_rig(P, rig) == 0 || (P.cam_tab != nullptr && P.cam_tab_kind == 2)) return false;
     const FusedChoice c = choose_fused(false, false, 0, P.Nv, P.Nh, n_views, false, timed_rig(P, rig));
     return c.small && c.early;
 }
@@ -78,21 +79,16 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     // kernel (prefer_gated) but keeps the views-per-lane rule of small launches -- the A/B that chose that kernel for sparse
     // selections, profiles/r04_sparse_mask.txt, was measured with it; following the kernel instead is 5-12 % slower at 19 % / 5 %
     // coverage with 4 views per launch, 1-4 % faster at 50 %: profiles/r05_sparse_small_launch_vpt_ab.txt)
-    const int vpt = views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0, !keep && P.F == 3 && n_views <= SL3D_SMALL_LAUNCH_VIEWS);
+    // (a MASKIN launch: one view per item -- nothing of a next view is in flight beside the selection bytes)
+    const int vpt = mi ? 1 : views_per_lane(bx, n_views, P.cam_tab != nullptr ? P.cam_tab_kind : 0, !keep && P.F == 3 && n_views <= SL3D_SMALL_LAUNCH_VIEWS);
     const dim3 grid(bx, (unsigned)((n_views + vpt - 1) / vpt), 1);
     // the timed kernels read the camera-side T1 from the per-calibration table whatever the batch is: with 8 views per lane it
     // costs nothing (1 B/px/view), with 1..4 it saves the iteration (+2..13 %), and a view's result does not depend on the
     // batch it was launched in
     P.use_cam_table = P.cam_tab != nullptr ? P.cam_tab_kind : 0;
     const int r = timed_rig(P, rig);
-    // the small-launch instantiations read the 4-byte form of a radial camera table where the calibration offers it (kind 3:
-    // nothing amortises the table's bytes in a launch of a few views)
-    if (P.use_cam_table == 1 && P.cam_tab_f32 == 1 && !keep && P.F == 3 &&
-        choose_fused(false, false, cmode, P.Nv, P.Nh, n_views, P.prefer_gated != 0, r).small)
-        P.cam_tab_f32 = 2;
 #ifdef SL3D_MEASURE
     if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 0) P.use_cam_table = 0;
-    if (getenv("SL3D_CAMTAB") && atoi(getenv("SL3D_CAMTAB")) == 1 && P.cam_tab_f32 == 2) P.cam_tab_f32 = 1;
 #endif
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's

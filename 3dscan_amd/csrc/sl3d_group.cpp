@@ -41,15 +41,18 @@ struct RcclApi {
     bool ok = false;
 };
 
-// allow_override: the caller created its group with SL3D_FLAG_GROUP_DISTINCT_SIDES (the flag of the one-GPU tests).  Only then is
-// SL3D_RCCL_LIB honoured -- another library with the same seven entry points (a test double that pairs sends with receives itself, so
-// that the N-rank exchange runs on one GPU); a production group never loads a library an environment variable names.  The first
-// caller of the process decides.
-RcclApi &rccl(bool allow_override = false)
+// allow_override: the group was created with SL3D_FLAG_GROUP_DISTINCT_SIDES (the flag of the one-GPU tests).  Only such a group honours
+// SL3D_RCCL_LIB -- another library with the same seven entry points (a test double that pairs sends with receives itself, so that the
+// N-rank exchange runs on one GPU); a production group never loads a library an environment variable names.  TWO bindings, chosen
+// per group by its flag: which library a group talks to does not depend on what kind of group the process happened to create first
+// (ADVICE r5).
+RcclApi &rccl(bool allow_override)
 {
-    static RcclApi R;
-    static std::once_flag once;
-    std::call_once(once, [allow_override] {
+    static RcclApi bindings[2];
+    static std::once_flag onces[2];
+    RcclApi &R = bindings[allow_override ? 1 : 0];
+    std::once_flag &once = onces[allow_override ? 1 : 0];
+    std::call_once(once, [allow_override, &R] {
         const char *override_lib = allow_override ? getenv("SL3D_RCCL_LIB") : nullptr;
         if (override_lib && *override_lib) {
             R.lib = dlopen(override_lib, RTLD_NOW | RTLD_LOCAL);
@@ -134,7 +137,7 @@ static int gfail(sl3d_group *g, int code, const std::string &msg)
 #define GNCCL(g, call)                                                                       \
     do {                                                                                     \
         ncclResult_t r_ = (call);                                                            \
-        if (r_ != ncclSuccess) return gfail((g), SL3D_E_HIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); \
+        if (r_ != ncclSuccess) return gfail((g), SL3D_E_HIP, std::string(#call) + ": " + rccl((g)->distinct_sides).GetErrorString(r_)); \
     } while (0)
 // a failing member context: its message becomes the group's
 #define GCTX(g, s, call)                                                                     \
@@ -159,7 +162,7 @@ try {
     for (auto &u : g->gpus) {
         DeviceGuard dg(u.device);
         if (u.comm) (void)hipStreamSynchronize(u.comm);
-        if (u.nccl) (void)rccl().CommDestroy(u.nccl);
+        if (u.nccl) (void)rccl(g->distinct_sides).CommDestroy(u.nccl);
         if (u.ev_comm) (void)hipEventDestroy(u.ev_comm);
         if (u.comm) (void)hipStreamDestroy(u.comm);
     }
@@ -392,12 +395,12 @@ static int group_exchange(sl3d_group *g, const std::vector<Xfer> &xs)
         const Stripe &S = g->st[(size_t)x.stripe];
         if (g->use_rccl && (S.gpu != 0 || (g->force_rccl && x.stripe != 0))) any_rccl = true;
     }
-    if (any_rccl) GNCCL(g, rccl().GroupStart());
+    if (any_rccl) GNCCL(g, rccl(g->distinct_sides).GroupStart());
     // an error between GroupStart and GroupEnd must not leave this thread inside an open RCCL group
     struct GroupCloser {
-        bool open;
-        ~GroupCloser() { if (open) (void)rccl().GroupEnd(); }
-    } closer{any_rccl};
+        bool open, override_;
+        ~GroupCloser() { if (open) (void)rccl(override_).GroupEnd(); }
+    } closer{any_rccl, g->distinct_sides};
     int in_group = 0;
     for (const Xfer &x : xs) {
         if (x.count == 0) continue;
@@ -406,13 +409,13 @@ static int group_exchange(sl3d_group *g, const std::vector<Xfer> &xs)
         if (by_rccl) {
             GpuSide &u = g->gpus[(size_t)S.gpu];
             if (in_group == 256) {  // a very large batch goes out as several RCCL groups (same order on both sides)
-                GNCCL(g, rccl().GroupEnd());
-                GNCCL(g, rccl().GroupStart());
+                GNCCL(g, rccl(g->distinct_sides).GroupEnd());
+                GNCCL(g, rccl(g->distinct_sides).GroupStart());
                 in_group = 0;
             }
             in_group++;
-            GNCCL(g, rccl().Send(x.src, x.count, x.type, 0, u.nccl, u.comm));
-            GNCCL(g, rccl().Recv(x.dst, x.count, x.type, S.gpu, root.nccl, root.comm));
+            GNCCL(g, rccl(g->distinct_sides).Send(x.src, x.count, x.type, 0, u.nccl, u.comm));
+            GNCCL(g, rccl(g->distinct_sides).Recv(x.dst, x.count, x.type, S.gpu, root.nccl, root.comm));
         } else if (S.gpu == 0) {
             DeviceGuard dg(root.device);
             GHIP(g, hipMemcpyAsync(x.dst, x.src, x.bytes(), hipMemcpyDeviceToDevice, root.comm));
@@ -422,7 +425,7 @@ static int group_exchange(sl3d_group *g, const std::vector<Xfer> &xs)
         }
     }
     closer.open = false;
-    if (any_rccl) GNCCL(g, rccl().GroupEnd());
+    if (any_rccl) GNCCL(g, rccl(g->distinct_sides).GroupEnd());
     for (auto &u : g->gpus) {
         DeviceGuard dg(u.device);
         GHIP(g, hipEventRecord(u.ev_comm, u.comm));

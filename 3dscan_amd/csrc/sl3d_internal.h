@@ -53,9 +53,6 @@ struct DevCal {
     double Rct[9], tcn[3];  // X = Rct*Y + tcn  (Rct = Rc^T, tcn = -Rc^T tc)
     double fx2, fy2;      // Kc[0]^2, Kc[1]^2 + Kc[4]^2
     double fxs;           // Kc[0]*Kc[1]: the skew term (0 for the usual K); the camera-frame form holds for any upper-triangular affine K
-    // camera table kind 3 (small launches, radial camera model): the factor of the last undistortion iteration minus 1 as
-    // t*(cam_poly[0] + t*(cam_poly[1] + t*cam_poly[2])), t = r0^2, plus an f32 residual per pixel (cam_poly_eval, sl3d_device.h)
-    double cam_poly[3];
 };
 
 // Scene + camera model of the synthetic-capture generator (k_synth).
@@ -141,8 +138,6 @@ struct KParams {
     int64_t *cpmap;            // [view][row][pitch][2]
     double *ipoints;           // [view][row][pitch][3]
     // (appended in round 6: the fields above keep their kernel-argument offsets)
-    int cam_tab_f32;           // kind-1 table only: 1 = an f32 residual table [H][pitch] follows the doubles (camera table kind 3);
-                               // set to 2 per launch: this (small) launch reads it instead of the doubles
     MaskIn mi;                 // MASKIN launches only (read through the kernel-argument segment, sl3d_fused.h: maskin_args)
 };
 static_assert(SL3D_SMALL_LAUNCH_VIEWS == 4, "KParams::mi_origin holds one entry per view of a small launch");

@@ -311,14 +311,8 @@ __global__ __launch_bounds__(256) void k_cam_table(const KParams P, const DevCal
     double u, v, icd;
     undistort_normalized((double)(P.col0 + x), (double)(P.row0 + y), C->cam, u, v, &icd);
     const size_t i = (size_t)y * P.pitch + x;
-    if (kind == 1) {
-        out[i] = icd;
-        if (P.cam_tab_f32) {  // kind 3 beside it: the f32 residual of the factor against the per-calibration cubic in r0^2 (cam_poly_eval)
-            const Intr &I = C->cam;
-            const double x0 = ((double)(P.col0 + x) - I.cx) * I.ifx, y0 = ((double)(P.row0 + y) - I.cy) * I.ify;
-            ((float *)(out + P.px_view_stride))[i] = (float)((icd - 1.0) - cam_poly_eval(*C, x0, y0));
-        }
-    } else {
+    if (kind == 1) out[i] = icd;
+    else {
         out[2 * i] = u;
         out[2 * i + 1] = v;
     }

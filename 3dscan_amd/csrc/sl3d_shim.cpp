@@ -9,9 +9,12 @@
 #include <cstdlib>
 #include <charconv>
 #include <cstring>
+#include <strings.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
+#include <new>
 #include <functional>
 #include <mutex>
 #include <map>
@@ -24,6 +27,7 @@
 #include <vector>
 
 #include "../../include/sl3d.h"
+#include "sl3d_shim_io.h"
 
 namespace {
 
@@ -74,12 +78,20 @@ struct Shim {
     // launch of the timed fused kernel and fills the globals the mask names.
     // (never set through sl3d_shim_globals: $SL3D_SHIM_GLOBALS = all | final | none | <hex mask> decides -- a relinked main() can be
     // switched to the deferred mode without touching its source)
+    // (case-insensitive; anything that is neither a keyword nor a hexadecimal number is reported and means `all`: a typo must not
+    // silently switch a relinked main() to "no globals at all")
     unsigned globals_mask = [] {
         const char *e = getenv("SL3D_SHIM_GLOBALS");
-        if (!e || !*e || !strcmp(e, "all")) return (unsigned)SL3D_SHIM_G_ALL;
-        if (!strcmp(e, "final")) return (unsigned)SL3D_SHIM_G_FINAL;
-        if (!strcmp(e, "none")) return (unsigned)SL3D_SHIM_G_NONE;
-        return (unsigned)strtoul(e, nullptr, 16) & (unsigned)SL3D_SHIM_G_EVERY;
+        if (!e || !*e || !strcasecmp(e, "all")) return (unsigned)SL3D_SHIM_G_ALL;
+        if (!strcasecmp(e, "final")) return (unsigned)SL3D_SHIM_G_FINAL;
+        if (!strcasecmp(e, "none")) return (unsigned)SL3D_SHIM_G_NONE;
+        char *end = nullptr;
+        const unsigned long v = strtoul(e, &end, 16);
+        if (end == e || *end != '\0') {
+            fprintf(stderr, "sl3d shim: SL3D_SHIM_GLOBALS=%s is neither all | final | none nor a hexadecimal mask: every global is filled (all)\n", e);
+            return (unsigned)SL3D_SHIM_G_ALL;
+        }
+        return (unsigned)v & (unsigned)SL3D_SHIM_G_EVERY;
     }();
     bool ctx_deferred = false;   // the mode the contexts were created in
     bool scan_open = false;      // deferred: a stage call of the current scan has been made (cleared by triangulate())
@@ -162,6 +174,12 @@ public:
         done_cv_.wait(lk, [&] { return pending_ == 0 && active_ == 0; });
         wanted_ = 0;  // (a worker that has not woken yet stays parked)
         job_ = nullptr;
+        if (error_) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            lk.unlock();
+            std::rethrow_exception(e);
+        }
     }
 
 private:
@@ -173,7 +191,13 @@ private:
     {
         int done = 0;
         for (int i; (i = next_.fetch_add(1)) < n_;) {
-            (*job_)(i);
+            try {  // (an exception must not leave a worker thread -- std::terminate -- nor stop the burst's bookkeeping: the first one
+                   // is kept and rethrown by run() on the calling thread, inside the stage function's own barrier)
+                (*job_)(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!error_) error_ = std::current_exception();
+            }
             done++;
         }
         if (done) {
@@ -205,6 +229,7 @@ private:
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_cv_;
     const std::function<void(int)> *job_ = nullptr;
+    std::exception_ptr error_;
     std::atomic<int> next_{0};
     int n_ = 0, pending_ = 0, wanted_ = 0, active_ = 0;
     unsigned long long generation_ = 0;
@@ -227,8 +252,40 @@ bool fail(int code, const std::string &msg)
 {
     g.status = code;
     g.err = msg;
+    // a failed stage call abandons the deferred scan in progress: the next stage call opens a new one (it waits for whatever is still
+    // running and brings selected_region up again) instead of taking this scan's state for its own
+    g.scan_open = g.mask_fresh = g.scan_done = false;
     fprintf(stderr, "\nsl3d shim: %s", msg.c_str());  // the reference reports with printf and carries on
     return false;
+}
+
+// The exception barrier of the shim's entry points: the reference's stage functions return void and report with printf, so an exception
+// stopped here becomes the shim's status (SL3D_E_NOMEM / SL3D_E_INTERNAL: sl3d_shim_status()) and a line on stderr; the scan in
+// progress is abandoned (the next stage call starts from a clean state).  Nothing in here throws.
+void shim_caught(const char *where) noexcept;
+#define SHIM_CATCH(where) catch (...) { shim_caught(where); }
+
+void shim_caught(const char *where) noexcept
+{
+    int code = SL3D_E_INTERNAL;
+    char buf[320];
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = SL3D_E_NOMEM;
+        snprintf(buf, sizeof buf, "%s: out of host memory (std::bad_alloc)", where);
+    } catch (const std::exception &e) {
+        snprintf(buf, sizeof buf, "%s: internal error: %s", where, e.what());
+    } catch (...) {
+        snprintf(buf, sizeof buf, "%s: unknown C++ exception", where);
+    }
+    g.status = code;
+    g.scan_open = g.mask_fresh = g.scan_done = false;
+    try {
+        g.err = buf;
+    } catch (...) {
+    }
+    fprintf(stderr, "\nsl3d shim: %s", buf);
 }
 
 bool ok(int rc, const char *what)
@@ -237,98 +294,11 @@ bool ok(int rc, const char *what)
     return fail(rc, std::string(what) + ": " + sl3d_strerror(rc) + ": " + sl3d_last_error(g.ctx));
 }
 
-// ---- 8-bit gray planes from BMP files: what cvLoadImage(..., CV_LOAD_IMAGE_GRAYSCALE) yields ----
-// (3/wrapped_phase.cpp:44, 4/phase_unwrap.cpp:78,84).  8-bit palettised and 24-bit BMPs; colour is converted
-// with OpenCV's fixed-point weights (B 1868, G 9617, R 4899, >> 14).
-inline uint8_t bgr2gray(int b, int gch, int r) { return (uint8_t)((b * 1868 + gch * 9617 + r * 4899 + (1 << 13)) >> 14); }
-
-// out: W * H bytes, top-down rows of W bytes.  scratch: the file's pixel array is read into it in one piece; a caller that decodes
-// the same number of files scan after scan hands in the same vectors again, so their pages are touched once, not once per scan
-bool read_bmp_gray(const std::string &path, uint8_t *out, std::vector<uint8_t> *scratch = nullptr)
-{
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    uint8_t hdr[54];
-    if (fread(hdr, 1, 54, f) != 54 || hdr[0] != 'B' || hdr[1] != 'M') { fclose(f); return false; }
-    auto u32 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8) | ((uint32_t)hdr[o + 2] << 16) | ((uint32_t)hdr[o + 3] << 24); };
-    const uint32_t data_off = u32(10), dib = u32(14);
-    const int32_t w = (int32_t)u32(18), hgt = (int32_t)u32(22);
-    const int bpp = hdr[28] | (hdr[29] << 8);
-    const uint32_t compression = u32(30);
-    uint32_t ncolors = u32(46);
-    if (w != W || (hgt != H && hgt != -H) || compression != 0 || (bpp != 8 && bpp != 24)) { fclose(f); return false; }
-    uint8_t pal[256];
-    for (int i = 0; i < 256; i++) pal[i] = (uint8_t)i;
-    if (bpp == 8) {
-        if (ncolors == 0) ncolors = 256;
-        fseek(f, 14 + dib, SEEK_SET);
-        for (uint32_t i = 0; i < ncolors && i < 256; i++) {
-            uint8_t q[4];
-            if (fread(q, 1, 4, f) != 4) { fclose(f); return false; }
-            pal[i] = bgr2gray(q[0], q[1], q[2]);
-        }
-    }
-    const size_t rowbytes = (((size_t)w * bpp + 31) / 32) * 4;
-    bool identity = bpp == 8;  // the grey ramp cvSaveImage writes for a 1-channel image: rows are copied, not looked up
-    for (int i = 0; i < 256 && identity; i++) identity = pal[i] == (uint8_t)i;
-    std::vector<uint8_t> own;
-    std::vector<uint8_t> &file = scratch ? *scratch : own;
-    file.resize(rowbytes * (size_t)H);  // one read for the whole pixel array
-    fseek(f, data_off, SEEK_SET);
-    if (fread(file.data(), 1, file.size(), f) != file.size()) { fclose(f); return false; }
-    fclose(f);
-    for (int i = 0; i < H; i++) {
-        const uint8_t *row = file.data() + (size_t)i * rowbytes;
-        const int y = hgt > 0 ? H - 1 - i : i;  // bottom-up unless the height is negative
-        uint8_t *dst = out + (size_t)y * W;
-        if (identity) memcpy(dst, row, (size_t)W);
-        else if (bpp == 8)
-            for (int x = 0; x < W; x++) dst[x] = pal[row[x]];
-        else
-            for (int x = 0; x < W; x++) dst[x] = bgr2gray(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
-    }
-    return true;
-}
-
-// B,G,R interleaved, top-down: what cvLoadImage(path) (colour) yields (8/save_point_cloud.cpp:46); 8-bit files go through
-// their palette, 24-bit files are copied
-bool read_bmp_bgr(const std::string &path, std::vector<uint8_t> &out)
-{
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    uint8_t hdr[54];
-    if (fread(hdr, 1, 54, f) != 54 || hdr[0] != 'B' || hdr[1] != 'M') { fclose(f); return false; }
-    auto u32 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8) | ((uint32_t)hdr[o + 2] << 16) | ((uint32_t)hdr[o + 3] << 24); };
-    const uint32_t data_off = u32(10), dib = u32(14);
-    const int32_t w = (int32_t)u32(18), hgt = (int32_t)u32(22);
-    const int bpp = hdr[28] | (hdr[29] << 8);
-    uint32_t ncolors = u32(46);
-    if (w != W || (hgt != H && hgt != -H) || u32(30) != 0 || (bpp != 8 && bpp != 24)) { fclose(f); return false; }
-    uint8_t pal[256][3];
-    for (int i = 0; i < 256; i++) pal[i][0] = pal[i][1] = pal[i][2] = (uint8_t)i;
-    if (bpp == 8) {
-        if (ncolors == 0) ncolors = 256;
-        fseek(f, 14 + dib, SEEK_SET);
-        for (uint32_t i = 0; i < ncolors && i < 256; i++) {
-            uint8_t q[4];
-            if (fread(q, 1, 4, f) != 4) { fclose(f); return false; }
-            pal[i][0] = q[0]; pal[i][1] = q[1]; pal[i][2] = q[2];
-        }
-    }
-    const size_t rowbytes = (((size_t)w * bpp + 31) / 32) * 4;
-    std::vector<uint8_t> row(rowbytes);
-    out.assign((size_t)W * H * 3, 0);
-    fseek(f, data_off, SEEK_SET);
-    for (int i = 0; i < H; i++) {
-        if (fread(row.data(), 1, rowbytes, f) != rowbytes) { fclose(f); return false; }
-        uint8_t *dst = out.data() + (size_t)(hgt > 0 ? H - 1 - i : i) * W * 3;
-        if (bpp == 24) memcpy(dst, row.data(), (size_t)W * 3);
-        else
-            for (int x = 0; x < W; x++) memcpy(dst + 3 * x, pal[row[x]], 3);
-    }
-    fclose(f);
-    return true;
-}
+// ---- the readers of the reference's input files (8/24-bit BMP, OpenCV XML matrices, PLY) live in sl3d_shim_io.h: every size a file
+// claims is checked against the file before it is used (tests/test_shim_io.py feeds them malformed files under ASan / UBSan) ----
+using sl3d_io::bgr2gray;
+inline bool read_bmp_gray(const std::string &path, uint8_t *out, std::vector<uint8_t> *scratch = nullptr) { return sl3d_io::read_bmp_gray(path, W, H, out, scratch); }
+inline bool read_bmp_bgr(const std::string &path, std::vector<uint8_t> &out) { return sl3d_io::read_bmp_bgr(path, W, H, out); }
 
 // 8-bit palettised BMP exactly as the reference's cvSaveImage (OpenCV 2.4 BMP encoder) writes a 1-channel image:
 // 14 + 40 byte headers with biSizeImage = biClrUsed = 0, 256 grey palette entries, bottom-up rows padded to 4 bytes.
@@ -504,23 +474,9 @@ bool read_xml_matrix(const std::string &rel, int count, double *out)
         }
     }
     const std::string path = data_root() + "/" + rel;
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return fail(SL3D_E_INVALID_ARG, "cannot open " + path);
     std::string s;
-    char buf[4096];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
-    fclose(f);
-    const size_t a = s.find("<data>"), b = s.find("</data>");
-    if (a == std::string::npos || b == std::string::npos) return fail(SL3D_E_INVALID_ARG, "no <data> in " + path);
-    const char *p = s.c_str() + a + 6;
-    const char *end = s.c_str() + b;
-    for (int i = 0; i < count; i++) {
-        char *q = nullptr;
-        out[i] = strtod(p, &q);
-        if (q == p || q > end) return fail(SL3D_E_INVALID_ARG, "too few numbers in " + path);
-        p = q;
-    }
+    if (!sl3d_io::read_text_file(path, s)) return fail(SL3D_E_INVALID_ARG, "cannot read " + path);
+    if (!sl3d_io::parse_xml_matrix(s, count, out)) return fail(SL3D_E_INVALID_ARG, "no <data> with " + std::to_string(count) + " numbers in " + path);
     return true;
 }
 
@@ -731,7 +687,9 @@ bool run_twins()
         sl3d_device_buffers b;
         int rc = sl3d_get_device_buffers(q.ctx, &b);
         // the part's 0/1 mask plane as a full-frame mask: frame pixel (gx, gy) = window pixel (gx, gy - row0)
-        const uint8_t *mask0 = b.mask + (ptrdiff_t)(2 - q.row0) * (ptrdiff_t)b.mask_pitch + 16;
+        // (as an integer: for a part below the frame's first rows that address lies in front of the plane -- it is only where row 0
+        // WOULD be; sl3d_set_masks reads, and classifies the memory at, the part's own rows)
+        const uint8_t *mask0 = (const uint8_t *)((uintptr_t)b.mask + (uintptr_t)((ptrdiff_t)(2 - q.row0) * (ptrdiff_t)b.mask_pitch + 16));
         if (rc == SL3D_OK) rc = sl3d_set_masks(q.twin, 0, 1, mask0, b.mask_pitch, 0);
         for (int a = 0; a < 2 && rc == SL3D_OK; a++) {
             const int n = g.F + 2 * (a == 0 ? g.Nv : g.Nh);
@@ -821,15 +779,16 @@ void write_deferred_debug_images()
 }  // namespace
 
 extern "C" void sl3d_shim_set_data_root(const char *dir)
-{
+try {
     g.root = dir ? dir : "";
     g.root_set = dir != nullptr;
 }
+SHIM_CATCH("sl3d_shim_set_data_root")
 extern "C" void sl3d_shim_write_debug_images(int enable) { g.write_debug = enable != 0; }
 extern "C" int sl3d_shim_last_status(void) { return g.status; }
 extern "C" const char *sl3d_shim_last_error(void) { return g.err.c_str(); }
 extern "C" void sl3d_shim_reset(void)
-{
+try {
     drop_ctx();
     std::vector<std::string>().swap(g.pcd_rows);
     std::vector<std::string>().swap(g.ply_rows);
@@ -837,13 +796,14 @@ extern "C" void sl3d_shim_reset(void)
     std::vector<uint8_t>().swap(g.cloud_rgb);
     std::vector<std::vector<uint8_t>>().swap(g.decode_scratch);
 }
+SHIM_CATCH("sl3d_shim_reset")
 extern "C" void sl3d_shim_host_transpose(int enable) { g.host_transpose = enable != 0; }
 extern "C" void sl3d_shim_globals(unsigned mask)
 {
     g.globals_mask = mask == SL3D_SHIM_G_ALL ? (unsigned)SL3D_SHIM_G_ALL : (mask & (unsigned)SL3D_SHIM_G_EVERY);
 }
 extern "C" int sl3d_shim_materialize(unsigned which)
-{
+try {
     g.status = SL3D_OK;
     if (!g.ctx || !g.ctx_deferred || !g.scan_done) {
         fail(SL3D_E_STATE, "sl3d_shim_materialize: no finished deferred scan (sl3d_shim_globals(mask != SL3D_SHIM_G_ALL), then the six stage calls)");
@@ -853,19 +813,22 @@ extern "C" int sl3d_shim_materialize(unsigned which)
     else fill_globals(which & (unsigned)SL3D_SHIM_G_EVERY);
     return g.status;
 }
+catch (...) { shim_caught("sl3d_shim_materialize"); return g.status; }
 extern "C" void sl3d_shim_cloud_format(int binary) { g.binary_clouds = binary != 0; }
 extern "C" void sl3d_shim_provide_image(const char *relative_path, const uint8_t *data, int width, int height, int channels, size_t stride)
-{
+try {
     if (!relative_path) return;
     if (!data) g.images.erase(relative_path);
     else g.images[relative_path] = Shim::MemImage{data, width, height, channels, stride};
 }
+SHIM_CATCH("sl3d_shim_provide_image")
 extern "C" void sl3d_shim_provide_matrix(const char *relative_path, const double *values, int count)
-{
+try {
     if (!relative_path) return;
     if (!values) g.matrices.erase(relative_path);
     else g.matrices[relative_path] = std::vector<double>(values, values + count);
 }
+SHIM_CATCH("sl3d_shim_provide_matrix")
 
 // ---- stage 1: generate_pattern() ----------------------------------------------------------------------
 // 1/pattern_generator.cpp:513-544.  The reference's allocate_memory() asks for the number of fringe patterns and the two
@@ -874,7 +837,7 @@ extern "C" void sl3d_shim_provide_matrix(const char *relative_path, const double
 // :224-229 does (and stores them in the globals, as the reference does), generates every pattern on the device and
 // saves the same files save_pattern_images() writes (:414-470) below <data root>/Generated_patterns/.
 void generate_pattern()
-{
+try {
     g.status = SL3D_OK;
     if (number_of_patterns_fringe < 3 || number_of_patterns_fringe > 5) { fail(SL3D_E_INVALID_ARG, "generate_pattern: 3, 4 or 5 fringe patterns"); return; }
     if (!ok(sl3d_pattern_counts(Projector_imagewidth, fringe_width_pixels_vertical, &number_of_codes_vertical, &number_of_patterns_binary_vertical), "sl3d_pattern_counts")) return;
@@ -904,10 +867,11 @@ void generate_pattern()
         }
     }
 }
+SHIM_CATCH("generate_pattern")
 
 // ---- stage 3 ----------------------------------------------------------------------------------------
 void compute_wrapped_phase(int pattern_type)
-{
+try {
     g.status = SL3D_OK;
     if (pattern_type != 0 && pattern_type != 1) return;
     if (!ensure_ctx()) return;
@@ -953,10 +917,11 @@ void compute_wrapped_phase(int pattern_type)
             write_bmp_gray(data_root() + "/Wrapped_phase_images/" + axis_dir(pattern_type) + "/Wrapped_phase_image.bmp", d.data());
     }
 }
+SHIM_CATCH("compute_wrapped_phase")
 
 // ---- stage 4 ----------------------------------------------------------------------------------------
 void unwrap_phase(int pattern_type)
-{
+try {
     g.status = SL3D_OK;
     if (pattern_type != 0 && pattern_type != 1) return;
     if (!g.ctx) { fail(SL3D_E_STATE, "unwrap_phase before compute_wrapped_phase"); return; }
@@ -1008,10 +973,11 @@ void unwrap_phase(int pattern_type)
                            d.data());
     }
 }
+SHIM_CATCH("unwrap_phase")
 
 // ---- stage 5 ----------------------------------------------------------------------------------------
 void compute_c_p_map()
-{
+try {
     g.status = SL3D_OK;
     if (!g.ctx) { fail(SL3D_E_STATE, "compute_c_p_map before the phase stages"); return; }
     if (g.ctx_deferred) return;  // deferred: stage 5 is part of triangulate()'s one launch
@@ -1024,10 +990,11 @@ void compute_c_p_map()
     // c_p_map is indexed [row*W + col] in the reference too (common_variables.h:15): the row-major plane is the global
     each_part("sl3d_get_c_p_map", [&](const Part &q) { return sl3d_get_c_p_map(q.ctx, 0, (int64_t *)c_p_map + 2 * (size_t)q.row0 * W); });
 }
+SHIM_CATCH("compute_c_p_map")
 
 // ---- stage 7 ----------------------------------------------------------------------------------------
 void triangulate()
-{
+try {
     g.status = SL3D_OK;
     if (!g.ctx) { fail(SL3D_E_STATE, "triangulate before compute_c_p_map"); return; }
     double cal[40];
@@ -1043,7 +1010,7 @@ void triangulate()
         // deferred: stages 3(v) 3(h) 4(v) 4(h) 5 7 as ONE launch of the timed fused kernel on the frames the stage calls brought up
         // (the launch the C ABI's sl3d_run makes: the same kernel bench.py times), then only the globals the mask names
         const bool launched = each_part("sl3d_run", [&](const Part &q) { return sl3d_run(q.ctx, 0, 1); });
-        g.scan_open = false;
+        g.scan_open = g.mask_fresh = false;  // (this scan is over whatever happened: EVERY exit of triangulate() -- fail() does the same)
         if (!launched) return;
         g.scan_done = true;
         if (g.globals_mask && !fill_globals(g.globals_mask)) return;
@@ -1061,6 +1028,7 @@ void triangulate()
     for (int r = 0; r < H; r++)
         for (int c = 0; c < W; c++) memcpy(intersection_points[c][r], &pts[3 * ((size_t)r * W + c)], 3 * sizeof(double));
 }
+SHIM_CATCH("triangulate")
 
 // ---- stage 8: save_point_cloud() ------------------------------------------------------------------------
 // 8/save_point_cloud.cpp:19-217: the valid pixels in row-major scan order (:85-104) as float xyz with the r,g,b of
@@ -1072,7 +1040,7 @@ void triangulate()
 // flavours of both formats (PCD "DATA binary", PLY "binary_little_endian"): the same values bit for bit, without the
 // float -> text -> float round trip, and ~30x faster to write.
 void save_point_cloud(unsigned cloud_index)
-{
+try {
     g.status = SL3D_OK;
     if (!g.ctx) { fail(SL3D_E_STATE, "save_point_cloud before triangulate"); return; }
     PhaseTimer pt;
@@ -1159,6 +1127,7 @@ void save_point_cloud(unsigned cloud_index)
     if (!ply_ok) { fail(SL3D_E_INVALID_ARG, "cannot write " + base + ".ply"); return; }
     fprintf(stderr, "Saved %lld data points to %s.pcd / .ply\n", (long long)n, base.c_str());
 }
+SHIM_CATCH("save_point_cloud")
 
 
 // ---- stage 9: register_point_clouds() -------------------------------------------------------------------
@@ -1166,79 +1135,11 @@ void save_point_cloud(unsigned cloud_index)
 // (tx,ty,tz) by theta_i (theta_0 = 0, theta_{i+1} = theta_i + rot_step in float, degrees with Pi = 22/7), colours kept,
 // concatenated into Point_cloud/registered_point_cloud.ply.  Reads the ASCII PLY files save_point_cloud() writes (vertex
 // properties x y z [red green blue] in any order, other properties ignored); the rotation runs on the device.
-namespace {
-struct PlyCloud {
-    std::vector<float> xyz;
-    std::vector<uint8_t> rgb;
-};
-// ASCII or binary_little_endian PLY with scalar vertex properties (what save_point_cloud() writes in either format)
-bool read_ply(const std::string &path, PlyCloud &c)
-{
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    char line[512];
-    long nv = -1;
-    std::vector<std::string> props, types;
-    bool ascii = false, binary = false, in_vertex = false, header_ok = false;
-    while (fgets(line, sizeof line, f)) {
-        char a[64] = "", b[64] = "", d[64] = "";
-        const int k = sscanf(line, "%63s %63s %63s", a, b, d);
-        if (k >= 1 && !strcmp(a, "end_header")) { header_ok = true; break; }
-        if (k >= 2 && !strcmp(a, "format")) { ascii = !strcmp(b, "ascii"); binary = !strcmp(b, "binary_little_endian"); }
-        if (k >= 3 && !strcmp(a, "element")) { in_vertex = !strcmp(b, "vertex"); if (in_vertex) nv = atol(d); }
-        if (k >= 3 && !strcmp(a, "property") && in_vertex && strcmp(b, "list")) { props.push_back(d); types.push_back(b); }
-    }
-    if (!header_ok || (!ascii && !binary) || nv < 0) { fclose(f); return false; }
-    int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1;
-    for (int i = 0; i < (int)props.size(); i++) {
-        if (props[i] == "x") ix = i; else if (props[i] == "y") iy = i; else if (props[i] == "z") iz = i;
-        else if (props[i] == "red" || props[i] == "r") ir = i; else if (props[i] == "green" || props[i] == "g") ig = i;
-        else if (props[i] == "blue" || props[i] == "b") ib = i;
-    }
-    if (ix < 0 || iy < 0 || iz < 0) { fclose(f); return false; }
-    c.xyz.resize((size_t)nv * 3);
-    c.rgb.assign((size_t)nv * 3, 0);
-    std::vector<double> v(props.size());
-    // byte size of a scalar PLY type (0 = unknown)
-    auto tsize = [](const std::string &t) -> int {
-        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
-        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
-        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
-        if (t == "double" || t == "float64") return 8;
-        return 0;
-    };
-    size_t rec = 0;
-    if (binary)
-        for (auto &t : types) { if (!tsize(t)) { fclose(f); return false; } rec += (size_t)tsize(t); }
-    std::vector<uint8_t> buf(rec);
-    for (long p = 0; p < nv; p++) {
-        if (binary) {
-            if (fread(buf.data(), 1, rec, f) != rec) { fclose(f); return false; }
-            size_t o = 0;
-            for (size_t i = 0; i < props.size(); i++) {
-                const std::string &t = types[i];
-                const int sz = tsize(t);
-                if (t == "float" || t == "float32") { float q; memcpy(&q, &buf[o], 4); v[i] = q; }
-                else if (t == "double" || t == "float64") { double q; memcpy(&q, &buf[o], 8); v[i] = q; }
-                else if (sz == 1) v[i] = (t == "char" || t == "int8") ? (double)(int8_t)buf[o] : (double)buf[o];
-                else if (sz == 2) { uint16_t q; memcpy(&q, &buf[o], 2); v[i] = (t == "short" || t == "int16") ? (double)(int16_t)q : (double)q; }
-                else { uint32_t q; memcpy(&q, &buf[o], 4); v[i] = (t == "int" || t == "int32") ? (double)(int32_t)q : (double)q; }
-                o += (size_t)sz;
-            }
-        } else {
-            for (size_t i = 0; i < props.size(); i++)
-                if (fscanf(f, "%lf", &v[i]) != 1) { fclose(f); return false; }
-        }
-        c.xyz[3 * p] = (float)v[ix]; c.xyz[3 * p + 1] = (float)v[iy]; c.xyz[3 * p + 2] = (float)v[iz];
-        if (ir >= 0 && ig >= 0 && ib >= 0) { c.rgb[3 * p] = (uint8_t)v[ir]; c.rgb[3 * p + 1] = (uint8_t)v[ig]; c.rgb[3 * p + 2] = (uint8_t)v[ib]; }
-    }
-    fclose(f);
-    return true;
-}
-}  // namespace
+using sl3d_io::PlyCloud;
+using sl3d_io::read_ply;
 
 void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float tz, float rot_step)
-{
+try {
     g.status = SL3D_OK;
     if (!ensure_ctx()) return;
     std::vector<float> all_xyz;
@@ -1274,3 +1175,4 @@ void register_point_clouds(unsigned num_point_clouds, float tx, float ty, float 
     }
     if (!write_pieces(outp, hdr, rows)) { fail(SL3D_E_INVALID_ARG, "cannot write " + outp); return; }
 }
+SHIM_CATCH("register_point_clouds")

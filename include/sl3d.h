@@ -271,8 +271,8 @@ int sl3d_fused_kernel_name(sl3d_ctx *ctx, int n_views, int clouds, char *buf, si
 int sl3d_last_fused_kernel_name(sl3d_ctx *ctx, char *buf, size_t capacity);
 /* Bytes per camera pixel a fused launch of n_views views reads from the camera-side table of sl3d_set_calibration (T1 per window pixel,
  * 7/triangulation.cpp:252-307), once per LAUNCH whatever the number of views: 0 = no table (no camera distortion, parity mode),
- * 8 = the radial factor as a double, 4 = its small-launch form (a per-calibration cubic in r0^2 + one float per pixel), 16 = the
- * normalised point (tangential terms).  Benchmarks state the bytes a launch moves beside the algorithmic ones with it.  < 0: error. */
+ * 8 = the radial factor as a double, 16 = the normalised point (tangential terms).  Benchmarks state the bytes a launch moves beside
+ * the algorithmic ones with it.  < 0: error. */
 int sl3d_camera_table_bytes_per_pixel(sl3d_ctx *ctx, int n_views);
 /* sl3d_run bracketed by HIP events on the context's stream; returns the kernel time of this launch */
 int sl3d_run_timed(sl3d_ctx *ctx, int first_view, int n_views, float *kernel_ms);

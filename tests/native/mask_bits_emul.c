@@ -112,6 +112,7 @@ int emul_check_byte_helpers(void)
  * stride multiples of 4, fullW >= 8), and every byte read must lie inside the mask (returns -1 - <count of bytes read outside>).
  * Outputs as emul_mask_prepare; returns the quads with a valid pixel. */
 static long g_oob;
+long g_plain_quads; /* quads the short form was checked on, over all calls */
 static void load8(const uint8_t *base, long off, const uint8_t *lo, const uint8_t *hi, unsigned *w0, unsigned *w1)
 {
     const uint8_t *p = base + off;
@@ -134,7 +135,7 @@ long emul_maskin(const uint8_t *mask, size_t stride, int fullW, int fullH, int c
     const int lo = direct ? LPAD - col0 : 0, hi = direct ? LPAD - col0 + fullW : mpitch;
     const uint8_t *mem_lo = direct ? mask : raw, *mem_hi = direct ? mask + (size_t)(fullH - 1) * stride + fullW : raw + (size_t)mpitch * rows;
     g_oob = 0;
-    long quads = 0;
+    long quads = 0, plain_mismatch = 0, n_plain = 0;
     /* planes the kernel never writes stay what the context's creation left them: zero */
     memset(norm, 0, (size_t)mpitch * rows);
     for (int row = 0; row < H; row++)
@@ -156,6 +157,13 @@ long emul_maskin(const uint8_t *mask, size_t stride, int fullW, int fullH, int c
             for (int a = 0; a < 4; a++) V[a] = (a == 0 && !have[0]) ? 0u : (mb_quad_word(w[a][0], w[a][1], delta) & c.REG);
             unsigned outw = mb_range_bits(0, W, cq * 4, 4);
             const unsigned v = mb_quad_valid(V[0], V[1], V[2], V[3], c, gy, fullH) & outw;
+            /* the short form of the plain interior (what whole waves of such lanes evaluate) must say the same */
+            if (mb_quad_plain(col0 + cq * 4, gy, fullW, fullH, gx0, gx1) && own - 2 >= lo && own + 6 <= hi && !first && !last && cq != 0 && cq != pitch / 4 - 1) {
+                n_plain++;
+                if (delta != -2 || have[0] || (c.REG & 0x3fcu) != 0x3fcu ||
+                    mb_quad_valid_plain(mb_quad_word(w[1][0], w[1][1], -2), mb_quad_word(w[2][0], w[2][1], -2), mb_quad_word(w[3][0], w[3][1], -2)) != v)
+                    plain_mismatch++;
+            }
             const unsigned vb = mb_expand_nibble(v);
             memcpy(band + (size_t)row * pitch + (size_t)cq * 4, &vb, 4);
             quads += v != 0;
@@ -169,5 +177,7 @@ long emul_maskin(const uint8_t *mask, size_t stride, int fullW, int fullH, int c
             }
         }
     free(raw);
+    g_plain_quads += n_plain;
+    if (plain_mismatch) return -1000000 - plain_mismatch;
     return g_oob ? -1 - g_oob : quads;
 }

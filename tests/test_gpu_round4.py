@@ -405,8 +405,16 @@ def test_small_launch_over_sparse_masks_takes_the_gated_kernel():
             assert np.array_equal(one[1], batch[v][1]) and np.array_equal(one[0], batch[v][0], equal_nan=True), v
             assert np.array_equal(sc.fused_clouds(v, 1)[0], clouds[v]), v
         frames = [(sc.frames(0, v), sc.frames(1, v)) for v in (0, 3, 4)]
+        # a new (dense) selection for view 0.  Since round 6 it is DEFERRED (evaluated by the launch that consumes it), so what is
+        # known is still the view's LAST selection: sparse -> k_mask_prepare + the gated kernel once more; that pass counts the new
+        # selection, and from then on a new mask + one view is ONE launch of the MASKIN instantiation
         sc.set_mask(dense, view=0)
-        assert sc.fused_kernel_name(1).endswith(", 1, 0, false, true>")                                        # view 0 is dense now
+        assert sc.fused_kernel_name(1).endswith(", 1, 0, true, false>"), sc.fused_kernel_name(1)
+        sc.run(0, 1)
+        sc.synchronize()
+        assert sc.fused_kernel_name(1).endswith(", 1, 0, false, true>"), sc.fused_kernel_name(1)               # view 0 is dense now
+        sc.set_mask(dense, view=0)
+        assert sc.fused_kernel_name(1).endswith(", 1, 4, false, true>"), sc.fused_kernel_name(1)               # ... and its next mask rides along
         assert sc.fused_kernel_name(5).endswith(", 1, 0, true, true>")                                         # a large launch, not all sparse: early requests
     for (v, m, got), fr in zip(((0, sparse, batch[0]), (3, sparse, batch[3]), (4, dense, mixed[1])), frames):
         o = Oracle(W, H, PW, PH, N, N, fw, fw)

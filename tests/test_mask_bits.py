@@ -161,6 +161,15 @@ def test_maskin_quads_read_a_callers_mask_in_place(emul):
             check_maskin(emul, mask, win, True, ref, (trial, win, stride))
 
 
+def test_maskin_short_form_was_exercised(emul):
+    """(runs after the tests above in file order) the short form of the plain interior was compared with the general one on many quads"""
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        mask = random_mask(rng, 96, 40, trial)
+        check_maskin(emul, mask, (0, 0, 96, 40), trial % 2 == 1, oracle_valid(mask), trial)
+    assert C.c_long.in_dll(emul, "g_plain_quads").value > 3000
+
+
 def test_maskin_degenerate_frames(emul):
     rng = np.random.default_rng(6)
     for FW, FH in ((1, 1), (1, 9), (9, 1), (2, 2), (2, 17), (17, 2), (3, 3), (8, 1), (8, 2)):

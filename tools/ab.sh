@@ -6,7 +6,7 @@
 #                   tools/ab.sh alt REPS [bench args]   -> the same, REPS times over, alternating the libraries (boxes drift by several
 #                                                          per cent within minutes: only alternating runs compare); CLOUDS=1 adds the
 #                                                          compacting launch, ONEVIEW=1 measures side.one_view_cold (one view per launch
-#                                                          from HBM) instead of the batch
+#                                                          from HBM) instead of the batch, PERSCAN=1 side.per_scan_device (new mask + one view)
 # ab/ is git-ignored but travels with gpurun.  The default library (3dscan_amd/libsl3d.so) is always measured as "base".
 set -u
 cd "$(dirname "$0")/.."
@@ -44,7 +44,9 @@ elif [ "$1" = alt ]; then
   for rep in $(seq 1 $reps); do
     for lib in 3dscan_amd/libsl3d.so ab/libsl3d_*.so; do
       [ -f "$lib" ] || continue
-      if [ "${ONEVIEW:-0}" = 1 ]; then
+      if [ "${PERSCAN:-0}" = 1 ]; then
+        r=$(SL3D_LIB=$PWD/$lib python3 tools/mask_timing.py 1920 1080 2>>gpurun_out/ab_stderr.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read())['per_scan_device']; t=d.get('two_kernel_route') or {}; print(d['scan_us'], 'us per scan,', d['kernel'].split('<')[1], '| two-kernel route', t.get('scan_us'), 'us, mask', t.get('mask_us'))")
+      elif [ "${ONEVIEW:-0}" = 1 ]; then
         r=$(SL3D_LIB=$PWD/$lib python3 bench.py --one-view-cold-only --steps 4000 "$@" 2>>gpurun_out/ab_stderr.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read())['one_view_cold']; print(d['launch_us'], 'us  frac', d['frac'], ' on moved bytes', d['frac_on_moved_bytes'])")
       else
         extra="--no-clouds"; [ "${CLOUDS:-0}" = 1 ] && extra=""
