@@ -1,5 +1,5 @@
 // sl3d_ctx.h -- the context behind the opaque sl3d_ctx handle, shared by the C-ABI translation units
-// (sl3d_capi.cpp: single-GPU entry points; sl3d_group.cpp: row-stripe groups over several GPUs).  Not part of the public ABI.
+// (sl3d_capi_*.cpp: single-GPU entry points; sl3d_group.cpp: row-stripe groups over several GPUs).  Not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,7 +29,7 @@ struct sl3d_ctx {
     int mask_raw_slots = 0;                   // k_mask_prepare; zero outside the copied region (the kernel relies on that)
     // quads with a valid pixel, per view: every block of k_mask_prepare stores {seq, count} into this host array (mapped into the
     // device: d_quad_part is the same memory as the kernels address it); the host adds a view's blocks up on demand and treats the
-    // view as unknown until every block carries the sequence number of the view's last preparation (quads_known, sl3d_capi.cpp)
+    // view as unknown until every block carries the sequence number of the view's last preparation (quads_known, sl3d_capi_inputs.cpp)
     volatile unsigned long long *h_quad_part = nullptr;
     unsigned long long *d_quad_part = nullptr;
     int quad_blocks = 0;                      // blocks per view
@@ -39,7 +39,7 @@ struct sl3d_ctx {
     unsigned mask_seq = 0;
     // Deferred masks (sl3d_set_mask(s) of at most SL3D_SMALL_LAUNCH_VIEWS views on a timed context, unless SL3D_FLAG_EAGER_MASK): the
     // view's selection has been handed over but not prepared -- the next small launch over such views evaluates it inside the fused
-    // kernel (a MASKIN launch, sl3d_fused.h), every other consumer of the view's planes prepares it first (flush_masks, sl3d_capi.cpp).
+    // kernel (a MASKIN launch, sl3d_fused.h), every other consumer of the view's planes prepares it first (flush_masks, sl3d_capi_inputs.cpp).
     struct PendingMask {
         bool pending = false;
         bool ours = false;     // the source is the context's staging plane (else the CALLER's device memory: prepared at the next synchronising call at the latest)
@@ -109,7 +109,7 @@ __attribute__((visibility("hidden"))) int sl3d_caught(sl3d_ctx *c, std::string *
 #define SL3D_CATCH(ctx) catch (...) { return sl3d_caught(ctx); }
 #define SL3D_CATCH_RETURN(value) catch (...) { (void)sl3d_caught(nullptr); return value; }
 #define SL3D_CATCH_VOID catch (...) { (void)sl3d_caught(nullptr); }
-// sl3d_process_views in two halves (sl3d_capi.cpp), shared with sl3d_group_process_views
+// sl3d_process_views in two halves (sl3d_capi_run.cpp), shared with sl3d_group_process_views
 __attribute__((visibility("hidden"))) int sl3d_process_views_enqueue(sl3d_ctx *x, int n_views, const uint8_t *const *planes, size_t stride, float *xyz,
                                                                      size_t xyz_view_stride, uint8_t *valid, size_t valid_view_stride, size_t out_width);
 __attribute__((visibility("hidden"))) int sl3d_process_views_wait(sl3d_ctx *x);

@@ -1,4 +1,4 @@
-// sl3d_internal.h -- structures shared by the C-ABI host code (sl3d_capi.cpp) and the HIP
+// sl3d_internal.h -- structures shared by the C-ABI host code (sl3d_capi_*.cpp) and the HIP
 // kernels (sl3d_kernels.hip).  Not part of the public ABI.
 #pragma once
 #include <stddef.h>
@@ -144,7 +144,7 @@ static_assert(SL3D_SMALL_LAUNCH_VIEWS == 4, "KParams::mi_origin holds one entry 
 
 // launchers (sl3d_fused_launch.hip, sl3d_kernels.hip); `stream` is a hipStream_t
 // cmode: 0 = dense xyz + valid planes, 2 = segmented clouds
-// prefer_gated: the views of a small launch are sparsely selected (sl3d_capi.cpp: sparse_views)
+// prefer_gated: the views of a small launch are sparsely selected (sl3d_capi_inputs.cpp: sparse_views)
 // mi != nullptr: a MASKIN launch (the views' valid bits from their raw selection; only where fused_maskin_available says so)
 int launch_fused(const KParams &P, const DevCal *d_cal, int rig, int first_view, int n_views, bool keep, int cmode, void *stream, bool prefer_gated = false,
                  const MaskIn *mi = nullptr);

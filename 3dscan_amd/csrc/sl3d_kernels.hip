@@ -26,7 +26,7 @@ namespace sl3d {
 // the per-stage kernel k_wrap reads) and the `band` plane (final valid bytes of every window pixel: what the fused kernel reads),
 // and counts the quads that hold a valid pixel: ONE 8-byte store per block {seq, count} into host memory mapped into the device --
 // no device atomics, no memset, no copy behind the kernel; the host adds the words up when it needs the number (sparse_views,
-// sl3d_capi.cpp) and knows by the sequence number whether every block of THIS preparation has landed.
+// sl3d_capi_inputs.cpp) and knows by the sequence number whether every block of THIS preparation has landed.
 // Two shapes (launch_mask_prepare; both measured per view with rocprofv3, profiles/r05_mask_variants.txt):
 //   OWN = 4,  256-thread blocks: many short waves -- the latency of a ~2-Mpx mask (1080p: 5.7 us against 6.5)
 //   OWN = 16, one wave per block: 16-byte loads and stores, a third of the arithmetic per pixel -- larger masks (12 Mpx: 13.0 us

@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak (default) = --views views per GPU per step, the batch grows with N; strong = BASELINE configs[3] as it is "
+                         "stated: --total-views views (64) row-sharded over the N GPUs, the same total work for every N")
+    ap.add_argument("--total-views", type=int, default=64, help="--scaling strong: views per step over all GPUs (configs[3]: 64)")
     ap.add_argument("--views", type=int, default=16, help="views per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -187,6 +191,10 @@ def rig_calibration(syn, np, rig, W, H, PW, PH):
     if rig == "general":
         Kc = np.array(cal_d["Kc"], dtype=np.float64).reshape(3, 3).copy()
         Kc[0, 1] = 0.35   # skew: the camera matrix is no longer "plain", so the camera-frame solve does not apply (RIG 0)
+        cal_d["Kc"] = Kc.ravel()
+    if rig == "rig0":     # K[1][0] != 0: not an upper-triangular camera matrix -- the un-pipelined general kernel (rig class 0)
+        Kc = np.array(cal_d["Kc"], dtype=np.float64).reshape(3, 3).copy()
+        Kc[1, 0] = 1e-3
         cal_d["Kc"] = Kc.ravel()
     return syn.cal_tuple(cal_d)
 
@@ -404,15 +412,34 @@ def one_scan_from_idle(args, scm, syn, np, dev_index):
     return out
 
 
+def config2_12mp(args, scm, syn, np, dev_index, W=4096, H=3000, views=3, fw=4, launches=150):
+    """BASELINE configs[2]: a 4096x3000 (12.3 Mpx) capture stack on one MI355X, N Gray planes per axis, `views` views resident and
+    processed per launch (3 x 737 MB of traffic; the small-launch instantiation at several views per lane), steady state, HIP events."""
+    N = args.ngray
+    full_mask = syn.default_mask(W, H)
+    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=views, device=dev_index) as sc:
+        sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
+        sc.set_masks(full_mask, first_view=0, n_views=views)
+        for v in range(views):
+            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=args.noise)
+        sc.run(0, views)      # (the masks are consumed: every timed launch is an ordinary one)
+        sc.synchronize()
+        v, f, ms = steady_rate(sc, views, views * W * H, 20 + 4 * N, launches)
+        return {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "width": W, "height": H, "views_per_launch": views,
+                "algorithmic_bytes_per_pixel": 20 + 4 * N, "kernel": sc.last_fused_kernel_name(),
+                "note": "BASELINE configs[2]: 4096x3000, 3 phase + 2x%d Gray frames per axis, %d views per launch" % (N, views)}
+
+
 def side_figures(args, scm, syn, np, dev_index):
     """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
     out = {}
     full_mask = syn.default_mask(W, H)
 
-    def ctx(rig, n_gray, views, proj=None, **kw):
+    def ctx(rig, n_gray, views, proj=None, fw_override=None, **kw):
         PW, PH = (proj, min(proj, H)) if proj else (W, H)
-        sc = scm.Scanner(W, H, PW, PH, n_gray, n_gray, fw, fw, max_views=views, device=dev_index, **kw)
+        f_ = fw_override or fw
+        sc = scm.Scanner(W, H, PW, PH, n_gray, n_gray, f_, f_, max_views=views, device=dev_index, **kw)
         sc.set_calibration(*rig_calibration(syn, np, rig, W, H, PW, PH))
         for v in range(views):
             sc.set_mask(full_mask, view=v)
@@ -443,6 +470,19 @@ def side_figures(args, scm, syn, np, dev_index):
         with ctx("reference", N - 1, args.views, proj=min(W, fw << (N - 1))) as sc:   # (a shorter Gray code covers a smaller projector)
             v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * (N - 1), 400)
             out[f"n_gray_{N - 1}"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "algorithmic_bytes_per_pixel": 20 + 4 * (N - 1)}
+        # The kernel families and BASELINE configurations no other figure of this line times (round 5's review): the un-pipelined general
+        # kernel (rig class 0: a camera matrix that is not upper triangular), more than 12 Gray planes per axis (the per-plane-test
+        # kernels, every rig class on the general kernel), and BASELINE configs[2] (4096x3000, 3 views per launch: what fits beside
+        # the headline's buffers).  Each names the instantiation that ran.
+        with ctx("rig0", N, args.views) as sc:
+            v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 300)
+            out["rig0_general"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "kernel": sc.last_fused_kernel_name(),
+                                   "note": "camera K[1][0] != 0: rig class 0, the un-pipelined kernel that evaluates every rig"}
+        with ctx("reference", 14, args.views, fw_override=1) as sc:
+            v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * 14, 200)
+            out["n_gray_14"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "algorithmic_bytes_per_pixel": 20 + 4 * 14,
+                                "kernel": sc.last_fused_kernel_name(), "note": "14 Gray planes per axis (fringe width 1): the per-plane-test kernel"}
+        out["config2_12mp"] = config2_12mp(args, scm, syn, np, dev_index)
     except Exception as e:
         out["error"] = repr(e)
     # the Level-1 drop-in path: the reference's six stage calls + save_point_cloud() through the shim at the reference's own
@@ -512,7 +552,22 @@ def main():
     dev_index = devs[rank]
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    rank_report = [{"rank": 0, "device": dev_index, "gpu": torch.cuda.get_device_name(dev_index), "comm_size": 1}]
+    def identity():
+        """what the driver needs to confirm N ranks on N GPUs: the device's PCI bus id and the RCCL this process binds"""
+        info = {}
+        try:
+            p = torch.cuda.get_device_properties(dev_index)
+            info["pci_bus_id"] = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1) & 0xff, getattr(p, "pci_device_id", 0) & 0xff)
+            info["uuid"] = str(getattr(p, "uuid", ""))
+        except Exception as e:
+            info["pci_bus_id"] = "unknown (%r)" % (e,)
+        try:
+            info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:
+            info["rccl_version"] = "unknown (%r)" % (e,)
+        return info
+
+    rank_report = [{"rank": 0, "device": dev_index, "gpu": torch.cuda.get_device_name(dev_index), "comm_size": 1, **identity()}]
     if world > 1:
         import datetime
         # a bounded rendezvous: a rank that never shows up (partial node, a rank that died on start) fails the others within
@@ -525,12 +580,13 @@ def main():
         # what every rank really got: its device and the size of the communicator it is part of, on stderr per rank and
         # (gathered) in rank 0's line -- the first collective of the run, so a broken fabric shows up here, not in the timing
         mine = {"rank": rank, "device": dev_index, "gpu": torch.cuda.get_device_name(dev_index), "comm_size": dist.get_world_size(),
-                "backend": dist.get_backend(), "pid": os.getpid()}
+                "backend": dist.get_backend(), "pid": os.getpid(), **identity()}
         print(f"[bench rank {rank}/{world}] device {dev_index} ({mine['gpu']}), communicator of {mine['comm_size']} ranks, backend {mine['backend']}",
               file=sys.stderr, flush=True)
         rank_report = [None] * world
         dist.all_gather_object(rank_report, mine)
-        if any(r["comm_size"] != world for r in rank_report) or (args.backend == "nccl" and len({r["device"] for r in rank_report}) != world):
+        if any(r["comm_size"] != world for r in rank_report) or (args.backend == "nccl" and (len({r["device"] for r in rank_report}) != world or
+                                                                                               len({r["pci_bus_id"] for r in rank_report}) != world)):
             raise SystemExit(f"rank {rank}: inconsistent job: {rank_report}")
     red_dev = dev if args.backend == "nccl" else None  # where the tiny timing reductions live
 
@@ -539,7 +595,11 @@ def main():
     W, H, N, fw, V = args.width, args.height, args.ngray, args.fringe_width, args.views
     PW, PH = W, H
     row0, rows = dmod.shard_rows(H, world, rank)
-    n_views = V * world  # batch grows with the GPU count; each GPU holds `rows` rows of every view
+    # weak scaling (default): the batch grows with the GPU count, each GPU holds `rows` rows of every view.  strong: configs[3] itself --
+    # a fixed batch of --total-views views, each row-sharded over the N GPUs (at N = 1: all rows of all views on one GPU)
+    n_views = args.total_views if args.scaling == "strong" else V * world
+    if args.scaling == "strong":
+        V = n_views // world if n_views % world == 0 else max(1, n_views // world)   # (views a rotating assembly leaves on each rank)
 
     if args.idle_only:
         emit(json.dumps({"one_scan_from_idle": one_scan_from_idle(args, scm, syn, np, dev_index)}))
@@ -610,12 +670,13 @@ def main():
     out = {
         "metric": "Mpixels/s decode+unwrap+triangulate @1920×1080",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (planes through the reference rig, generated on the device, a different plane and noise stream per view)",
         "config": {"workload": f"configs[1]: {W}x{H} camera, 3 phase-shift + {N} Gray-code bit planes per axis, two axes, "
                                f"Gray frames thresholded against inverse frames (46 frames/view); one step = one fused-kernel "
-                               f"launch over {V} views per GPU, frames resident in HBM",
-                   "views_per_gpu_per_step": V, "rows_per_gpu": rows, "frames_per_view": 2 * (3 + 2 * N),
+                               f"launch over {n_views} views ({rows} rows of each) per GPU, frames resident in HBM"
+                               + (f"; configs[3]: a fixed batch of {n_views} views row-sharded over {world} GPU(s)" if args.scaling == "strong" else ""),
+                   "views_per_gpu_per_step": V, "views_per_step": n_views, "rows_per_gpu": rows, "frames_per_view": 2 * (3 + 2 * N),
                    "projector": f"{PW}x{PH}", "fringe_width": fw, "sharding": "image rows" if world > 1 else "none",
                    "rig": args.rig, "setup_preconditioning_ms": args.precondition_ms},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -812,6 +873,11 @@ def single_rank_digests(np, sc, n_views):
     return {"dense_sha256": hd.hexdigest(), "compact_sha256": hc.hexdigest()}
 
 
+def syn_full_mask(W, H):
+    import importlib
+    return importlib.import_module("3dscan_amd.synth").default_mask(W, H)
+
+
 def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, V, rows, W, H, rank, world, px_per_step, digests):
     """End to end WITH the assembly of the clouds on rank 0 (the north star's single gather), pipelined: the batch is cut
     into chunks of views; chunk k's stripes leave on the communication stream (one grouped batch of sends that land in place
@@ -895,7 +961,7 @@ def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, 
                 sc.download_views(0, n_views, hp, hv)     # 2-D copies on the compute stream, then one wait
 
         if herr is None:
-            steps_of["host_parallel"] = host_step
+            steps_of["host_parallel"] = host_step   # (measured and reported; never a headline candidate: see the end of this function)
         t = timed(host_step, max(2, reps // 4))
         res["host_parallel"] = ({"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 3),
                                  "bytes_to_host_per_rank_per_step": int(n_views * rows * W * 13),
@@ -938,8 +1004,28 @@ def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, 
                 h.update(out_cloud[o:o + 3 * c].cpu().numpy().tobytes())
             digests["compact_sha256"] = h.hexdigest()
 
+        # ---- the same on the reference's own kind of selection: 358,580 of 1,920,000 pixels (18.7 %) lie inside the lasso of its real
+        # captures -- the one case in which the north star's SINGLE-root gather carries a fifth of the bytes.
+        # Every view gets a centred rectangle of that share; afterwards the full-frame masks are back.
+        try:
+            share = 358580.0 / 1920000.0
+            mh, mw = int(round(H * share ** 0.5)), int(round(W * share ** 0.5))
+            lasso = np_mod.zeros((H, W), np_mod.uint8)
+            lasso[(H - mh) // 2:(H - mh) // 2 + mh, (W - mw) // 2:(W - mw) // 2 + mw] = 1
+            sc.set_masks(lasso, 0, n_views)
+            t = timed(compact_step, reps)
+            res["compact_root_gather_19pct_selection"] = {"value": round(px_per_step / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(t * 1e3, 3),
+                                                          "points_per_step": int(sum(state["counts"])), "selected_fraction": round(float(lasso.mean()), 4),
+                                                          "note": "compact_root_gather with the share of the frame the reference's real captures select; never the headline"}
+        except Exception as e:
+            res["compact_root_gather_19pct_selection"] = {"error": repr(e)}
+        finally:
+            sc.set_masks(syn_full_mask(W, H), 0, n_views)
+            sc.run(0, n_views)
+            sc.synchronize()
+
         # ---- rotating roots: one all_to_all after the compute (every rank assembles V of the views) ----
-        if nccl:
+        if nccl and n_views == V * world:   # (a strong-scaled batch that does not divide by N has no equal shares to rotate)
             def rot_step(first):
                 sc.run(0, n_views)
                 ev_run[0].record(compute_stream)
@@ -1012,7 +1098,17 @@ def measure_assembly(args, torch, dist, dmod, sc, compute_stream, dev, n_views, 
             res["whole_views_no_exchange"] = {"error": repr(e)}
         # ---- the headline of an N > 1 line: the best ASSEMBLED variant, timed once more over exactly --steps steps between barriers
         # (the calibration runs above decide which; the choice is the same on every rank: the figures are MAX-over-ranks already) ----
-        best = max((k for k in steps_of if "value" in res.get(k, {})), key=lambda k: res[k]["value"], default=None)
+        # Candidates: only variants that leave COMPLETE DENSE views on a rank -- the gather to the root and the rotating assemblies.
+        # host_parallel (every rank keeps its own rows in its own host buffer: nobody holds an assembled view) and compact_root_gather
+        # (another payload: clouds, not dense planes) are reported beside it, never as `value`.  The choice is rank 0's,
+        # handed to every rank: a variant that failed on ONE rank only must not make the ranks time different collectives.
+        names = sorted(k for k in steps_of if k.startswith("dense_"))
+        ok_here = [1.0 if "value" in res.get(k, {}) else 0.0 for k in names]
+        ok_all = [dmod.max_over_ranks(-x, dev if nccl else None) == -1.0 for x in ok_here]   # (min over ranks through the max reduction)
+        cand = [k for k, ok in zip(names, ok_all) if ok]
+        pick = float(names.index(max(cand, key=lambda k: res[k]["value"]))) if (cand and rank == 0) else -1.0
+        pick = int(dmod.max_over_ranks(pick, dev if nccl else None))
+        best = names[pick] if pick >= 0 else None
         if best is not None:
             t = timed(steps_of[best], args.steps)
             res[best]["headline_value"] = round(px_per_step / t / 1e6, 1)

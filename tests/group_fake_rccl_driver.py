@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs in a FRESH process (started by tests/test_gpu_round4.py) with SL3D_RCCL_LIB pointing at the test double of librccl
+"""Runs in a FRESH process (started by tests/test_gpu_group.py) with SL3D_RCCL_LIB pointing at the test double of librccl
 (tests/native/fake_rccl.cpp): the library binds its seven RCCL entry points once per process, so the double has to be in place
 before the first group is created.
 

@@ -1,7 +1,7 @@
 // Two host threads at the C ABI at once (threading row: "contexts independent and thread-safe with respect to
 // each other").  The reference's callers are single-threaded (intermodule_dependencies.h); the C ABI promises more, so it is
 // exercised: both threads start behind one gate, so the FIRST sl3d_create of the process -- the one that runs the one-time
-// atan2 self-check under a mutex (sl3d_capi.cpp) -- is raced; each thread then creates / uses / destroys its own context
+// atan2 self-check under a mutex (sl3d_capi_context.cpp) -- is raced; each thread then creates / uses / destroys its own context
 // `rounds` times (different shapes; thread 0 in parity mode through the per-stage entry points, thread 1 in the timed mode
 // with two view slots, the fused kernel and the in-kernel compaction), generating its captures on the device.  The last
 // round's inputs and results are dumped for tests/test_gpu_round3.py, which replays the dumped frames through the oracle.

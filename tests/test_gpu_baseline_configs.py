@@ -1,10 +1,16 @@
-"""GPU tests (-m gpu) of the round-2 rows: the ordered compaction inside the fused kernel (sl3d_run_clouds), the mask
-preparation on the device, row-stripe groups behind the C ABI (sl3d_group_*: the multi-GPU path of the reference's single
-process, here with several stripes on one GPU), and BASELINE configs[2] / [3] / [4] at their full sizes."""
+"""GPU tests (-m gpu): BASELINE.json's configurations at their FULL sizes against the oracle -- configs[2] (4096x3000), configs[3] (64 views x
+8 row stripes), configs[4] (8192x6144, two axes, 12 Gray planes, as 8 stripes on one GPU) -- plus the other rig classes, Gray depths and
+fringe counts at 1920x1080 and contexts whose views straddle 4-GiB boundaries."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import assert_points_close, pkg
+from conftest import ROOT, assert_points_close, pkg
 from oracle.oracle import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -12,255 +18,6 @@ pytestmark = pytest.mark.gpu
 
 def _S():
     return pkg("scanner")
-
-
-def _random_mask(rng, W, H, holes=6):
-    m = np.zeros((H, W), np.uint8)
-    m[1:H - 1, 1:W - 1] = 1
-    for _ in range(holes):
-        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
-        w, h = int(rng.integers(1, max(2, W // 3))), int(rng.integers(1, max(2, H // 3)))
-        m[y:y + h, x:x + w] = rng.integers(0, 2)
-    m[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 0
-    m[rng.integers(0, H, 10), rng.integers(0, W, 10)] = 7   # selected iff == 1
-    return m
-
-
-# ---- ordered compaction inside the fused kernel ------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(640, 200, 8, 8, 4), (333, 77, 9, 9, 4), (200, 120, 6, 5, 16), (1021, 64, 7, 7, 4), (64, 3, 6, 6, 8)])
-@pytest.mark.parametrize("dist_proj", [False, True])
-def test_fused_compaction_equals_dense(shape, dist_proj):
-    """sl3d_run_clouds (segmented ordered clouds written by the fused kernel itself): the cloud of every view equals xyz[valid]
-    of the dense pass (8/save_point_cloud.cpp:85-104 order), the valid map is the same, repeated launches and sub-ranges too."""
-    S, syn = _S(), pkg("synth")
-    W, H, Nv, Nh, fw = shape
-    PW, PH, NV = 512, 384, 5
-    rng = np.random.default_rng(W * 7 + H)
-    caps = [syn.make_capture(W, H, PW, PH, Nv, Nh, fw, fw, view=v, noise=2, plane=(2.0 * v, 0.05, 0.03 + 0.01 * v)) for v in range(NV)]
-    cal = {k: np.array(v, dtype=np.float64).copy() for k, v in caps[0]["cal"].items()}
-    if dist_proj:
-        cal["dp"] = np.array([0.04, -0.01, 0.001, -0.0005, 0.0])
-    with S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=NV) as sc:
-        sc.set_calibration(*syn.cal_tuple(cal))
-        for v, c in enumerate(caps):
-            sc.set_mask(_random_mask(rng, W, H) if v else c["mask"], view=v)
-            sc.set_frames(0, c["planes_v"], view=v)
-            sc.set_frames(1, c["planes_h"], view=v)
-        sc.run(0, NV)
-        dense = [sc.points(v) for v in range(NV)]
-        for rep in range(3):
-            first, n = (0, NV) if rep != 1 else (1, NV - 2)   # a sub-range too
-            clouds = sc.fused_clouds(first, n)
-            for k, cl in enumerate(clouds):
-                xyz, val = dense[first + k]
-                assert cl.shape[0] == int((val == 1).sum()), (rep, k)
-                assert np.array_equal(cl, xyz[val == 1]), (rep, k)
-                assert np.array_equal(sc.valid_map(view=first + k), val)
-        assert sum(len(c) for c in clouds) > 0
-        # the older three-launch compaction still agrees
-        for v in range(NV):
-            assert np.array_equal(sc.cloud(v), dense[v][0][dense[v][1] == 1])
-
-
-def test_fused_compaction_full_hd_batch():
-    """BASELINE configs[1] shape: 16 views of 1920x1080 in one launch (2025 tiles per view, 4 views per lane): every
-    cloud equals xyz[valid]; a sparse mask and an empty mask included.  The dense planes AND the clouds of the segmented kernel
-    (k_fused<..., CMODE = 2>) are compared DIRECTLY with the oracle: valid map / point count bit exact, the cloud against the
-    oracle's own row-major append (8/save_point_cloud.cpp:85-104) point by point within 1e-5."""
-    S, syn = _S(), pkg("synth")
-    W, H, N, fw, NV = 1920, 1080, 10, 2, 16
-    cal = syn.cal_tuple(syn.synth_rig(W, H, W, H))
-    rng = np.random.default_rng(5)
-    with S.Scanner(W, H, W, H, N, N, fw, fw, max_views=NV) as sc:
-        sc.set_calibration(*cal)
-        for v in range(NV):
-            m = syn.default_mask(W, H)
-            if v == 3:
-                m[:] = 0
-            elif v == 5:
-                m = _random_mask(rng, W, H, holes=30)
-            elif v == 7:
-                m[:, ::2] = 0
-            sc.set_mask(m, view=v)
-            sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=2)
-        sc.run(0, NV)
-        dense = [sc.points(v) for v in range(NV)]
-        for rep in range(2):
-            clouds = sc.fused_clouds(0, NV)
-            for v in range(NV):
-                xyz, val = dense[v]
-                assert np.array_equal(clouds[v], xyz[val == 1]), v
-        assert len(clouds[3]) == 0 and len(clouds[0]) > 1_900_000
-        # the batched launch (the benchmark's exact shape) against the oracle, view by view: full, empty, holes, every other column, last
-        for v in (0, 3, 5, 7, 15):
-            m = syn.default_mask(W, H)
-            if v == 3:
-                m[:] = 0
-            elif v == 5:
-                m = _random_mask(np.random.default_rng(5), W, H, holes=30)
-            elif v == 7:
-                m[:, ::2] = 0
-            o = Oracle(W, H, W, H, N, N, fw, fw)
-            o.set_mask(m)
-            o.set_calibration(*cal)
-            oxyz, ovalid, _ = o.run_scan_rowmajor(sc.frames(0, v), sc.frames(1, v))
-            assert np.array_equal(dense[v][1], ovalid), v
-            assert_points_close(dense[v][0], oxyz, ovalid == 1)
-            # the cloud the compacting instantiation wrote, against the oracle's append in scan order (not against the dense pass)
-            ocloud = oxyz[ovalid == 1]
-            assert clouds[v].shape == ocloud.shape, v
-            if len(ocloud):
-                assert_points_close(clouds[v], ocloud, np.ones(len(ocloud), bool))
-
-
-# ---- mask preparation on the device -------------------------------------------------------------------------------------
-def test_device_mask_preparation_windows_and_borders():
-    """sl3d_set_mask prepares the mask on the device (normalisation + border band by k_mask_prepare): valid maps of
-    windows that touch every frame border, with arbitrary mask bytes, equal the oracle's boundary removal; pinned and
-    pageable sources give the same."""
-    S, syn = _S(), pkg("synth")
-    FW, FH, PW, PH, N, fw = 150, 90, 256, 192, 6, 8
-    rng = np.random.default_rng(11)
-    cap = syn.make_capture(FW, FH, PW, PH, N, N, fw, fw, noise=1)
-    cal = syn.cal_tuple(cap["cal"])
-    for trial in range(4):
-        mask = _random_mask(rng, FW, FH, holes=10)
-        if trial == 0:
-            mask[:] = 1   # border pixels selected too
-        o = Oracle(FW, FH, PW, PH, N, N, fw, fw)
-        o.set_mask(mask)
-        o.set_calibration(*cal)
-        o.run_scan(cap["planes_v"], cap["planes_h"])
-        vo = o.valid_map(2)
-        for (x0, y0, w, h) in [(0, 0, FW, FH), (0, 0, 70, 40), (83, 51, 67, 39), (5, 0, 100, 90), (0, 7, 150, 50), (31, 29, 17, 5)]:
-            with S.Scanner(w, h, PW, PH, N, N, fw, fw, full_size=(FW, FH), origin=(x0, y0), keep_stages=True) as sc:
-                sc.set_calibration(*cal)
-                pm = sc.pinned(mask.shape, np.uint8)
-                pm[:] = mask
-                for src in (mask, pm):
-                    sc.set_mask(src)
-                    sc.set_frames(0, [p[y0:y0 + h, x0:x0 + w] for p in cap["planes_v"]])
-                    sc.set_frames(1, [p[y0:y0 + h, x0:x0 + w] for p in cap["planes_h"]])
-                    sc.run()
-                    assert np.array_equal(sc.valid_map(0), o.valid_map(0)[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
-                    assert np.array_equal(sc.valid_map(2), vo[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
-                    sc.run_stages()
-                    assert np.array_equal(sc.valid_map(2), vo[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
-
-
-def test_set_frames_one_copy_per_axis_and_download():
-    """Planes that follow each other in host memory go up as ONE 2-D copy per axis (pageable and pinned sources); the result
-    equals plane-by-plane uploads.  sl3d_download returns device addresses the library hands out."""
-    S, syn = _S(), pkg("synth")
-    W, H, PW, PH, N, fw = 203, 77, 256, 192, 6, 8     # width != device pitch: the copy really is 2-D
-    cap = syn.make_capture(W, H, PW, PH, N, 5, fw, fw, noise=2)
-    cal = syn.cal_tuple(cap["cal"])
-    with S.Scanner(W, H, PW, PH, N, 5, fw, fw, max_views=3) as sc:
-        sc.set_calibration(*cal)
-        stack_v, stack_h = np.stack(cap["planes_v"]), np.stack(cap["planes_h"])
-        pin_v, pin_h = sc.pinned(stack_v.shape, np.uint8), sc.pinned(stack_h.shape, np.uint8)
-        pin_v[:], pin_h[:] = stack_v, stack_h
-        for v, (pv, ph) in enumerate(((cap["planes_v"], cap["planes_h"]), (list(stack_v), list(stack_h)), (list(pin_v), list(pin_h)))):
-            sc.set_mask(cap["mask"], view=v)
-            sc.set_frames(0, pv, view=v)
-            sc.set_frames(1, ph, view=v)
-        sc.run(0, 3)
-        ref = sc.points(0)
-        for v in (1, 2):
-            got = sc.points(v)
-            assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0], equal_nan=True), v
-            for a in (0, 1):
-                for x, y in zip(sc.frames(a, v), sc.frames(a, 0)):
-                    assert np.array_equal(x, y)
-        b = sc.device_buffers()
-        row = np.empty(W, dtype=np.uint8)
-        sc._d2h(row, b.valid + 5 * b.valid_pitch)
-        assert np.array_equal(row, ref[1][5])
-
-
-# ---- row-stripe groups behind the C ABI -----------------------------------------------------------------------------------
-def _single_context_reference(W, H, PW, PH, N, fw, cal, masks, caps):
-    S = _S()
-    out = []
-    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=len(caps)) as sc:
-        sc.set_calibration(*cal)
-        for v, c in enumerate(caps):
-            sc.set_mask(masks[v], view=v)
-            sc.set_frames(0, c["planes_v"], view=v)
-            sc.set_frames(1, c["planes_h"], view=v)
-        sc.run(0, len(caps))
-        for v in range(len(caps)):
-            out.append(sc.points(v))
-    return out
-
-
-@pytest.mark.parametrize("n_stripes,H", [(4, 200), (4, 203), (7, 64), (1, 50)])
-@pytest.mark.parametrize("transport", ["copy", "rccl"])
-def test_group_stripes_equal_single_context(n_stripes, H, transport):
-    """sl3d_group_*: n row stripes (unequal heights included) on GPU 0, run + gather == the single-context result bit for
-    bit (valid, xyz), dense and compacted; with device copies and with the RCCL send/recv path forced (self sends)."""
-    S, syn = _S(), pkg("synth")
-    W, PW, PH, N, fw, NV = 320, 512, 384, 7, 4, 3
-    rng = np.random.default_rng(H + n_stripes)
-    caps = [syn.make_capture(W, H, PW, PH, N, N, fw, fw, view=v, noise=2, plane=(3.0 * v, 0.05, 0.02 * v)) for v in range(NV)]
-    cal = syn.cal_tuple(caps[0]["cal"])
-    masks = [caps[0]["mask"]] + [_random_mask(rng, W, H) for _ in range(NV - 1)]
-    ref = _single_context_reference(W, H, PW, PH, N, fw, cal, masks, caps)
-    flags = S.SL3D_FLAG_GROUP_FORCE_RCCL if transport == "rccl" else S.SL3D_FLAG_GROUP_NO_RCCL
-    with S.Group(W, H, PW, PH, N, N, fw, fw, devices=[0] * n_stripes, max_views=NV, flags=flags) as g:
-        assert g.transport == transport
-        st = g.stripes()
-        assert st[0][0] == 0 and sum(s[1] for s in st) == H and max(s[1] for s in st) - min(s[1] for s in st) <= 1
-        g.set_calibration(*cal)
-        for v, c in enumerate(caps):
-            g.set_mask(masks[v], view=v)
-            g.set_frames(0, c["planes_v"], view=v)
-            g.set_frames(1, c["planes_h"], view=v)
-        # pipelined the way a caller would: compute view v+1 while view v's stripes travel
-        for v in range(NV):
-            g.run(v, 1)
-            g.gather(v, 1)
-        for rep in range(2):
-            for v in range(NV):
-                xyz, val = g.points(v)
-                assert np.array_equal(val, ref[v][1]), (rep, v)
-                assert np.array_equal(xyz, ref[v][0], equal_nan=True), (rep, v)
-            g.run(0, NV)      # the whole batch in one launch per stripe, one exchange
-            g.gather(0, NV)
-        g.run_clouds(0, NV)
-        counts = g.gather_clouds(0, NV)
-        for v in range(NV):
-            cl = g.cloud(v)
-            assert counts[v] == len(cl) == int((ref[v][1] == 1).sum())
-            assert np.array_equal(cl, ref[v][0][ref[v][1] == 1]), v
-        g.synchronize()
-
-
-def test_group_many_messages_rccl_path():
-    """A gather of 40 views x 7 stripes x (xyz + valid) = 560 messages through the forced RCCL path: the exchange is cut into
-    several RCCL groups of at most 256 send/recv pairs, in the same order on both sides."""
-    S, syn = _S(), pkg("synth")
-    W, H, PW, PH, N, fw, NV, NS = 64, 28, 128, 96, 6, 4, 40, 7
-    cap = syn.make_capture(W, H, PW, PH, N, N, fw, fw, noise=1)
-    cal = syn.cal_tuple(cap["cal"])
-    rng = np.random.default_rng(3)
-    masks = [_random_mask(rng, W, H, holes=3) for _ in range(NV)]
-    ref = _single_context_reference(W, H, PW, PH, N, fw, cal, masks, [cap] * NV)
-    with S.Group(W, H, PW, PH, N, N, fw, fw, devices=[0] * NS, max_views=NV, flags=S.SL3D_FLAG_GROUP_FORCE_RCCL) as g:
-        g.set_calibration(*cal)
-        for v in range(NV):
-            g.set_mask(masks[v], view=v)
-            g.set_frames(0, cap["planes_v"], view=v)
-            g.set_frames(1, cap["planes_h"], view=v)
-        g.run(0, NV)
-        g.gather(0, NV)
-        for v in range(NV):
-            xyz, val = g.points(v)
-            assert np.array_equal(val, ref[v][1]) and np.array_equal(xyz, ref[v][0], equal_nan=True), v
-        g.run_clouds(0, NV)
-        counts = g.gather_clouds(0, NV)
-        for v in range(NV):
-            assert np.array_equal(g.cloud(v), ref[v][0][ref[v][1] == 1]) and counts[v] == int((ref[v][1] == 1).sum())
 
 
 # ---- BASELINE configs at their full sizes ---------------------------------------------------------------------------------
@@ -610,3 +367,45 @@ def test_fringe_counts_full_hd_vs_oracle(F):
         assert np.array_equal(valid, ovalid)
         assert int((ovalid == 1).sum()) > 1_500_000
         assert_points_close(xyz, oxyz, ovalid == 1)
+
+
+# ---- a context larger than 4 GiB: results do not depend on where in the address space a view lies -------------------------------
+def test_views_across_4gib_boundaries():
+    """The kernels address a view's planes and results as (wave-uniform 64-bit base) + (32-bit lane offset).  400 views of 1 Mpx keep
+    5 GB of points and 20 GB of frames in single allocations, so the bases of the views picked here differ in every one of the address
+    bits 31..34 (a base whose low half has bit 31 set once came back sign-extended from a scalar read: intermittent faults, caught
+    by the A/B runs, not by a test -- hence this one).  Dense results and ordered clouds of views spread over the allocation, each
+    launched alone (small-launch kernels) and in a batch of 6 (the large-launch kernels), against the oracle."""
+    from oracle.oracle import Oracle
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, PW, PH, N, fw = 1024, 1024, 1024, 768, 9, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
+    mask = syn.default_mask(W, H)
+    picks = [0, 97, 171, 172, 255, 342, 394]
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=400) as sc:
+        sc.set_calibration(*cal)
+        for v in picks + list(range(394, 400)):
+            sc.set_mask(mask, view=v)
+            sc.synth_view(v, plane=(0.01 * v, 0.04, 0.03), view_id=v, noise=2)
+        got = {}
+        for v in picks:
+            sc.run(v, 1)
+            got[v] = sc.points(v)
+            cl = sc.fused_clouds(v, 1)[0]
+            assert np.array_equal(cl, got[v][0][got[v][1] == 1]), v
+        sc.run(394, 6)
+        batch = [sc.points(v) for v in range(394, 400)]
+        clouds = sc.fused_clouds(394, 6)
+        assert np.array_equal(batch[0][1], got[394][1]) and np.array_equal(batch[0][0], got[394][0], equal_nan=True)
+        for i in range(6):
+            assert np.array_equal(clouds[i], batch[i][0][batch[i][1] == 1]), i
+        frames = {v: (sc.frames(0, v), sc.frames(1, v)) for v in picks + [399]}
+        got[399] = batch[5]
+    for v in picks + [399]:
+        o = Oracle(W, H, PW, PH, N, N, fw, fw)
+        o.set_mask(mask)
+        o.set_calibration(*cal)
+        oxyz, ovalid, _ = o.run_scan_rowmajor(*frames[v])
+        assert int(ovalid.sum()) > 100_000
+        assert np.array_equal(got[v][1], ovalid), v
+        assert_points_close(got[v][0], oxyz, ovalid == 1)

@@ -41,6 +41,11 @@ def test_bench_spawns_ranks_and_assembly_equals_single_rank(world, height):
     assert wa["dense_root_gather"]["value"] > 0 and wa["compact_root_gather"]["value"] > 0
     # the headline of an N > 1 line is an assembled figure over exactly --steps steps; the compute-only rate sits beside it
     assert many["value_is"] == wa["headline"] and many["value"] == wa[wa["headline"]]["headline_value"] > 0
+    # ... of a variant that leaves COMPLETE DENSE views on a rank; the host-parallel and compacted variants sit beside it
+    assert wa["headline"].startswith("dense_") and wa["host_parallel"]["value"] > 0
+    assert wa["compact_root_gather_19pct_selection"]["value"] > 0 and abs(wa["compact_root_gather_19pct_selection"]["selected_fraction"] - 0.187) < 0.01
+    assert 0 < wa["compact_root_gather_19pct_selection"]["points_per_step"] < 0.25 * wa["compact_root_gather"]["points_per_step"]
+    assert [r["rank"] for r in many["ranks"]] == list(range(world)) and all(r["comm_size"] == world and r["pci_bus_id"] and r["rccl_version"] for r in many["ranks"])
     assert many["compute_only"]["value"] > 0
     assert wa["whole_views_no_exchange"]["value"] > 0 and many["value_is"] != "whole_views_no_exchange"   # the other sharding: reported, never the headline
     assert many["check"]["dense_sha256"] == one["check"]["dense_sha256"]
@@ -56,3 +61,13 @@ def test_bench_refuses_wrong_world_and_stacked_rccl():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--steps", "1"],
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "one GPU per rank" in (p.stderr + p.stdout)
+
+
+def test_bench_strong_scaling_is_configs3_as_stated():
+    """--scaling strong: BASELINE configs[3] itself -- a FIXED batch of views, each row-sharded over the N ranks; the assembled digests
+    equal a 1-rank run over the same batch."""
+    one = _bench("--gpus", "1", "--scaling", "strong", "--total-views", "6", "--height", "1000", *COMMON)
+    many = _bench("--gpus", "3", "--backend", "gloo", "--devices", "0,0,0", "--scaling", "strong", "--total-views", "6", "--height", "1000", "--chunks", "2", *COMMON)
+    assert one["scaling"] == many["scaling"] == "strong" and one["config"]["views_per_step"] == many["config"]["views_per_step"] == 6
+    assert many["config"]["rows_per_gpu"] == 334 and one["config"]["rows_per_gpu"] == 1000
+    assert many["check"]["dense_sha256"] == one["check"]["dense_sha256"] and many["check"]["compact_sha256"] == one["check"]["compact_sha256"]

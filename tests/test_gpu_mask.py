@@ -1,13 +1,129 @@
-"""GPU tests (-m gpu) added in round 5: the bit-plane k_mask_prepare (H0 / S3b / S3d) through every way a mask reaches it --
-one view, several views in one launch, pageable / pinned / device-resident sources, windows on every frame border -- against the
-oracle's literal scan of 3/wrapped_phase.cpp:253-279; the selected-quad count that picks a small launch's kernel; an axis without
-Gray planes on the last resident view."""
+"""GPU tests (-m gpu): H0 / S3b / S3d on the device -- k_mask_prepare's bit-plane arithmetic through every way a mask reaches it (one view, several
+views per launch, pageable / pinned / device-resident sources, windows on every frame border) against the oracle's literal scan of
+3/wrapped_phase.cpp:253-279, and the selected-quad count that picks a small launch's kernel.  (The same through the fused kernel itself:
+test_gpu_mask_fused.py.)"""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import assert_points_close, pkg
+from conftest import ROOT, assert_points_close, pkg
+from oracle.oracle import Oracle
 
 pytestmark = pytest.mark.gpu
+
+
+def _S():
+    return pkg("scanner")
+
+
+def _random_mask(rng, W, H, holes=6):
+    m = np.zeros((H, W), np.uint8)
+    m[1:H - 1, 1:W - 1] = 1
+    for _ in range(holes):
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
+        w, h = int(rng.integers(1, max(2, W // 3))), int(rng.integers(1, max(2, H // 3)))
+        m[y:y + h, x:x + w] = rng.integers(0, 2)
+    m[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 0
+    m[rng.integers(0, H, 10), rng.integers(0, W, 10)] = 7   # selected iff == 1
+    return m
+
+
+# ---- mask preparation on the device -------------------------------------------------------------------------------------
+def test_device_mask_preparation_windows_and_borders():
+    """sl3d_set_mask prepares the mask on the device (normalisation + border band by k_mask_prepare): valid maps of
+    windows that touch every frame border, with arbitrary mask bytes, equal the oracle's boundary removal; pinned and
+    pageable sources give the same."""
+    S, syn = _S(), pkg("synth")
+    FW, FH, PW, PH, N, fw = 150, 90, 256, 192, 6, 8
+    rng = np.random.default_rng(11)
+    cap = syn.make_capture(FW, FH, PW, PH, N, N, fw, fw, noise=1)
+    cal = syn.cal_tuple(cap["cal"])
+    for trial in range(4):
+        mask = _random_mask(rng, FW, FH, holes=10)
+        if trial == 0:
+            mask[:] = 1   # border pixels selected too
+        o = Oracle(FW, FH, PW, PH, N, N, fw, fw)
+        o.set_mask(mask)
+        o.set_calibration(*cal)
+        o.run_scan(cap["planes_v"], cap["planes_h"])
+        vo = o.valid_map(2)
+        for (x0, y0, w, h) in [(0, 0, FW, FH), (0, 0, 70, 40), (83, 51, 67, 39), (5, 0, 100, 90), (0, 7, 150, 50), (31, 29, 17, 5)]:
+            with S.Scanner(w, h, PW, PH, N, N, fw, fw, full_size=(FW, FH), origin=(x0, y0), keep_stages=True) as sc:
+                sc.set_calibration(*cal)
+                pm = sc.pinned(mask.shape, np.uint8)
+                pm[:] = mask
+                for src in (mask, pm):
+                    sc.set_mask(src)
+                    sc.set_frames(0, [p[y0:y0 + h, x0:x0 + w] for p in cap["planes_v"]])
+                    sc.set_frames(1, [p[y0:y0 + h, x0:x0 + w] for p in cap["planes_h"]])
+                    sc.run()
+                    assert np.array_equal(sc.valid_map(0), o.valid_map(0)[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
+                    assert np.array_equal(sc.valid_map(2), vo[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
+                    sc.run_stages()
+                    assert np.array_equal(sc.valid_map(2), vo[y0:y0 + h, x0:x0 + w]), (trial, x0, y0)
+
+
+# ---- sparse selections: a small launch asks the mask first ------------------------------------------------------------------------
+def test_small_launch_over_sparse_masks_takes_the_gated_kernel():
+    """k_mask_prepare counts the quads of a view that hold a valid pixel; a launch of at most 4 views whose views are ALL known to be
+    sparsely selected (< 65 % of the quads; the reference's real captures select 19 % of the frame) takes the large-launch
+    instantiation, which requests a view's planes only for quads its valid bits leave standing, instead of the small-launch one,
+    which requests them first (one 1080p view at 19 %: 15.8 us against 22.2, profiles/r04_sparse_mask.txt).  Which kernel runs must
+    not change a bit of the result: one view alone and in launches of 2 and 4, sparse and dense views mixed, dense results and
+    ordered clouds, against the oracle."""
+    from oracle.oracle import Oracle
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, PW, PH, N, fw = 960, 540, 1024, 768, 9, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
+    dense = syn.default_mask(W, H)
+    sparse = np.zeros((H, W), np.uint8)
+    sparse[150:390, 300:700] = 1                       # 18.5 % of the frame
+    rng = np.random.default_rng(3)
+    sparse[rng.random((H, W)) < 0.02] = 0
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=5) as sc:
+        sc.set_calibration(*cal)
+        for v in range(5):
+            sc.set_mask(sparse if v < 4 else dense, view=v)     # (pageable source: the call returns after the count has landed)
+            sc.synth_view(v, plane=(1.5 * v, 0.05, 0.04), view_id=v, noise=2)
+        for n in (1, 2, 4):
+            assert sc.fused_kernel_name(n).endswith(", 1, 0, true, false>"), sc.fused_kernel_name(n)          # views 0..n-1: all sparse
+            assert sc.fused_kernel_name(n, clouds=True).endswith(", 1, 2, true, false>")
+        sc.run(0, 4)
+        batch = [sc.points(v) for v in range(4)]
+        clouds = sc.fused_clouds(0, 4)
+        sc.run(3, 2)                                            # views 3 (sparse) + 4 (dense): the small-launch kernel
+        mixed = [sc.points(3), sc.points(4)]
+        assert np.array_equal(mixed[0][1], batch[3][1]) and np.array_equal(mixed[0][0], batch[3][0], equal_nan=True)
+        for v in range(4):
+            sc.run(v, 1)
+            one = sc.points(v)
+            assert np.array_equal(one[1], batch[v][1]) and np.array_equal(one[0], batch[v][0], equal_nan=True), v
+            assert np.array_equal(sc.fused_clouds(v, 1)[0], clouds[v]), v
+        frames = [(sc.frames(0, v), sc.frames(1, v)) for v in (0, 3, 4)]
+        # a new (dense) selection for view 0.  Since round 6 it is DEFERRED (evaluated by the launch that consumes it), so what is
+        # known is still the view's LAST selection: sparse -> k_mask_prepare + the gated kernel once more; that pass counts the new
+        # selection, and from then on a new mask + one view is ONE launch of the MASKIN instantiation
+        sc.set_mask(dense, view=0)
+        assert sc.fused_kernel_name(1).endswith(", 1, 0, true, false>"), sc.fused_kernel_name(1)
+        sc.run(0, 1)
+        sc.synchronize()
+        assert sc.fused_kernel_name(1).endswith(", 1, 0, false, true>"), sc.fused_kernel_name(1)               # view 0 is dense now
+        sc.set_mask(dense, view=0)
+        assert sc.fused_kernel_name(1).endswith(", 1, 4, false, true>"), sc.fused_kernel_name(1)               # ... and its next mask rides along
+        assert sc.fused_kernel_name(5).endswith(", 1, 0, true, true>")                                         # a large launch, not all sparse: early requests
+    for (v, m, got), fr in zip(((0, sparse, batch[0]), (3, sparse, batch[3]), (4, dense, mixed[1])), frames):
+        o = Oracle(W, H, PW, PH, N, N, fw, fw)
+        o.set_mask(m)
+        o.set_calibration(*cal)
+        oxyz, ovalid, _ = o.run_scan_rowmajor(*fr)
+        assert int(ovalid.sum()) > 50_000
+        assert np.array_equal(got[1], ovalid), v
+        assert_points_close(got[0], oxyz, ovalid == 1)
 
 
 def _mask(rng, W, H, trial):
@@ -156,109 +272,3 @@ def test_selected_quad_count_follows_masks_and_copies():
         assert np.array_equal(got[1], ref0[1]) and np.array_equal(got[0], ref0[0], equal_nan=True)
         sc.run_clouds(0, 1)
         assert ", 1, 2, " in sc.last_fused_kernel_name()
-
-
-@pytest.mark.parametrize("Nv,Nh", [(7, 0), (0, 9), (0, 0)])
-def test_axis_without_gray_planes_on_the_last_resident_view(Nv, Nh):
-    """n_gray = 0 is a valid configuration (include/sl3d.h: 0..16): the code is 0 and the absolute phase is the shifted wrapped
-    phase.  The padded straight-line kernels must not read past the frame stack for the empty axis of the LAST view of the context
-    (ADVICE r4): every view of a full context, large and small launches, against the oracle."""
-    from oracle.oracle import Oracle
-    S, syn = pkg("scanner"), pkg("synth")
-    W, H, V = 168, 60, 6
-    PW, PH, fwv, fwh = 64, 48, 64, 48
-    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
-    rng = np.random.default_rng(10 * Nv + Nh)
-    planes = [([rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(3 + 2 * Nv)],
-               [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(3 + 2 * Nh)]) for _ in range(V)]
-    masks = np.stack([(rng.random((H, W)) < 0.9).astype(np.uint8) for _ in range(V)])
-    with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, max_views=V) as sc:
-        sc.set_calibration(*cal)
-        sc.set_masks(masks)
-        for v in range(V):
-            sc.set_frames(0, planes[v][0], view=v)
-            sc.set_frames(1, planes[v][1], view=v)
-        sc.run(0, V)
-        batch = [sc.points(v) for v in range(V)]
-        sc.run(V - 1, 1)
-        last = sc.points(V - 1)
-        clouds = sc.fused_clouds(0, V)
-    assert np.array_equal(last[1], batch[V - 1][1]) and np.array_equal(last[0], batch[V - 1][0], equal_nan=True)
-    nvalid = 0
-    for v in range(V):
-        o = Oracle(W, H, PW, PH, Nv, Nh, fwv, fwh)
-        o.set_mask(masks[v])
-        o.set_calibration(*cal)
-        oxyz, ovalid, _ = o.run_scan_rowmajor(*planes[v])
-        assert np.array_equal(batch[v][1], ovalid), v
-        assert_points_close(batch[v][0], oxyz, ovalid == 1)
-        assert np.array_equal(clouds[v], batch[v][0][ovalid == 1]), v
-        nvalid += int(ovalid.sum())
-    assert nvalid > 100
-
-
-# ---- small launches leave the scan of the segment counts to the consumer ---------------------------------------------------------------
-@pytest.mark.parametrize("W,H", [(640, 203), (1021, 64), (96, 5)])
-def test_consumers_scan_on_entry_after_small_cloud_launches(W, H):
-    """sl3d_run_clouds over at most 4 views launches no k_seg_scan; whoever consumes the clouds gets offsets and totals on entry:
-    the one-view download into pinned memory (k_seg_close<.., SCAN>: scan + gap closing + count in one launch, also with a
-    destination smaller than the cloud), the contiguous device copy (sl3d_get_cloud_counts), the raw segments (the scan runs then),
-    the registration, and a large launch afterwards -- every cloud equals xyz[valid] of the dense launch, in scan order."""
-    S, syn = pkg("scanner"), pkg("synth")
-    PW, PH, N, fw, V = 512, 384, 8, 4, 6
-    rng = np.random.default_rng(W + H)
-    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
-    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=V) as sc:
-        sc.set_calibration(*cal)
-        masks = np.stack([_mask(rng, W, H, t) for t in range(V)])
-        masks[0] = syn.default_mask(W, H)
-        sc.set_masks(masks)
-        for v in range(V):
-            sc.synth_view(v, plane=(1.5 * v, 0.05, 0.04 - 0.01 * v), view_id=v, noise=2)
-        sc.run(0, V)
-        dense = [sc.points(v) for v in range(V)]
-        want = [xyz[val == 1] for xyz, val in dense]
-        pin = sc.pinned((W * H * 3,), np.float32)
-        for v in range(V):
-            sc.run_clouds(v, 1)
-            pin[:] = -7.0
-            n = sc.download_cloud_into(v, pin)                  # pinned, roomy: the scanning gap-closer
-            assert n == len(want[v]), v
-            assert np.array_equal(pin[:3 * n].reshape(n, 3), want[v]), v
-            assert (pin[3 * n:3 * n + 3] == -7.0).all()         # nothing past the cloud
-            if n > 10:                                          # a destination smaller than the cloud: its first points, the full count
-                sc.run_clouds(v, 1)
-                small = sc.pinned((3 * (n // 2),), np.float32)
-                small[:] = -7.0
-                assert sc.download_cloud_into(v, small) == n
-                assert np.array_equal(small.reshape(-1, 3), want[v][:n // 2]), v
-            sc.run_clouds(v, 1)
-            page = np.full(W * H * 3, -7.0, np.float32)         # pageable: counts first (the scan runs), then the copy
-            assert sc.download_cloud_into(v, page) == n and np.array_equal(page[:3 * n].reshape(n, 3), want[v])
-        # the contiguous device copy of a small launch (scan on entry of the gap-closer), then the raw segments of the same launch
-        sc.run_clouds(1, 3)
-        ptr, stride, counts = sc.cloud_counts(1, 3)
-        assert counts == [len(want[v]) for v in (1, 2, 3)]
-        for k, v in enumerate((1, 2, 3)):
-            a = np.empty((counts[k], 3), np.float32)
-            if counts[k]:
-                sc._d2h(a, ptr + 12 * k * stride)
-            assert np.array_equal(a, want[v]), v
-        seg, counts2 = sc.cloud_segments(1, 3)
-        assert counts2 == counts
-        offs = np.empty(seg.n_segments, np.uint64)
-        cnts = np.empty(seg.n_segments, np.uint32)
-        for k in range(3):
-            sc._d2h(offs, seg.offsets + 8 * k * seg.view_stride_segments)
-            sc._d2h(cnts, seg.counts + 4 * k * seg.view_stride_segments)
-            assert int(cnts.sum()) == counts[k] and np.array_equal(offs, np.concatenate([[0], np.cumsum(cnts.astype(np.uint64))[:-1]]).astype(np.uint64))
-        # registration straight from a small launch, against the dense route
-        sc.run_clouds(2, 2)
-        reg = sc.register_clouds(2, 2, 10.0, 0.0, 300.0, 7.5)
-        sc.run(2, 2)
-        ref = sc.register_views(2, 2, 10.0, 0.0, 300.0, 7.5)
-        assert np.array_equal(reg, ref)
-        # and a large launch afterwards scans by itself
-        got = sc.fused_clouds(0, V)
-        for v in range(V):
-            assert np.array_equal(got[v], want[v]), v

@@ -1,7 +1,7 @@
 """k_mask_prepare's arithmetic on the CPU: the bit-plane closed form of stage 3's boundary removal (3dscan_amd/csrc/sl3d_maskbits.h,
 the header the HIP kernel is compiled from) driven by the kernel's own lane / strip indexing (tests/native/mask_bits_emul.c),
 against the oracle's literal scan of 3/wrapped_phase.cpp:253-279 -- full frames, windows touching every border, 1- and 2-pixel
-frames' worth of edge cases, arbitrary mask bytes.  The GPU run of the same comparison is tests/test_gpu_round5.py."""
+frames' worth of edge cases, arbitrary mask bytes.  The GPU run of the same comparison is tests/test_gpu_mask.py."""
 import ctypes as C
 import os
 import subprocess

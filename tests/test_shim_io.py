@@ -28,7 +28,8 @@ def test_every_extern_c_entry_point_is_behind_the_exception_barrier():
     import re
     csrc = os.path.join(ROOT, "3dscan_amd", "csrc")
     guarded = 0
-    for name, catch in (("sl3d_capi.cpp", r"SL3D_CATCH"), ("sl3d_group.cpp", r"SL3D_GROUP_CATCH|SL3D_CATCH"), ("sl3d_shim.cpp", r"SHIM_CATCH|catch \(\.\.\.\)")):
+    for name, catch in (("sl3d_capi_context.cpp", r"SL3D_CATCH"), ("sl3d_capi_inputs.cpp", r"SL3D_CATCH"), ("sl3d_capi_run.cpp", r"SL3D_CATCH"),
+                        ("sl3d_capi_clouds.cpp", r"SL3D_CATCH"), ("sl3d_capi_next.cpp", r"SL3D_CATCH"), ("sl3d_group.cpp", r"SL3D_GROUP_CATCH|SL3D_CATCH"), ("sl3d_shim.cpp", r"SHIM_CATCH|catch \(\.\.\.\)")):
         lines = open(os.path.join(csrc, name)).read().split("\n")
         i = 0
         while i < len(lines):

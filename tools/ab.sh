@@ -17,7 +17,7 @@ if [ "$1" = build ]; then
     n=$1; f=$2; shift 2
     # every translation unit of the library, compiled in parallel into its own object directory, with this variant's flags
     mkdir -p /tmp/ab_obj_$n; : > ab/$n.res; pids=""
-    for src in 3dscan_amd/csrc/sl3d_fused_*.hip 3dscan_amd/csrc/sl3d_kernels.hip 3dscan_amd/csrc/sl3d_capi.cpp 3dscan_amd/csrc/sl3d_group.cpp; do
+    for src in 3dscan_amd/csrc/sl3d_fused_*.hip 3dscan_amd/csrc/sl3d_kernels.hip 3dscan_amd/csrc/sl3d_capi_*.cpp 3dscan_amd/csrc/sl3d_group.cpp; do
       ( hipcc $FLAGS $f -Iinclude -Rpass-analysis=kernel-resource-usage -c -x hip $src -o /tmp/ab_obj_$n/$(basename $src).o 2> /tmp/ab_obj_$n/$(basename $src).res ) & pids="$pids $!"
     done
     ok=1; for p in $pids; do wait $p || ok=0; done
