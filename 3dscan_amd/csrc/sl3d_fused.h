@@ -392,6 +392,12 @@ __device__ __forceinline__ void maskin_emit(const KParams &P, uint8_t *mask_view
 __device__ __forceinline__ unsigned maskin_finish(const KParams &P, const Item &it, int view, int slot, mrow_t w0, mrow_t w1, mrow_t w2, mrow_t w3, mrow_t w4, bool fast)
 {
     if (fast) {
+        // ... and most plain waves need no arithmetic at all: a wave whose 3 x 8 bytes are ALL 1 lies inside the selection (every pixel
+        // valid), one whose bytes are all 0 outside it (none is) -- 14 instructions instead of ~70; only the waves the selection's
+        // outline crosses evaluate the closed form
+        const unsigned all_and = w1.x & w1.y & w2.x & w2.y & w3.x & w3.y, all_or = w1.x | w1.y | w2.x | w2.y | w3.x | w3.y;
+        if (__ballot(all_and != 0x01010101u || all_or != 0x01010101u) == 0ull) return 0xffu;
+        if (__ballot(all_or != 0u) == 0ull) return 0u;
         const unsigned v = mb_quad_valid_plain(mb_quad_word(w1.x, w1.y, -2), mb_quad_word(w2.x, w2.y, -2), mb_quad_word(w3.x, w3.y, -2));
         return v | (mb_pack_nibble(mb_eq1_bytes(mb_quad_own(w2.x, w2.y, -2))) << 4);
     }

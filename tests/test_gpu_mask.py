@@ -239,7 +239,9 @@ def test_device_resident_masks_direct_and_staged():
 
 def test_selected_quad_count_follows_masks_and_copies():
     """The count of selected quads (per-block words in mapped host memory, no atomics, no copy) decides a small launch's kernel: it
-    follows sl3d_set_masks, survives sl3d_copy_view, and sl3d_last_fused_kernel_name reports the instantiation that ran."""
+    follows sl3d_set_masks, survives sl3d_copy_view, and sl3d_last_fused_kernel_name reports the instantiation that ran.  (An
+    SL3D_FLAG_EAGER_MASK context: every mask is prepared -- and counted -- by k_mask_prepare when it is set; what the counts of the
+    deferred route decide is test_gpu_mask_fused.py::test_fused_mask_route_counts_selected_quads.)"""
     S, syn = pkg("scanner"), pkg("synth")
     W, H, PW, PH, N, fw = 960, 540, 1024, 768, 9, 2
     cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
@@ -247,7 +249,7 @@ def test_selected_quad_count_follows_masks_and_copies():
     sparse = np.zeros((H, W), np.uint8)
     sparse[150:390, 300:700] = 1
     gated, small = ", 1, 0, true, false>", ", 1, 0, false, true>"
-    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=4) as sc:
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=4, eager_mask=True) as sc:
         sc.set_calibration(*cal)
         sc.set_masks(np.stack([sparse, dense, sparse, dense]))
         for v in range(4):
