@@ -3,8 +3,7 @@
 # A recipe is a file tools/recipes/<recipe>.sh, sourced on the GPU box from the root of the repository copy with
 #   OUT = gpurun_out/<recipe>  (created), TMPDIR = /tmp, and the helpers below.
 # Standing recipes: full (suite + smoke + bench), profile <tag> (the rocprofv3 passes behind profiles/<tag>_*), r8, soak,
-# tests <pytest -k expression>, mask (k_mask_prepare: tests + kernel stats), perscan, idle ...; r4a .. r4ac are round 4's sessions
-# kept for provenance of the profiles/r04_* files.
+# tests <pytest -k expression>, mask (k_mask_prepare: tests + kernel stats), perscan (new mask + one view, both routes), idle, final <tag> ...
 set -u
 R=${1:?usage: tools/session.sh <recipe> [args]}
 shift
