@@ -185,6 +185,7 @@ try {
     x->quad_seq.assign(V, 0u);
     x->quad_sum_seq.assign(V, 0u);
     x->quad_sum.assign(V, 0u);
+    x->quad_last.assign(V, ~0u);
     x->quad_src.resize(V);
     for (size_t v = 0; v < V; v++) x->quad_src[v] = (int)v;
     x->quad_kind.assign(V, 0);

@@ -32,20 +32,24 @@ bool quads_known(const sl3d_ctx *x, int view, unsigned *quads)
     }
     x->quad_sum_seq[view] = seq;
     x->quad_sum[view] = sum;
+    x->quad_last[view] = sum;
     *quads = sum;
     return true;
 }
 
-// true if every view of [first, first + n) is KNOWN to be sparsely selected (fewer than 65 % of its quads hold a valid pixel): a
+// true if every view of [first, first + n) is known to be sparsely selected (fewer than 65 % of its quads hold a valid pixel): a
 // launch over such views takes the instantiation whose every plane request waits for the valid bits (choose_fused: the large-launch
-// kernel without early requests, also for a small launch).  Unknown (the count has not landed, or no mask was ever set) counts as
-// dense: that is the default this library was tuned on.
+// kernel without early requests, also for a small launch).  A view whose count is still on its way -- the reference's loop sets a new
+// selection and launches at once, scan after scan -- is routed by the last count that did arrive (the lasso of one scan is about as
+// large as that of the scan before; the route decides time only, never results); a view that never had a complete count is dense:
+// the default this library was tuned on.
 bool sparse_views(const sl3d_ctx *x, int first, int n)
 {
     const double quads = (double)(x->P.pitch >> 2) * (double)x->P.H;
     for (int v = first; v < first + n; v++) {
         unsigned c;
-        if (!quads_known(x, v, &c) || (double)c >= 0.65 * quads) return false;
+        if (!quads_known(x, v, &c)) c = x->quad_last[(size_t)v];
+        if (c == ~0u || (double)c >= 0.65 * quads) return false;
     }
     return true;
 }
@@ -109,6 +113,8 @@ static int prepare_masks(sl3d_ctx *x, int first_view, int n_views, const MaskSrc
 {
     const unsigned seq = ++x->mask_seq;
     for (int v = first_view; v < first_view + n_views; v++) {
+        unsigned c;
+        (void)quads_known(x, v, &c);  // (the count of the selection this one replaces, if it has arrived: quad_last, what sparse_views falls back on)
         x->quad_seq[v] = seq;
         x->quad_src[v] = v;
         x->quad_kind[v] = 0;
@@ -427,6 +433,7 @@ try {
     x->quad_seq[dst] = x->quad_seq[src];  // the duplicate's count of selected quads is the source's (until either mask is set again)
     x->quad_src[dst] = x->quad_src[src];
     x->quad_kind[dst] = x->quad_kind[src];
+    x->quad_last[dst] = x->quad_last[src];
     x->quad_sum_seq[dst] = 0u;  // (a sum cached for dst under the same sequence number -- one sl3d_set_masks call serves many views -- is not the source's)
     return SL3D_OK;
 }

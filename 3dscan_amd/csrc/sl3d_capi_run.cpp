@@ -57,12 +57,12 @@ SL3D_CATCH(x)
 // every fused launch of the library goes through here: the kernel is chosen by what is known about the views' masks NOW, and the
 // choice is recorded (sl3d_last_fused_kernel_name reports the instantiation that ran, not a later prediction)
 // can the launch over views [first_view, first_view + n_views) evaluate their (deferred) selections itself?  Every view's mask is
-// deferred, in one layout, the launch has a MASKIN instantiation, and the views are not known -- by their LAST counts -- to be
-// sparsely selected (a MASKIN launch requests and computes every pixel of the window before it knows the selection; sparse views keep
-// the two-kernel route whose plane requests wait for the valid bits)
+// deferred, in one layout, and the launch has a MASKIN instantiation.  (Views known -- by their LAST counts -- to be sparsely selected take
+// the gated MASKIN form, whose plane requests wait for the valid bits the launch has just evaluated: launch_fused.)
 bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep, bool prefer_gated)
 {
-    if (x->n_pending == 0 || prefer_gated || !fused_maskin_available(x->P, x->rig, n_views, keep)) return false;
+    (void)prefer_gated;  // (sparsely selected views have a MASKIN form too: the gated kernel, whose plane requests wait for the valid bits)
+    if (x->n_pending == 0 || !fused_maskin_available(x->P, x->rig, n_views, keep)) return false;
     const sl3d_ctx::PendingMask &p0 = x->pend[(size_t)first_view];
     for (int v = first_view; v < first_view + n_views; v++) {
         const sl3d_ctx::PendingMask &pm = x->pend[(size_t)v];
@@ -106,7 +106,7 @@ int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode)
     mi.part = x->d_mi_part;
     mi.part_stride = x->mi_part_stride;
     mi.seq = seq & 0xffffffu;
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, false, &mi));
+    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, prefer_gated, &mi));
 }
 
 extern "C" int sl3d_last_fused_kernel_name(sl3d_ctx *x, char *buf, size_t capacity)

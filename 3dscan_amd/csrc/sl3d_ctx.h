@@ -36,6 +36,8 @@ struct sl3d_ctx {
     std::vector<unsigned> quad_seq;           // [max_views] sequence number of the view's last preparation (0 = never set)
     std::vector<int> quad_src;                // [max_views] the view whose blocks hold this view's count (sl3d_copy_view duplicates masks)
     mutable std::vector<unsigned> quad_sum_seq, quad_sum;  // [max_views] the sum once it was complete, and the preparation it belongs to
+    mutable std::vector<unsigned> quad_last;               // [max_views] the last sum that WAS complete, of whichever preparation (~0u: none yet):
+                                                           // what routes a launch while the current count is still on its way (sparse_views)
     unsigned mask_seq = 0;
     // Deferred masks (sl3d_set_mask(s) of at most SL3D_SMALL_LAUNCH_VIEWS views on a timed context, unless SL3D_FLAG_EAGER_MASK): the
     // view's selection has been handed over but not prepared -- the next small launch over such views evaluates it inside the fused

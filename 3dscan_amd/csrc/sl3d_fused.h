@@ -284,8 +284,11 @@ __device__ __forceinline__ MaskInArgs maskin_read_args(int slot)
 {
     const MaskInP M = maskin_args();
     MaskInArgs A;
-    A.src = (const GLOBAL_AS uint8_t *)M->origin[slot];
-    A.stride = (unsigned)M->stride;
+    // (wave-uniform by construction; said explicitly -- the request sits under `if (alive)`, and the code generator otherwise meets a
+    // uniform value in a vector register where the scalar-base load form wants it: "illegal VGPR to SGPR copy")
+    const unsigned long long o = (unsigned long long)M->origin[first_lane_u32((unsigned)slot)];
+    A.src = (const GLOBAL_AS uint8_t *)(((unsigned long long)first_lane_u32((unsigned)(o >> 32)) << 32) | (unsigned long long)first_lane_u32((unsigned)o));
+    A.stride = first_lane_u32((unsigned)M->stride);
     A.bx0 = M->bx0; A.bx1 = M->bx1; A.r0 = M->r0; A.r1 = M->r1; A.lo = M->lo; A.hi = M->hi;
     return A;
 }
@@ -557,6 +560,9 @@ __device__ __forceinline__ void issue_fringe(const KParams &P, int view, unsigne
 //      capture set is N_v = 6, N_h = 5 (global_cv.h:49-62); until round 4 unequal axes took the per-plane tests below, whose code
 //      spills kilobytes: 3.8 x slower at 6 / 5, 40 x at 10 / 9 (tools/nvnh.py, profiles/r04_unequal_axes.txt).  With equal axes it is
 //      1 % behind the exact form (the plane offsets are no longer compile-time multiples), which therefore stays.
+//   3  padded, with the pad count taken through v_readfirstlane: the gated MASKIN kernels of rig classes 2 and 3 -- there the code
+//      generator holds the (uniform) plane count in a vector register at the empty asm below and stops with "illegal VGPR to SGPR
+//      copy"; the other padded kernels keep form 2 (their instruction streams are round 5's)
 //   0  per-plane tests (parity mode, more than 12 planes): an axis with fewer planes skips the surplus loads through a wave-uniform
 //      test
 template <int NMAX, int PLANES>
@@ -576,10 +582,11 @@ __device__ __forceinline__ void issue_gray(const KParams &P, int view, unsigned 
         // (behind an empty asm: everything derived from it is loop-invariant, and 40 hoisted plane offsets + 20 masks are more
         // SGPRs than there are)
         int pad = NMAX - N;
-        if (PLANES == 2) asm volatile("" : "+s"(pad));
+        if (PLANES == 3) pad = __builtin_amdgcn_readfirstlane(pad);
+        if (PLANES >= 2) asm volatile("" : "+s"(pad));
 #pragma unroll
         for (int i = 0; i < NMAX; i++) {
-            if (PLANES == 2) {
+            if (PLANES >= 2) {
                 const unsigned idx = (unsigned)max(i - pad, 0);
                 g[a][i] = ldg32(vb + (size_t)(pg + idx * psv), lo);
                 iv[a][i] = ldg32(vb + (size_t)(pg + ((unsigned)N + idx) * psv), lo);
@@ -611,8 +618,9 @@ __device__ __forceinline__ void decode_gray(const unsigned (&g)[2][NMAX], const 
         const unsigned H = 0x80808080u;
         unsigned bacc = 0;  // running binary bit of pixel k at bit 8k+7
         unsigned hi = 0, lo = 0;
-        if (PLANES == 2) {
+        if (PLANES >= 2) {
             int pad = NMAX - N;
+            if (PLANES == 3) pad = __builtin_amdgcn_readfirstlane(pad);
             asm volatile("" : "+s"(pad));
 #pragma unroll
             for (int i = 0; i < NMAX; i++) {
@@ -988,7 +996,8 @@ struct RadialLds<3> {
 // FGEN  false: 3-step fringes (the reference's configuration) with the F test folded at compile time
 // RIG   stage 7, see above
 // CMODE 0: dense xyz + valid planes; 2: segmented ordered clouds + the valid plane (sl3d_run_clouds); + 4 (MASKIN, the pipelined
-//       small-launch instantiations only): the launch evaluates the views' raw selection itself -- see maskin_request
+//       small-launch instantiations, and the gated large-launch ones for views known to be sparsely selected): the launch evaluates
+//       the views' raw selection itself -- see maskin_request
 // RCPT  true: 1/d of the atan2 quotient from an LDS table (6 KB per block, 768 IEEE divisions + a block barrier to fill it);
 //       false: the instantiation for SMALL launches (a handful of views: the reference's one scan per call) -- v_rcp_f64 + one
 //       Newton step instead of the table, whose fill nothing amortises when a block lives for one or two views, and the first
@@ -1007,7 +1016,8 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
     constexpr bool MASKIN = (CMODE & 4) != 0;
     constexpr int BLK = RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK;
     static_assert((CMODE & ~6) == 0, "0 = dense planes, 2 = segmented clouds (1 was round 2's look-back compaction), + 4 = MASKIN");
-    static_assert(!MASKIN || (!RCPT && EARLY_ && !KEEP && RIG != 0), "MASKIN: the pipelined small-launch instantiations");
+    static_assert(!MASKIN || (!KEEP && RIG != 0 && (RCPT ? !EARLY_ : EARLY_)),
+                  "MASKIN: the pipelined small-launch instantiations, and the gated large-launch ones (views known to be sparsely selected)");
     static_assert(!(KEEP && CMODE != 0), "the parity mode writes dense planes");
     static_assert(!(KEEP && RIG != 0), "the parity mode evaluates everything with the reference's operation order");
     __shared__ __attribute__((aligned(16))) float s_xyz[BLK * 12];  // staging area: correspondences, then xyz, of the lane's 4 pixels
@@ -1053,7 +1063,7 @@ __global__ __launch_bounds__(RCPT ? SL3D_BLOCK : SL3D_SMALL_BLOCK, SL3D_OCC) voi
 
     // EXACT: both axes have exactly NMAX Gray planes (the usual case)
     // how the axes map onto the NMAX unrolled planes (issue_gray): exact; padded (the timed 3-step kernels up to 12 planes); tests
-    constexpr int PLANES = EXACT ? 1 : (!KEEP && NMAX <= 12) ? 2 : 0;
+    constexpr int PLANES = EXACT ? 1 : (!KEEP && NMAX <= 12) ? ((MASKIN && RCPT) ? 3 : 2) : 0;
     const int Nv = EXACT ? NMAX : P.Nv, Nh = EXACT ? NMAX : P.Nh;
     const bool proj_table = RIG == 2 || (RIG == 0 && !KEEP && P.proj_disp != nullptr);
 
@@ -1295,14 +1305,16 @@ static void launch_fused_n(int nv, int nh, dim3 grid, hipStream_t st, const KPar
 }
 
 // MASKIN launches (CMODE | 4): the pipelined small-launch instantiation of every N, exact and padded, nothing else
-template <int RIG, int CMODE>
+// GATED: the views are known (by their last counts) to be sparsely selected -- the large-launch form whose plane requests wait for the
+// valid bits (k_fused<..., true, false>); the selection is then evaluated under the block's reciprocal-table fill, in front of those requests
+template <int RIG, int CMODE, bool GATED>
 static void launch_fused_maskin_n(int nv, int nh, dim3 grid, hipStream_t st, const KParams &P, const DevCal *C, int first_view, int n_views, int vpt)
 {
     static_assert(RIG != 0 && (CMODE == 4 || CMODE == 6), "MASKIN: rig classes 1..3, dense or segmented clouds");
-    const FusedChoice c = choose_fused(false, false, CMODE & 2, nv, nh, n_views, false, RIG);
+    const FusedChoice c = choose_fused(false, false, CMODE & 2, nv, nh, n_views, GATED, RIG);
     const long quads_ = (long)(P.pitch >> 2) * P.H;
     const dim3 small_grid((((unsigned)((quads_ + SL3D_SMALL_BLOCK - 1) / SL3D_SMALL_BLOCK)) + 7u) & ~7u, grid.y, 1);
-#define SL3D_LAUNCH_MI(NM, EX) hipLaunchKernelGGL((k_fused<false, NM, false, EX, RIG, CMODE, false, true>), small_grid, dim3(SL3D_SMALL_BLOCK), 0, st, P, C, first_view, n_views, vpt)
+#define SL3D_LAUNCH_MI(NM, EX) hipLaunchKernelGGL((k_fused<false, NM, false, EX, RIG, CMODE, GATED, !GATED>), GATED ? grid : small_grid, dim3(GATED ? SL3D_BLOCK : SL3D_SMALL_BLOCK), 0, st, P, C, first_view, n_views, vpt)
     if (c.exact) {
         switch (c.nmax) {
         case 6: SL3D_LAUNCH_MI(6, true); break;
@@ -1338,9 +1350,9 @@ void fused_clouds_rig0(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig1(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig2(SL3D_FUSED_FAMILY_ARGS);
 void fused_clouds_rig3(SL3D_FUSED_FAMILY_ARGS);
-void fused_maskin_rig1(int cmode, SL3D_FUSED_FAMILY_ARGS);  // MASKIN launches (cmode 4 / 6), one translation unit per rig class
-void fused_maskin_rig2(int cmode, SL3D_FUSED_FAMILY_ARGS);
-void fused_maskin_rig3(int cmode, SL3D_FUSED_FAMILY_ARGS);
+void fused_maskin_rig1(int cmode, bool gated, SL3D_FUSED_FAMILY_ARGS);  // MASKIN launches (cmode 4 / 6), one translation unit per rig class
+void fused_maskin_rig2(int cmode, bool gated, SL3D_FUSED_FAMILY_ARGS);
+void fused_maskin_rig3(int cmode, bool gated, SL3D_FUSED_FAMILY_ARGS);
 void fused_fgen(int rig, int cmode, SL3D_FUSED_FAMILY_ARGS);  // 4-step (and the all-invalid 5-step) fringes: the F test stays a run-time branch
 void fused_parity(bool fgen, SL3D_FUSED_FAMILY_ARGS);
 

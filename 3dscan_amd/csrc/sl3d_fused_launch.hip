@@ -52,6 +52,8 @@ bool fused_maskin_available(const KParams &P, int rig, int n_views, bool keep)
 {
     // (a MASKIN kernel compiles the one-double camera table only: its mask words live in the registers of the two-double kind)
     if (keep || P.F != 3 || n_views > SL3D_SMALL_LAUNCH_VIEWS || timed_rig(P, rig) == 0 || (P.cam_tab != nullptr && P.cam_tab_kind == 2)) return false;
+    // the small-launch form with early requests, or (views known to be sparsely selected) the gated large-launch form: both exist for
+    // every pattern set the pipelined kernels take
     const FusedChoice c = choose_fused(false, false, 0, P.Nv, P.Nh, n_views, false, timed_rig(P, rig));
     return c.small && c.early;
 }
@@ -71,7 +73,6 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     if (mi) {
         if (!fused_maskin_available(P, rig, n_views, keep)) return (int)hipErrorInvalidValue;
         P.mi = *mi;
-        P.prefer_gated = 0;
     }
     const long quads = (long)(P.pitch >> 2) * P.H;
     const unsigned bx = ((unsigned)((quads + SL3D_BLOCK - 1) / SL3D_BLOCK) + 7u) & ~7u;  // a multiple of 8: consecutive tiles go round the 8 XCDs
@@ -93,7 +94,7 @@ int launch_fused(const KParams &P_, const DevCal *d_cal, int rig, int first_view
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();  // an earlier sticky error of another library is not this launch's
     if (mi) {
-        (r == 1 ? fused_maskin_rig1 : r == 2 ? fused_maskin_rig2 : fused_maskin_rig3)(cmode, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
+        (r == 1 ? fused_maskin_rig1 : r == 2 ? fused_maskin_rig2 : fused_maskin_rig3)(cmode, prefer_gated, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
     } else if (keep) {
         fused_parity(P.F != 3, P.Nv, P.Nh, grid, st, P, d_cal, first_view, n_views, vpt);
     } else if (P.F != 3) {
@@ -112,10 +113,7 @@ int fused_kernel_name(const KParams &P, int rig, int n_views, bool keep, int cmo
 {
     const bool fgen = P.F != 3;
     const int r = keep ? 0 : timed_rig(P, rig);
-    if (maskin) {
-        prefer_gated = false;
-        cmode |= 4;
-    }
+    if (maskin) cmode |= 4;
     const FusedChoice c = choose_fused(keep, fgen, cmode & 2, P.Nv, P.Nh, n_views, prefer_gated, r);
     auto b = [](bool v) { return v ? "true" : "false"; };
     return snprintf(buf, cap, "sl3d::k_fused<%s, %d, %s, %s, %d, %d, %s, %s>", b(keep), c.nmax, b(fgen), b(c.exact), r, keep ? 0 : cmode, b(!c.small), b(c.early));

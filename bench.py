@@ -285,13 +285,16 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
                         f"> 256 MiB Infinity Cache): the frames come from HBM"}
 
 
-def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=False, eager=False):
+def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=False, eager=False, lasso=False):
     """What ONE iteration of the reference's scan loop costs on the device once the frames are resident (m_tech_project_console.cpp:
     366-395): a NEW selection mask (image_scissor's result, here already in device memory: no PCIe in this figure) and ONE one-view
     launch, a different resident view and a different mask every scan (frames from HBM, as in one_view_cold).  HIP events on the
     context's stream around `scans` such scans.  Default route (since round 6): ONE launch -- the fused kernel evaluates the selection
     itself (H0 / S3b / S3d: 3/wrapped_phase.cpp:106-115, :253-279 inside k_fused, a MASKIN launch).  eager: the two-kernel route of
-    SL3D_FLAG_EAGER_MASK (k_mask_prepare, then the fused kernel); mask_us = that loop with the mask preparation alone."""
+    SL3D_FLAG_EAGER_MASK (k_mask_prepare, then the fused kernel); mask_us = that loop with the mask preparation alone.
+    lasso: every selection is a rectangle of the share the reference's real captures select (358,580 of 1,920,000 pixels, BASELINE.md
+    section 1), at a slightly different place each scan -- the launch then takes the gated kernels, whose plane requests wait for the
+    valid bits (the views' previous selections were as sparse: sparse_views)."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
     V = max(2, args.cold_views)
     rng = np.random.default_rng(5)
@@ -300,6 +303,13 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
         ys, xs = rng.integers(8, H - 8, 12), rng.integers(8, W - 8, 12)
         for y, x in zip(ys, xs):
             masks[v, y:y + 3, x:x + 5] = 0
+    if lasso:
+        share = 358580.0 / 1920000.0
+        mh, mw = int(round(H * share ** 0.5)), int(round(W * share ** 0.5))
+        masks[:] = 0
+        for v in range(V):
+            y0, x0 = (H - mh) // 2 + 3 * v, (W - mw) // 2 + 5 * v
+            masks[v, y0:y0 + mh, x0:x0 + mw] = 1
     with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index, eager_mask=eager) as sc:
         sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
         d_masks = torch.from_numpy(masks).to(torch.device("cuda", dev_index))
@@ -329,13 +339,16 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
         alg = 20 + 4 * N
         out = {"scan_us": round(us, 2), "value": round(W * H / us, 1), "unit": "Mpixels/s",
                "frac": round(alg * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernel": kernel, "resident_views": V, "scans": scans}
+        if lasso:
+            out["selected_fraction"] = round(float(masks[0].mean()), 4)
+            out["frac_note"] = "frac prices the whole frame's algorithmic bytes; a gated launch moves the planes of the selected quads only"
         if not eager:
             out["launches_per_scan"] = 1
             out["note"] = ("per scan: sl3d_set_masks on a device-resident mask (recorded, nothing launched) + sl3d_run" + ("_clouds" if clouds else "") +
                            " of ONE view, a different view and mask each scan: ONE kernel, which evaluates the selection (the boundary removal of "
                            "stage 3 included) itself and leaves the band / 0-1 planes and the quad count k_mask_prepare would have left; frac = the "
                            "launch's algorithmic bytes (60 B/px) over its time")
-            out["two_kernel_route"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=scans, clouds=clouds, eager=True)
+            out["two_kernel_route"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=scans, clouds=clouds, eager=True, lasso=lasso)
             return out
         sc.timer_start()
         for i in range(scans):
@@ -461,6 +474,7 @@ def side_figures(args, scm, syn, np, dev_index):
             out["one_scan_from_idle"] = one_scan_from_idle(args, scm, syn, np, dev_index)
         out["per_scan_device"] = per_scan_device(args, scm, syn, np, torch, dev_index)
         out["per_scan_device_clouds"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, clouds=True)
+        out["per_scan_device_19pct_selection"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, lasso=True)
         # (distorted: projector k1,k2,p1,p2 + camera tangential terms; general: a skewed camera matrix as well -- since round 3 both
         # take the pipelined table kernel, RIG 2; the un-pipelined general kernel is left with perspective rows in K)
         for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig2_general_skewed_camera"), ("radial", "rig3_radial_projector")):

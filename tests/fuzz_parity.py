@@ -22,6 +22,7 @@ def main():
     # FUZZ_MAXW / FUZZ_MAXH: larger frames (thousands of 1024-pixel tiles per view: long look-back chains of the fused compaction)
     MAXW, MAXH = int(os.environ.get("FUZZ_MAXW", 400)), int(os.environ.get("FUZZ_MAXH", 200))
     bad = 0
+    maskin_cases = [0, 0]
     for case in range(cases):
         fullW, fullH = int(rng.integers(5, MAXW)), int(rng.integers(5, MAXH))
         if rng.random() < 0.5:
@@ -164,12 +165,55 @@ def main():
                         msg.append(f"batch of {V}: view {v} differs from its single launch")
                     if not np.array_equal(bclouds[v], one[0][one[1] == 1]):
                         msg.append(f"batch of {V}: cloud of view {v} != xyz[valid]")
+        # deferred masks (round 6): 1..4 views get NEW random selections and ONE launch -- a MASKIN launch wherever the configuration has
+        # one (3-step fringes, a pipelined rig class, 1..12 Gray planes, no tangential camera terms), else k_mask_prepare + the ordinary
+        # kernel -- must equal an SL3D_FLAG_EAGER_MASK context bit for bit: results, clouds, and the 0/1 plane it leaves behind
+        if not msg:
+            V = int(rng.integers(1, 5))
+            kw = dict(n_fringe=F, max_views=V, full_size=(fullW, fullH), origin=(col0, row0))
+            with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, **kw) as sc, S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, eager_mask=True, **kw) as eg:
+                masks = []
+                for v in range(V):
+                    m = (rng.random((fullH, fullW)) < rng.choice([0.7, 0.95, 1.0])).astype(np.uint8)
+                    if rng.random() < 0.3:
+                        m[rng.random(m.shape) < 0.3] = int(rng.integers(2, 256))
+                    masks.append(m)
+                clouds_route = rng.random() < 0.5
+                # the history the launch is routed by: dense (the early-request MASKIN kernel) or sparse (the gated one)
+                hist = np.ones((fullH, fullW), np.uint8) if rng.random() < 0.6 else (rng.random((fullH, fullW)) < 0.15).astype(np.uint8)
+                for x in (sc, eg):
+                    x.set_calibration(*ct)
+                    for v in range(V):
+                        x.set_frames(0, cap["planes_v"], view=v)
+                        x.set_frames(1, cap["planes_h"], view=v)
+                    x.set_masks(hist, 0, V)
+                    x.run(0, V)
+                    x.synchronize()
+                    x.set_masks(np.stack(masks))
+                    if not clouds_route:
+                        x.run(0, V)
+                    else:
+                        x.run_clouds(0, V)
+                names = sc.last_fused_kernel_name()
+                for v in range(V):
+                    a_, b_ = sc.points(v), eg.points(v)
+                    if not (np.array_equal(a_[1], b_[1]) and np.array_equal(a_[0], b_[0], equal_nan=True)):
+                        msg.append(f"deferred masks, {V} views ({names}): view {v} differs from the eager context")
+                    ba, bb = sc.device_buffers(), eg.device_buffers()
+                    pa, pb = np.empty((H + 4, ba.mask_pitch), np.uint8), np.empty((H + 4, bb.mask_pitch), np.uint8)
+                    sc._d2h(pa, ba.mask + v * ba.mask_view_stride); eg._d2h(pb, bb.mask + v * bb.mask_view_stride)
+                    if not np.array_equal(pa, pb):
+                        msg.append(f"deferred masks, {V} views ({names}): the 0/1 plane of view {v} differs")
+                if any(t in names for t in (", 4, false, true>", ", 6, false, true>")):
+                    maskin_cases[0] += 1
+                if any(t in names for t in (", 4, true, false>", ", 6, true, false>")):
+                    maskin_cases[1] += 1
         tag = f"case {case}: full {fullW}x{fullH} window {W}x{H}@({col0},{row0}) proj {PW}x{PH} N {Nv}/{Nh} fw {fwv}/{fwh} F {F} noise {noise} rig {rig} valid {int((o.valid_map(2) == 1).sum())}"
         if msg:
             bad += 1
             print("FAIL", tag, msg, flush=True)
         del o
-    print(f"{cases} cases, {bad} failures")
+    print(f"{cases} cases, {bad} failures; MASKIN launches: {maskin_cases[0]} early-request, {maskin_cases[1]} gated")
     return 1 if bad else 0
 
 if __name__ == "__main__":

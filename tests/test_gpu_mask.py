@@ -106,10 +106,10 @@ def test_small_launch_over_sparse_masks_takes_the_gated_kernel():
             assert np.array_equal(sc.fused_clouds(v, 1)[0], clouds[v]), v
         frames = [(sc.frames(0, v), sc.frames(1, v)) for v in (0, 3, 4)]
         # a new (dense) selection for view 0.  Since round 6 it is DEFERRED (evaluated by the launch that consumes it), so what is
-        # known is still the view's LAST selection: sparse -> k_mask_prepare + the gated kernel once more; that pass counts the new
-        # selection, and from then on a new mask + one view is ONE launch of the MASKIN instantiation
+        # known is still the view's LAST selection: sparse -> the GATED MASKIN form once more (plane requests behind the valid bits it
+        # evaluates); that launch counts the new selection, and from then on the view takes the form that requests its planes at once
         sc.set_mask(dense, view=0)
-        assert sc.fused_kernel_name(1).endswith(", 1, 0, true, false>"), sc.fused_kernel_name(1)
+        assert sc.fused_kernel_name(1).endswith(", 1, 4, true, false>"), sc.fused_kernel_name(1)
         sc.run(0, 1)
         sc.synchronize()
         assert sc.fused_kernel_name(1).endswith(", 1, 0, false, true>"), sc.fused_kernel_name(1)               # view 0 is dense now

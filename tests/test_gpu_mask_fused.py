@@ -12,6 +12,7 @@ from conftest import assert_points_close, pkg
 pytestmark = pytest.mark.gpu
 
 MASKIN_DENSE, MASKIN_CLOUDS = ", 4, false, true>", ", 6, false, true>"
+MASKIN_GATED, MASKIN_GATED_CLOUDS = ", 4, true, false>", ", 6, true, false>"   # the form for views known to be sparsely selected
 
 
 def _mask(rng, W, H, trial):
@@ -48,8 +49,8 @@ def _mask_plane(sc, view):
 
 
 def _dense_history(sc, FW, FH, V):
-    """What is known about a view's LAST selection decides its route (sparse: k_mask_prepare + the kernel whose plane requests wait for
-    the valid bits): give every view a fully selected one."""
+    """What is known about a view's LAST selection decides which MASKIN form its next scan takes (sparse: the gated one): give every
+    view a fully selected one."""
     sc.set_masks(np.ones((FH, FW), np.uint8), first_view=0, n_views=V)
     sc.run(0, V)
     sc.synchronize()
@@ -85,7 +86,7 @@ def test_fused_mask_route_against_literal_scan(FW, FH):
     for (x0, y0, w, h) in wins:
         kw = dict(full_size=(FW, FH), origin=(x0, y0), max_views=V)
         # (a window whose pitch padding alone leaves fewer than 65 % of its quads selectable is "sparsely selected" whatever the mask:
-        # such views keep the two-kernel route, whose plane requests wait for the valid bits)
+        # such views take the gated MASKIN form, whose plane requests wait for the valid bits)
         fused_route = -(-w // 4) >= 0.65 * (((w + 15) & ~15) // 4)
         with S.Scanner(w, h, PW, PH, N, N, fw, fw, **kw) as sc, S.Scanner(w, h, PW, PH, N, N, fw, fw, eager_mask=True, **kw) as eager:
             for c in (sc, eager):
@@ -105,8 +106,8 @@ def test_fused_mask_route_against_literal_scan(FW, FH):
                         for c in (sc, eager):
                             c.set_mask((pm if how == "single_pinned" else masks)[v], view=v)
                             c.run(v, 1)
-                        assert sc.last_fused_kernel_name().endswith(MASKIN_DENSE) == fused_route, sc.last_fused_kernel_name()
-                        assert not eager.last_fused_kernel_name().endswith(MASKIN_DENSE)
+                        assert sc.last_fused_kernel_name().endswith(MASKIN_DENSE if fused_route else MASKIN_GATED), sc.last_fused_kernel_name()
+                        assert ", 4, " not in eager.last_fused_kernel_name()
                 else:
                     for c in (sc, eager):
                         c.set_masks(masks)
@@ -114,11 +115,11 @@ def test_fused_mask_route_against_literal_scan(FW, FH):
                     pass
                 elif how == "batch":
                     sc.run(0, V)
-                    assert sc.last_fused_kernel_name().endswith(MASKIN_DENSE) == fused_route, sc.last_fused_kernel_name()
+                    assert sc.last_fused_kernel_name().endswith(MASKIN_DENSE if fused_route else MASKIN_GATED), sc.last_fused_kernel_name()
                     eager.run(0, V)
                 else:
                     clouds = sc.fused_clouds(0, V)
-                    assert sc.last_fused_kernel_name().endswith(MASKIN_CLOUDS) == fused_route, sc.last_fused_kernel_name()
+                    assert sc.last_fused_kernel_name().endswith(MASKIN_CLOUDS if fused_route else MASKIN_GATED_CLOUDS), sc.last_fused_kernel_name()
                     eclouds = eager.fused_clouds(0, V)
                 for v in range(V):
                     want = refs[v][y0:y0 + h, x0:x0 + w]
@@ -134,7 +135,7 @@ def test_fused_mask_route_against_literal_scan(FW, FH):
                     assert np.array_equal(_mask_plane(sc, v), _mask_plane(eager, v)), tag
                 # an ordinary launch over the same views reads the band plane the MASKIN launch wrote
                 sc.run(0, V)
-                assert not sc.last_fused_kernel_name().endswith(MASKIN_DENSE)
+                assert ", 4, " not in sc.last_fused_kernel_name()
                 for v in range(V):
                     assert np.array_equal(sc.points(v)[1], refs[v][y0:y0 + h, x0:x0 + w]), (how, v, "second launch")
 
@@ -247,14 +248,14 @@ def test_deferred_masks_are_prepared_for_every_other_consumer():
 
 def test_fused_mask_route_counts_selected_quads():
     """A MASKIN launch leaves the view's count of selected quads (one word per wave in mapped host memory): a view whose LAST selection
-    was sparse keeps the two-kernel route (its plane requests wait for the valid bits), a dense one takes the one-launch route."""
+    was sparse takes the gated form (its plane requests wait for the valid bits the launch evaluates), a dense one the form that requests
+    its planes at once.  Either way: one launch, and the eager context's results bit for bit."""
     S, syn = pkg("scanner"), pkg("synth")
     W, H, PW, PH, N, fw = 960, 540, 1024, 768, 9, 2
     cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
     dense = syn.default_mask(W, H)
     sparse = np.zeros((H, W), np.uint8)
     sparse[150:390, 300:700] = 1
-    gated = ", 1, 0, true, false>"
     with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=2) as sc, S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=2, eager_mask=True) as eager:
         for c in (sc, eager):
             c.set_calibration(*cal)
@@ -262,9 +263,9 @@ def test_fused_mask_route_counts_selected_quads():
                 c.synth_view(v, plane=(1.5 * v, 0.05, 0.04), view_id=v, noise=2)
         seq = [sparse, sparse, dense, dense, sparse, sparse]
         want = [MASKIN_DENSE,    # nothing known about the view: counts as dense
-                gated,           # its last selection was sparse
-                gated,           # ... still what is known when the dense one arrives
-                MASKIN_DENSE, MASKIN_DENSE, gated]
+                MASKIN_GATED,    # its last selection was sparse: the form whose plane requests wait for the valid bits
+                MASKIN_GATED,    # ... still what is known when the dense one arrives
+                MASKIN_DENSE, MASKIN_DENSE, MASKIN_GATED]
         for i, (m, k) in enumerate(zip(seq, want)):
             sc.set_mask(m, view=0)
             eager.set_mask(m, view=0)
@@ -273,6 +274,51 @@ def test_fused_mask_route_counts_selected_quads():
             assert sc.last_fused_kernel_name().endswith(k), (i, sc.last_fused_kernel_name())
             a, b = sc.points(0), eager.points(0)
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True), i
+
+
+def test_route_of_back_to_back_scans_follows_the_last_count_that_arrived():
+    """The reference's loop sets a new selection and launches at once, scan after scan (m_tech_project_console.cpp:366-395): the count
+    of the selection a scan replaces is usually still on its way when the next launch is routed.  The route then follows the last count
+    that DID arrive (sparse_views): lassos of the reference's size keep the gated kernels -- one MASKIN launch on a deferring context,
+    k_mask_prepare + the gated fused kernel on an eager one -- without a single synchronisation between scans, and whichever kernel
+    runs, the results are the eager context's bit for bit."""
+    import torch
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, PW, PH, N, fw = 960, 540, 1024, 768, 9, 2
+    cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
+    lassos = np.zeros((6, H, W), np.uint8)
+    for k in range(6):
+        lassos[k, 150 + 3 * k:390 + 3 * k, 300 + 5 * k:700 + 5 * k] = 1
+    d_lassos = torch.from_numpy(lassos).cuda()
+    d_dense = torch.from_numpy(syn.default_mask(W, H)).cuda()
+    torch.cuda.synchronize()
+    with S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=2) as sc, S.Scanner(W, H, PW, PH, N, N, fw, fw, max_views=2, eager_mask=True) as eager:
+        for c in (sc, eager):
+            c.set_calibration(*cal)
+            for v in range(2):
+                c.synth_view(v, plane=(1.5 * v, 0.05, 0.04), view_id=v, noise=2)
+                c.set_masks_device(d_lassos.data_ptr(), W, 0, v, 1)
+            c.run(0, 2)
+            c.synchronize()                       # the views' counts are known now: sparse
+        for c, gated in ((sc, MASKIN_GATED), (eager, ", 1, 0, true, false>")):
+            for i in range(24):                   # nothing is waited for in this loop
+                c.set_masks_device(d_lassos.data_ptr() + (i % 6) * W * H, W, 0, i % 2, 1)
+                c.run(i % 2, 1)
+                assert c.last_fused_kernel_name().endswith(gated), (i, c.last_fused_kernel_name())
+        for v in range(2):
+            a, b = sc.points(v), eager.points(v)
+            assert b[1].sum() > 0 and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True), v
+        # a dense selection behind sparse ones: routed as sparse once (all that is known), as dense from then on
+        for c, first, then in ((sc, MASKIN_GATED, MASKIN_DENSE), (eager, ", 1, 0, true, false>", ", 1, 0, false, true>")):
+            for want in (first, then):
+                c.set_masks_device(d_dense.data_ptr(), W, 0, 0, 1)
+                c.run(0, 1)
+                name = c.last_fused_kernel_name()
+                c.synchronize()
+                if c is sc or want == then:       # (eager, first launch: its own count may or may not have landed before the launch was routed)
+                    assert name.endswith(want), (want, name)
+        a, b = sc.points(0), eager.points(0)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
 
 
 def test_fused_mask_route_several_views_per_lane():
