@@ -267,7 +267,9 @@ int sl3d_register_clouds(sl3d_ctx *ctx, int first_view, int n_views, float tx, f
 int sl3d_fused_kernel_name(sl3d_ctx *ctx, int n_views, int clouds, char *buf, size_t capacity);
 /* The instantiation the LAST fused launch of this context ran (sl3d_run, sl3d_run_clouds, sl3d_run_timed, sl3d_process_views): the
  * choice is recorded when the launch is made -- it depends on what was known about the views' masks at that moment (a small
- * launch over sparsely selected views takes another kernel), so a later prediction could name a different one. */
+ * launch over sparsely selected views takes another kernel; while the count of a selection is still on its way from the device, the
+ * last count of that view that did arrive decides), so a later prediction could name a different one.  The choice never changes a
+ * bit of the results. */
 int sl3d_last_fused_kernel_name(sl3d_ctx *ctx, char *buf, size_t capacity);
 /* Bytes per camera pixel a fused launch of n_views views reads from the camera-side table of sl3d_set_calibration (T1 per window pixel,
  * 7/triangulation.cpp:252-307), once per LAUNCH whatever the number of views: 0 = no table (no camera distortion, parity mode),

@@ -15,6 +15,11 @@ cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc.json profiles/${TAG}_tra
 STATS_LINES=6 stats ${TAG}_per_scan python3 tools/mask_timing.py 1920 1080
 STATS_LINES=6 stats c2_${TAG}_per_scan python3 tools/mask_timing.py 4096 3000
 cp $T/${TAG}_per_scan.out $T/${TAG}_per_scan.json; cp $T/c2_${TAG}_per_scan.out $T/c2_${TAG}_per_scan.json
+# ... and with the reference's own kind of selection (a 19 % lasso, a new one every scan): the gated kernels
+export LASSO=1
+STATS_LINES=6 stats ${TAG}_per_scan_19pct python3 tools/mask_timing.py 1920 1080
+unset LASSO
+cp $T/${TAG}_per_scan_19pct.out $T/${TAG}_per_scan_19pct.json
 STATS_LINES=6 stats ${TAG}_oneview python3 tools/oneview_clouds.py
 cp $T/${TAG}_oneview.out $T/${TAG}_oneview_dense_clouds_host.txt
 STATS_LINES=4 stats ${TAG}_oneview_cold python3 bench.py --one-view-cold-only --steps 4000
