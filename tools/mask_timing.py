@@ -20,7 +20,8 @@ args = bench.parse()
 syn = importlib.import_module("3dscan_amd.synth")
 scm = importlib.import_module("3dscan_amd.scanner")
 LASSO = os.environ.get("LASSO", "0") == "1"   # the reference's 19 % selections: the gated kernels
-out = {"size": [W, H], "per_scan_device": bench.per_scan_device(args, scm, syn, np, torch, 0, lasso=LASSO)}
+CLOUDS = os.environ.get("PERSCAN_CLOUDS", "0") == "1"   # the ordered cloud instead of the dense planes
+out = {"size": [W, H], "per_scan_device": bench.per_scan_device(args, scm, syn, np, torch, 0, lasso=LASSO, clouds=CLOUDS)}
 full = syn.default_mask(W, H)
 with scm.Scanner(W, H, W, H, args.ngray, args.ngray, args.fringe_width, args.fringe_width, max_views=16) as sc:
     pm = sc.pinned(full.shape, np.uint8)
