@@ -36,6 +36,11 @@ def test_committed_bench_line_keeps_the_contract():
     assert p["launches_per_scan"] == 1 and p["kernel"].endswith(", 1, 4, false, true>") and p["scan_us"] <= 31.0
     t = p["two_kernel_route"]
     assert t["launches_per_scan"] == 2 and t["mask_us"] <= 8.0 and p["scan_us"] <= t["scan_us"] - 1.0
+    # ... and on the reference's own kind of selection (a 19 % lasso): one launch of the gated MASKIN form, ahead of the two gated kernels
+    g = s["per_scan_device_19pct_selection"]
+    assert g["launches_per_scan"] == 1 and g["kernel"].endswith(", 1, 4, true, false>") and 0.15 <= g["selected_fraction"] <= 0.22
+    assert g["two_kernel_route"]["kernel"].endswith(", 1, 0, true, false>") and g["scan_us"] <= g["two_kernel_route"]["scan_us"] - 1.0
+    assert g["scan_us"] <= 0.75 * p["scan_us"]
     assert s["one_view_cold_clouds"]["frac"] >= 0.57 and s["one_view_cold"]["moved_bytes_per_pixel"] == 68
     assert d["set_mask_us"]["pinned"]["until_ready"] <= 70.0
     assert {"resident", "with_upload"} <= set(s["one_scan_from_idle"])
