@@ -321,6 +321,59 @@ def test_route_of_back_to_back_scans_follows_the_last_count_that_arrived():
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0], equal_nan=True)
 
 
+@pytest.mark.parametrize("rig,rig_class", [("reference", 1), ("tangential", 2), ("radial", 3)])
+@pytest.mark.parametrize("Nv,Nh", [(7, 7), (7, 6)])
+def test_gated_form_every_rig_class_exact_and_padded(rig, rig_class, Nv, Nh):
+    """The gated MASKIN kernels (views whose last selection was sparse) of every rig class that has them, with equal Gray depths (the
+    exact instantiation) and unequal ones (the padded one -- for rig classes 2 and 3 the form that takes its pad count through
+    v_readfirstlane, sl3d_fused.h: issue_gray), dense planes and clouds, one view and three: the kernel that ran is the gated one, the
+    valid map lies inside the oracle's literal scan of the new selection, and valid map, results, clouds and the 0/1 plane equal the eager context's
+    (k_mask_prepare + the ordinary gated kernel) bit for bit."""
+    S, syn = pkg("scanner"), pkg("synth")
+    W, H, fw, V = 328, 150, 4, 3
+    PW, PH = fw << Nv, fw << Nh
+    cal_d = syn.synth_rig(W, H, PW, PH)
+    if rig == "tangential":
+        cal_d["dp"] = np.array([-0.05, 0.02, 0.001, -0.0015, 0.0])
+    elif rig == "radial":
+        cal_d["dp"] = np.array([-0.05, 0.02, 0.0, 0.0, 0.0])
+    cal = syn.cal_tuple(cal_d)
+    rng = np.random.default_rng(Nv * 10 + Nh)
+    lassos = np.zeros((V + 1, H, W), np.uint8)
+    for k in range(V + 1):
+        lassos[k, 40 + 2 * k:100 + 2 * k, 90 + 3 * k:220 + 3 * k] = 1
+        lassos[k][rng.random((H, W)) < 0.01] = 0
+    refs = [_oracle_valid(m) for m in lassos]
+    tail = f", {rig_class}, %d, true, false>"
+    with S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=V) as sc, S.Scanner(W, H, PW, PH, Nv, Nh, fw, fw, max_views=V, eager_mask=True) as eager:
+        for c in (sc, eager):
+            c.set_calibration(*cal)
+            for v in range(V):
+                c.synth_view(v, plane=(1.5 * v, 0.05, 0.04), view_id=v, noise=2)
+        for n, clouds in ((1, False), (V, False), (1, True), (V, True)):
+            for c in (sc, eager):
+                c.set_masks(lassos[V], 0, V)      # the history: every view sparsely selected, and known to be
+                c.run(0, V)
+                c.synchronize()
+                c.set_masks(lassos[:n])
+                got = c.fused_clouds(0, n) if clouds else c.run(0, n)
+                if c is sc:
+                    mine = got
+            name = sc.last_fused_kernel_name()
+            assert name.endswith(tail % (6 if clouds else 4)), name
+            assert ("true" if Nv == Nh else "false") + f", {rig_class}, " in name, name
+            assert eager.last_fused_kernel_name().endswith(tail % (2 if clouds else 0)), eager.last_fused_kernel_name()
+            for v in range(n):
+                a, b = sc.points(v), eager.points(v)
+                # (stage 3's valid map is the oracle's literal scan of the selection; stage 5 then drops what the projector does not light)
+                assert np.array_equal(a[1], b[1]) and not (a[1] & ~refs[v]).any() and a[1].sum() > 0.5 * refs[v].sum(), (n, clouds, v)
+                if clouds:
+                    assert np.array_equal(mine[v], got[v]) and len(mine[v]) == int(a[1].sum()), (n, v)
+                else:
+                    assert np.array_equal(a[0], b[0], equal_nan=True), (n, v)
+                assert np.array_equal(_mask_plane(sc, v), _mask_plane(eager, v)), (n, clouds, v)
+
+
 def test_fused_mask_route_several_views_per_lane():
     """4.2 Mpx: a launch of 3 views runs 2 views per lane (tools: views_per_lane) -- every view of an item evaluates its own selection."""
     S, syn = pkg("scanner"), pkg("synth")

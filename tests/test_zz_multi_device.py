@@ -165,6 +165,26 @@ def test_bench_two_ranks_over_rccl_assemble_the_single_rank_result():
 
 
 @needs_two
+@pytest.mark.skipif(PRETEND > 0, reason="RCCL needs one physical GPU per rank")
+def test_bench_two_ranks_strong_scaling_and_rank_identity():
+    """--scaling strong over RCCL: BASELINE configs[3] as stated (a FIXED batch of views, every view row-sharded over the ranks) -- the
+    assembled digests equal the one-rank run over the same batch; the line names the RCCL version, the communicator size and one
+    distinct PCI bus id per rank (what lets the driver confirm N ranks on N GPUs); the 19 % selection variant of the single-root
+    compact gather is there and never the headline."""
+    common = ["--steps", "3", "--warmup", "1", "--precondition-ms", "0", "--no-cpu-baseline", "--no-side", "--check", "--height", "1080",
+              "--scaling", "strong", "--total-views", "4"]
+    one = _bench("--gpus", "1", *common)
+    two = _bench("--gpus", "2", "--backend", "nccl", "--chunks", "2", *common)
+    assert two["scaling"] == "strong" and two["config"]["views_per_step"] == 4 and two["config"]["rows_per_gpu"] == 540
+    assert two["check"]["dense_sha256"] == one["check"]["dense_sha256"] and two["check"]["compact_sha256"] == one["check"]["compact_sha256"]
+    ids = [r["pci_bus_id"] for r in two["ranks"]]
+    assert len(set(ids)) == 2 and all(ids), ids
+    assert all(r["comm_size"] == 2 and r["rccl_version"] for r in two["ranks"]), two["ranks"]
+    wa = two["with_assembly"]
+    assert two["value_is"].startswith("dense_") and "compact_root_gather_19pct_selection" in wa and "error" not in wa["compact_root_gather_19pct_selection"]
+
+
+@needs_two
 @pytest.mark.parametrize("mode", ["memory", "memory+deferred_final"])
 def test_shim_over_two_devices(tmp_path, mode):
     """The drop-in shim with SL3D_DEVICES=0,1: the scan as two row stripes on two GPUs, stage by stage and deferred -- every global
