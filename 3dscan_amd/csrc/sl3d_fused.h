@@ -42,7 +42,7 @@
 #define SL3D_STAMP(k)                                                                                                               \
     do {                                                                                                                            \
         /* every lane of the wave stores the same (scalar) clock to the same word: no divergent branch in the instrumented code */   \
-        if (CMODE == 0 && !KEEP && P.dbg)                                                                                           \
+        if ((CMODE & 2) == 0 && !KEEP && P.dbg)                                                                                           \
             P.dbg[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64();              \
     } while (0)
 #else

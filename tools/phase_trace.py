@@ -3,9 +3,10 @@
 every wave stamps the 100 MHz wall clock at its phase boundaries (sl3d_kernels.hip, SL3D_STAMP).  Prints where the time of a
 launch goes -- start-up, the rounds of blocks, how many waves sit in which phase at every microsecond -- i.e. what bounds the
 one-view launch (the reference's real usage: one scan per call).
-    SL3D_LIB=$PWD/ab/trace_libsl3d.so python3 tools/phase_trace.py [views] [cold]   -> gpurun_out/phase_trace_<views>.npz + a summary
+    SL3D_LIB=$PWD/ab/libsl3d_trace.so python3 tools/phase_trace.py [views] [cold] [maskin]   -> gpurun_out/phase_trace_<views>.npz + a summary
 `cold` (with 1 view per launch): 8 views are resident and every launch takes the next one, so the traced launch reads its frames
-from HBM, not from the Infinity Cache (side.one_view_cold of bench.py)."""
+from HBM, not from the Infinity Cache (side.one_view_cold of bench.py).  `maskin`: every launch is preceded by a new device-resident
+selection (side.per_scan_device): the traced launch is a MASKIN launch; "item set-up" then contains the evaluation of the selection."""
 import ctypes as C
 import importlib
 import os
@@ -20,7 +21,8 @@ scm = importlib.import_module("3dscan_amd.scanner")
 syn = importlib.import_module("3dscan_amd.synth")
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-COLD = len(sys.argv) > 2 and sys.argv[2] == "cold"
+COLD = "cold" in sys.argv[2:]
+MASKIN = "maskin" in sys.argv[2:]
 R = 8 if COLD else 1            # resident batches the launches rotate over
 W, H, N, fw = 1920, 1080, 10, 2
 sc = scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V * R)
@@ -29,13 +31,23 @@ m = syn.default_mask(W, H)
 for v in range(V * R):
     sc.set_mask(m, view=v)
     sc.synth_view(v, plane=(0.75 * v, 0.05, 0.05 - 0.003 * v), view_id=v, noise=2)
-for i in range(500):          # clocks up: the launch that is traced is one of a back-to-back series
+d_m = torch.from_numpy(m).cuda() if MASKIN else None
+
+
+def launch(i):
+    if MASKIN:
+        sc.set_masks_device(d_m.data_ptr(), W, 0, (i % R) * V, V)
     sc.run((i % R) * V, V)
+
+
+for i in range(500):          # clocks up: the launch that is traced is one of a back-to-back series
+    launch(i)
 sc.synchronize()
 sc.timer_start()
 for i in range(200):
-    sc.run((i % R) * V, V)
+    launch(i)
 ms = sc.timer_stop() / 200
+print("kernel:", sc.last_fused_kernel_name())
 sc.synchronize()
 L = sc.L
 dev, nbytes, nt = C.c_void_p(), C.c_size_t(), C.c_int()
