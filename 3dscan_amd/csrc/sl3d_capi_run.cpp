@@ -59,9 +59,8 @@ SL3D_CATCH(x)
 // can the launch over views [first_view, first_view + n_views) evaluate their (deferred) selections itself?  Every view's mask is
 // deferred, in one layout, and the launch has a MASKIN instantiation.  (Views known -- by their LAST counts -- to be sparsely selected take
 // the gated MASKIN form, whose plane requests wait for the valid bits the launch has just evaluated: launch_fused.)
-bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep, bool prefer_gated)
+bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep)
 {
-    (void)prefer_gated;  // (sparsely selected views have a MASKIN form too: the gated kernel, whose plane requests wait for the valid bits)
     if (x->n_pending == 0 || !fused_maskin_available(x->P, x->rig, n_views, keep)) return false;
     const sl3d_ctx::PendingMask &p0 = x->pend[(size_t)first_view];
     for (int v = first_view; v < first_view + n_views; v++) {
@@ -74,7 +73,7 @@ bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep, bo
 int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode)
 {
     const bool prefer_gated = sparse_views(x, first_view, n_views);
-    const bool maskin = maskin_launch(x, first_view, n_views, keep, prefer_gated);
+    const bool maskin = maskin_launch(x, first_view, n_views, keep);
     x->last_fused.n_views = n_views;
     x->last_fused.cmode = cmode;
     x->last_fused.keep = keep;
@@ -135,7 +134,7 @@ try {
     if (!x || !buf || capacity == 0 || n_views < 1) return fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: null argument");
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called (the rig class is part of the name)");
     const bool fits = n_views <= x->cfg.max_views, gated = fits && sparse_views(x, 0, n_views);
-    const int n = fused_kernel_name(x->P, x->rig, n_views, x->keep, clouds ? 2 : 0, buf, capacity, gated, fits && maskin_launch(x, 0, n_views, x->keep, gated));
+    const int n = fused_kernel_name(x->P, x->rig, n_views, x->keep, clouds ? 2 : 0, buf, capacity, gated, fits && maskin_launch(x, 0, n_views, x->keep));
     return n > 0 && (size_t)n < capacity ? SL3D_OK : fail(x, SL3D_E_INVALID_ARG, "fused_kernel_name: buffer too small");
 }
 SL3D_CATCH(x)

@@ -97,8 +97,8 @@ def test_fused_mask_route_against_literal_scan(FW, FH):
             pm = sc.pinned(masks.shape, np.uint8)
             pm[:] = masks
             for how in ("single", "single_pinned", "batch", "batch_clouds"):
-                # what is known about the views' last selections decides the route (a view whose last selection was sparse keeps the
-                # two-kernel route, test_fused_mask_route_counts_selected_quads): every pass starts from densely selected views
+                # what is known about the views' last selections decides the MASKIN form (a view whose last selection was sparse takes
+                # the gated one, test_fused_mask_route_counts_selected_quads): every pass starts from densely selected views
                 for c in (sc, eager):
                     _dense_history(c, FW, FH, V)
                 if how.startswith("single"):   # the reference's loop: a new selection, then the scan (m_tech_project_console.cpp:366-395)
@@ -170,7 +170,7 @@ def test_fused_mask_route_device_resident_and_colrow():
                 for v in range(V):
                     assert np.array_equal(sc.points(v)[1], refs[v][y0:y0 + h, x0:x0 + w]), (name, v, x0, y0)
                 # one view at a time, each with the mask of ANOTHER view than last time (what bench.py's per_scan_device does); a view
-                # whose last selection was sparse would keep the two-kernel route: every view starts from a dense one
+                # whose last selection was sparse would take the gated MASKIN form: every view starts from a dense one
                 _dense_history(sc, FW, FH, V)
                 for v in range(V):
                     k = (v + 1) % V
@@ -196,7 +196,7 @@ def test_deferred_masks_are_prepared_for_every_other_consumer():
     PW, PH = fw << N, fw << N
     rng = np.random.default_rng(77)
     cal = syn.cal_tuple(syn.synth_rig(W, H, PW, PH))
-    # (densely selected throughout: a view whose last selection was sparse keeps the two-kernel route whatever else happens)
+    # (densely selected throughout: a view whose last selection was sparse would take the gated MASKIN form)
     masks = np.stack([(rng.random((H, W)) < 0.97).astype(np.uint8) * (1 if t % 2 == 0 else rng.integers(1, 2, (H, W), dtype=np.uint8)) for t in range(V)])
     masks[1][masks[1] == 0] = 7
     refs = [_oracle_valid(m) for m in masks]
