@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--idle-samples", type=int, default=20, help="samples per variant of side.one_scan_from_idle (0 = skip it; each sample sleeps --idle-sleep s)")
     ap.add_argument("--idle-sleep", type=float, default=1.0, help="idle time in front of every sample of side.one_scan_from_idle, seconds")
     ap.add_argument("--idle-only", action="store_true", help="run only side.one_scan_from_idle and print it")
+    ap.add_argument("--families-only", action="store_true",
+                    help="run only the 16-view launches of the other kernel families (rig classes 2 / 3 / 0, 9 and 14 Gray planes) and print them: "
+                         "the command behind profiles/rNN_families_kernel_stats.csv")
     ap.add_argument("--cold-views", type=int, default=8, help="resident views the one-view-cold figure rotates over (8 x 97.5 MB of frames > 256 MiB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--devices", default="", help="comma-separated HIP device per rank (default: LOCAL_RANK). Repeating a device "
@@ -443,8 +446,10 @@ def config2_12mp(args, scm, syn, np, dev_index, W=4096, H=3000, views=3, fw=4, l
                 "note": "BASELINE configs[2]: 4096x3000, 3 phase + 2x%d Gray frames per axis, %d views per launch" % (N, views)}
 
 
-def side_figures(args, scm, syn, np, dev_index):
-    """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`."""
+def side_figures(args, scm, syn, np, dev_index, families_only=False):
+    """Other instantiations of the same kernel on the same box, steady state, kernel-only (HIP events): never `value`.
+    families_only (--families-only, what runs under rocprofv3 for profiles/rNN_families_kernel_stats.csv): the 16-view launches of the
+    other kernel families alone -- rig classes 2, 3 and 0, 9 and 14 Gray planes."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
     out = {}
     full_mask = syn.default_mask(W, H)
@@ -461,29 +466,31 @@ def side_figures(args, scm, syn, np, dev_index):
         return sc
 
     try:
-        with ctx("reference", N, 1) as sc:   # the reference's real usage: one view per scan (m_tech_project_console.cpp:372-395)
-            v, f, ms = steady_rate(sc, 1, W * H, 20 + 4 * N, 2000)
-            out["one_view_cache_resident"] = {"value": v, "unit": "Mpixels/s", "frac_of_hbm_peak_but_served_by_the_infinity_cache": f,
-                                              "launch_us": round(ms * 1e3, 2),
-                                              "note": "the SAME view launched back to back: its 124 MB working set sits in the 256 MiB Infinity Cache, so this is "
-                                                      "not an HBM figure (round 3 reported it as one_view_latency); one_view_cold is"}
-        out["one_view_cold"] = one_view_cold(args, scm, syn, np, dev_index)
-        out["one_view_cold_clouds"] = one_view_cold(args, scm, syn, np, dev_index, launches=1000, clouds=True)
-        import torch
-        if args.idle_samples > 0:
-            out["one_scan_from_idle"] = one_scan_from_idle(args, scm, syn, np, dev_index)
-        out["per_scan_device"] = per_scan_device(args, scm, syn, np, torch, dev_index)
-        out["per_scan_device_clouds"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, clouds=True)
-        out["per_scan_device_19pct_selection"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, lasso=True)
+        if not families_only:
+            with ctx("reference", N, 1) as sc:   # the reference's real usage: one view per scan (m_tech_project_console.cpp:372-395)
+                v, f, ms = steady_rate(sc, 1, W * H, 20 + 4 * N, 2000)
+                out["one_view_cache_resident"] = {"value": v, "unit": "Mpixels/s", "frac_of_hbm_peak_but_served_by_the_infinity_cache": f,
+                                                  "launch_us": round(ms * 1e3, 2),
+                                                  "note": "the SAME view launched back to back: its 124 MB working set sits in the 256 MiB Infinity Cache, so this is "
+                                                          "not an HBM figure (round 3 reported it as one_view_latency); one_view_cold is"}
+            out["one_view_cold"] = one_view_cold(args, scm, syn, np, dev_index)
+            out["one_view_cold_clouds"] = one_view_cold(args, scm, syn, np, dev_index, launches=1000, clouds=True)
+            import torch
+            if args.idle_samples > 0:
+                out["one_scan_from_idle"] = one_scan_from_idle(args, scm, syn, np, dev_index)
+            out["per_scan_device"] = per_scan_device(args, scm, syn, np, torch, dev_index)
+            out["per_scan_device_clouds"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, clouds=True)
+            out["per_scan_device_19pct_selection"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=200, lasso=True)
         # (distorted: projector k1,k2,p1,p2 + camera tangential terms; general: a skewed camera matrix as well -- since round 3 both
         # take the pipelined table kernel, RIG 2; the un-pipelined general kernel is left with perspective rows in K)
         for rig, key in (("distorted", "rig2_distorted_projector"), ("general", "rig2_general_skewed_camera"), ("radial", "rig3_radial_projector")):
             with ctx(rig, N, args.views) as sc:
                 v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * N, 400)
-                out[key] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms}
+                out[key] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "kernel": sc.last_fused_kernel_name()}
         with ctx("reference", N - 1, args.views, proj=min(W, fw << (N - 1))) as sc:   # (a shorter Gray code covers a smaller projector)
             v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * (N - 1), 400)
-            out[f"n_gray_{N - 1}"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "algorithmic_bytes_per_pixel": 20 + 4 * (N - 1)}
+            out[f"n_gray_{N - 1}"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "algorithmic_bytes_per_pixel": 20 + 4 * (N - 1),
+                                      "kernel": sc.last_fused_kernel_name()}
         # The kernel families and BASELINE configurations no other figure of this line times (round 5's review): the un-pipelined general
         # kernel (rig class 0: a camera matrix that is not upper triangular), more than 12 Gray planes per axis (the per-plane-test
         # kernels, every rig class on the general kernel), and BASELINE configs[2] (4096x3000, 3 views per launch: what fits beside
@@ -496,13 +503,14 @@ def side_figures(args, scm, syn, np, dev_index):
             v, f, ms = steady_rate(sc, args.views, args.views * W * H, 20 + 4 * 14, 200)
             out["n_gray_14"] = {"value": v, "unit": "Mpixels/s", "frac": f, "ms_per_launch": ms, "algorithmic_bytes_per_pixel": 20 + 4 * 14,
                                 "kernel": sc.last_fused_kernel_name(), "note": "14 Gray planes per axis (fringe width 1): the per-plane-test kernel"}
-        out["config2_12mp"] = config2_12mp(args, scm, syn, np, dev_index)
+        if not families_only:
+            out["config2_12mp"] = config2_12mp(args, scm, syn, np, dev_index)
     except Exception as e:
         out["error"] = repr(e)
     # the Level-1 drop-in path: the reference's six stage calls + save_point_cloud() through the shim at the reference's own
     # 1600x1200 (tools/shim_bench.cpp: host wall time per scan, BMP files / memory, device-side [col][row] globals vs host transposes)
     # (behind --shim-timing since round 4: it needs a host compiler and disk I/O; the committed figure is profiles/r04_shim_scan_ms.json)
-    if args.shim_timing:
+    if args.shim_timing and not families_only:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import shim_timing
@@ -620,6 +628,9 @@ def main():
         return
     if args.one_view_cold_only:
         emit(json.dumps({"one_view_cold": one_view_cold(args, scm, syn, np, dev_index, launches=max(args.steps, 200))}))
+        return
+    if args.families_only:
+        emit(json.dumps({"families": side_figures(args, scm, syn, np, dev_index, families_only=True)}))
         return
 
     # ---- synthetic inputs, generated on the device, resident in HBM before the timed region ----

@@ -24,6 +24,9 @@ STATS_LINES=6 stats ${TAG}_oneview python3 tools/oneview_clouds.py
 cp $T/${TAG}_oneview.out $T/${TAG}_oneview_dense_clouds_host.txt
 STATS_LINES=4 stats ${TAG}_oneview_cold python3 bench.py --one-view-cold-only --steps 4000
 cp $T/${TAG}_oneview_cold.out $T/${TAG}_oneview_cold_under_rocprof.json
+# the 16-view launches of the other kernel families (rig classes 2 / 3 / 0, 9 and 14 Gray planes): one rocprofv3 row per side.* figure
+STATS_LINES=8 stats ${TAG}_families python3 bench.py --families-only
+cp $T/${TAG}_families.out $T/${TAG}_families.json
 STATS_LINES=4 stats ${TAG}_rig3 python3 bench.py --rig radial --no-cpu-baseline --no-side
 cp $T/${TAG}_rig3.out $T/${TAG}_rig3_bench_under_rocprof.json
 SL3D_SHIM_TIMING=1 timeout 900 python3 tools/shim_timing.py 7 > $T/${TAG}_shim_scan_ms.json 2> $T/shim_timing.err
