@@ -133,7 +133,7 @@ __device__ __forceinline__ double recip1(double d)
 // on EVERY point of that lattice.  That equality is not assumed: tests/native/exact_arith_check.c proves it
 // on the CPU with the same constants (sl3d_atan_coeffs.h), and sl3d_create() runs k_atan_selfcheck over all
 // 521,731 points against a table built with the host's libm and refuses to create a context if a single
-// value differs (tests/test_gpu_parity.py repeats the check).
+// value differs (tests/test_gpu_stage_parity.py repeats the check).
 // Method: octant reduction on the integers, a second reduction lo/hi > 70/169 -> (hi-lo)/(hi+lo) (still a
 // quotient of small integers, so there is exactly one division), atan(r) = r + r*z*Q(z), z = r^2, Horner.
 // Accuracy budget: the true atan2 of a lattice point stays >= 6.7e-14 (relative, ~300 ulp of a double) away
