@@ -5,4 +5,4 @@ The product is the C-ABI library built from csrc/ (see include/sl3d.h); this pac
 thin Python host layer around it (ctypes bindings, synthetic captures, multi-GPU launch glue).
 The directory name starts with a digit, so import it with importlib.import_module("3dscan_amd").
 """
-__version__ = "0.5.0"  # = SL3D_VERSION_STRING of include/sl3d.h (tests/test_abi.py checks)
+__version__ = "0.6.0"  # = SL3D_VERSION_STRING of include/sl3d.h (tests/test_abi.py checks)

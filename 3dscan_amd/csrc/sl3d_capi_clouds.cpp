@@ -51,10 +51,14 @@ try {
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     if (x->keep) return fail(x, SL3D_E_STATE, "sl3d_run_clouds is the timed mode: create the context without SL3D_FLAG_KEEP_STAGES");
-    ON_DEVICE(x);
+    ON_DEVICE_QUIET(x);
+    // (a small launch goes beside the one before it, sl3d_ctx.h: launch lanes -- once the cloud buffers exist; its consumers join)
+    const bool small = x->lanes_ok && x->clouds_ready && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && x->runs_in_a_row > 0;
+    if (!overlap && (rc = sl3d_lanes_join(x))) return rc;
+    if (small) x->runs_in_a_row++;
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
-    rc = run_fused(x, first_view, n_views, false, 2);
+    rc = run_fused(x, first_view, n_views, false, 2, overlap);
     if (rc) return rc;
     // A launch of a few views (the reference's one scan per call) leaves the scan of the segment counts to whoever consumes the
     // clouds: the gap-closing kernel adds up the counts in front of its segments itself, so there is no scan launch -- 4.8 us + a

@@ -130,6 +130,9 @@ try {
     }
     CREATE_CHK(hipEventCreate(&x->ev0));
     CREATE_CHK(hipEventCreate(&x->ev1));
+    // (launch lanes: only beside a stream nobody else can see, never in the parity mode; SL3D_NO_LAUNCH_LANES=1 in the environment
+    // switches them off for a whole process -- A/B measurements of programs that cannot pass the flag)
+    x->lanes_ok = x->own_stream && !(c.flags & (SL3D_FLAG_SERIAL_LAUNCHES | SL3D_FLAG_KEEP_STAGES)) && !getenv("SL3D_NO_LAUNCH_LANES");
 
     KParams &P = x->P;
     P.W = c.width; P.H = c.height; P.fullW = c.full_width; P.fullH = c.full_height;
@@ -269,7 +272,14 @@ extern "C" void sl3d_destroy(sl3d_ctx *x)
 try {
     if (!x) return;
     DeviceGuard dev_guard_(x->cfg.device);
+    for (int l = 0; l < 2; l++)
+        if (x->lane[l]) (void)hipStreamSynchronize(x->lane[l]);
     if (x->stream) (void)hipStreamSynchronize(x->stream);
+    for (int l = 0; l < 2; l++) {
+        if (x->ev_lane[l]) (void)hipEventDestroy(x->ev_lane[l]);
+        if (x->lane[l]) (void)hipStreamDestroy(x->lane[l]);
+    }
+    if (x->ev_main) (void)hipEventDestroy(x->ev_main);
     for (void *p : x->allocs) (void)hipFree(p);
     if (x->h_counts) (void)hipHostFree(x->h_counts);
     if (x->h_quad_part) (void)hipHostFree((void *)x->h_quad_part);

@@ -111,6 +111,9 @@ MaskRegion mask_region(const KParams &P, MaskSrc &S)
 // k_mask_prepare over the views of one call; the views' counts become known under a new sequence number
 static int prepare_masks(sl3d_ctx *x, int first_view, int n_views, const MaskSrc &S)
 {
+    // (the views' mask planes are rewritten on the context's stream: behind any launch a lane still runs over them)
+    const int jrc = sl3d_lanes_join(x);
+    if (jrc) return jrc;
     const unsigned seq = ++x->mask_seq;
     for (int v = first_view; v < first_view + n_views; v++) {
         unsigned c;
@@ -213,7 +216,7 @@ try {
     if (view_stride != 0 && view_stride < stride * (size_t)(x->cfg.full_height - 1) + (size_t)x->cfg.full_width)
         return fail(x, SL3D_E_INVALID_ARG, "masks: view_stride is smaller than one mask (0 = the same mask for every view)");
     const KParams &P = x->P;
-    ON_DEVICE(x);
+    ON_DEVICE_QUIET(x);  // (a device-resident mask that is merely recorded gives the stream nothing: the launches the lanes hold go on)
     MaskSrc S;
     const MaskRegion g = mask_region(P, S);
     int dev = -1;
@@ -231,6 +234,7 @@ try {
         rc = supersede_masks(x, first_view, n_views, 0);
         if (rc) return rc;
     } else {
+        if ((rc = sl3d_lanes_join(x))) return rc;  // (the staging plane is rewritten: behind any MASKIN launch that still reads it)
         rc = ensure_mask_staging(x, distinct);
         if (rc || (rc = supersede_masks(x, first_view, n_views, distinct))) return rc;
         for (int k = 0; k < distinct; k++) {

@@ -70,7 +70,62 @@ bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep)
     return true;
 }
 
-int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode)
+// ---- launch lanes (sl3d_ctx.h) ------------------------------------------------------------------------------------------------------
+// everything the lanes hold comes in front of whatever the context's stream is given next
+int sl3d_lanes_join(sl3d_ctx *x)
+{
+    x->main_epoch++;  // (the caller is about to enqueue on the context's stream: a later lane launch has to come behind that)
+    x->runs_in_a_row = 0;
+    if (!x->lane_busy[0] && !x->lane_busy[1]) return SL3D_OK;
+    for (int l = 0; l < 2; l++) {
+        if (!x->lane_busy[l]) continue;
+        HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_lane[l], 0));
+        x->lane_busy[l] = false;
+    }
+    std::fill(x->view_lane.begin(), x->view_lane.end(), (int8_t)-1);
+    return SL3D_OK;
+}
+
+// the lane the next small launch over views [first_view, first_view + n_views) goes to, made to wait for what it depends on: everything
+// the context's stream was given before (uploads, masks, tables), and the other lane where that one still works on one of these views
+static int lane_begin(sl3d_ctx *x, int first_view, int n_views, int *lane)
+{
+    if (!x->lane[0]) {
+        for (int l = 0; l < 2; l++) {
+            HIPCHK(x, hipStreamCreateWithFlags(&x->lane[l], hipStreamNonBlocking));
+            HIPCHK(x, hipEventCreateWithFlags(&x->ev_lane[l], hipEventDisableTiming));
+        }
+        HIPCHK(x, hipEventCreateWithFlags(&x->ev_main, hipEventDisableTiming));
+        x->view_lane.assign((size_t)x->cfg.max_views, (int8_t)-1);
+    }
+    const int l = x->next_lane, other = l ^ 1;
+    x->next_lane = other;
+    if (x->lane_epoch[l] != x->main_epoch) {
+        HIPCHK(x, hipEventRecord(x->ev_main, x->stream));
+        HIPCHK(x, hipStreamWaitEvent(x->lane[l], x->ev_main, 0));
+        x->lane_epoch[l] = x->main_epoch;
+    }
+    if (x->lane_busy[other]) {
+        for (int v = first_view; v < first_view + n_views; v++) {
+            if (x->view_lane[(size_t)v] != other) continue;
+            HIPCHK(x, hipStreamWaitEvent(x->lane[l], x->ev_lane[other], 0));  // (the other lane's work up to its last launch)
+            break;
+        }
+    }
+    *lane = l;
+    return SL3D_OK;
+}
+
+static int lane_end(sl3d_ctx *x, int lane, int first_view, int n_views)
+{
+    HIPCHK(x, hipEventRecord(x->ev_lane[lane], x->lane[lane]));
+    x->lane_busy[lane] = true;
+    for (int v = first_view; v < first_view + n_views; v++) x->view_lane[(size_t)v] = (int8_t)lane;
+    return SL3D_OK;
+}
+
+// may_overlap: the caller (sl3d_run, sl3d_run_clouds) took the QUIET form of ON_DEVICE for a small launch on a context with lanes
+int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode, bool may_overlap)
 {
     const bool prefer_gated = sparse_views(x, first_view, n_views);
     const bool maskin = maskin_launch(x, first_view, n_views, keep);
@@ -79,10 +134,24 @@ int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode)
     x->last_fused.keep = keep;
     x->last_fused.prefer_gated = prefer_gated;
     x->last_fused.maskin = maskin;
+    hipStream_t st = x->stream;
+    int lane = -1;
     if (!maskin) {
-        const int rc = flush_masks(x, first_view, n_views);
+        const unsigned epoch = x->main_epoch;
+        int rc = flush_masks(x, first_view, n_views);  // (k_mask_prepare on the context's stream: joins the lanes itself)
         if (rc) return rc;
-        return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, prefer_gated));
+        if (x->main_epoch != epoch) may_overlap = false;  // (... and the launch stays behind it on that stream: no hand-over)
+        if (may_overlap) {
+            if ((rc = lane_begin(x, first_view, n_views, &lane))) return rc;
+            st = x->lane[lane];
+        }
+        rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, st, prefer_gated));
+        return rc || lane < 0 ? rc : lane_end(x, lane, first_view, n_views);
+    }
+    if (may_overlap) {
+        const int rc = lane_begin(x, first_view, n_views, &lane);
+        if (rc) return rc;
+        st = x->lane[lane];
     }
     MaskIn mi;
     MaskSrc S;
@@ -105,7 +174,8 @@ int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode)
     mi.part = x->d_mi_part;
     mi.part_stride = x->mi_part_stride;
     mi.seq = seq & 0xffffffu;
-    return launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, x->stream, prefer_gated, &mi));
+    const int rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, st, prefer_gated, &mi));
+    return rc || lane < 0 ? rc : lane_end(x, lane, first_view, n_views);
 }
 
 extern "C" int sl3d_last_fused_kernel_name(sl3d_ctx *x, char *buf, size_t capacity)
@@ -123,8 +193,12 @@ try {
     int rc = check_view(x, first_view, n_views);
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
-    ON_DEVICE(x);
-    return run_fused(x, first_view, n_views, x->keep, 0);
+    ON_DEVICE_QUIET(x);
+    // a small launch that follows a small launch goes beside it, on a lane (sl3d_ctx.h); anything else behind everything, on the stream
+    const bool small = x->lanes_ok && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && x->runs_in_a_row > 0;
+    if (!overlap && (rc = sl3d_lanes_join(x))) return rc;
+    if (small) x->runs_in_a_row++;
+    return run_fused(x, first_view, n_views, x->keep, 0, overlap);
 }
 SL3D_CATCH(x)
 

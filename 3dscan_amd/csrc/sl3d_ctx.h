@@ -22,6 +22,21 @@ struct sl3d_ctx {
     bool own_stream = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Launch lanes (sl3d_capi_run.cpp: lane_begin / lanes_join).  A one-view launch spends ~3 of its 25 us ramping up and draining;
+    // consecutive small launches over DIFFERENT views are independent, so sl3d_run / sl3d_run_clouds put them on two internal
+    // streams in turn and the tail of one runs under the ramp of the next (one view per launch from HBM: 25.8 -> 21.8 us per launch,
+    // 0.60 -> 0.71 of the roofline).  Every other entry point first makes the context's stream wait for both lanes (ON_DEVICE), so the
+    // one-stream ordering the ABI promises holds for everything a caller can observe.  Only on a stream the context created itself.
+    bool lanes_ok = false;
+    hipStream_t lane[2] = {nullptr, nullptr};
+    hipEvent_t ev_lane[2] = {nullptr, nullptr}, ev_main = nullptr;
+    bool lane_busy[2] = {false, false};       // the lane has work the context's stream has not been made to wait for yet
+    unsigned main_epoch = 1, lane_epoch[2] = {0, 0};  // what of the context's stream a lane has already been made to wait for
+    int next_lane = 0;
+    unsigned runs_in_a_row = 0;               // small launches since the context's stream was last given anything: the FIRST goes to the
+                                              // stream itself (a launch behind an upload or a mask kernel pays no cross-stream hand-over,
+                                              // ~10 us each way); the lanes take over when launch follows launch
+    std::vector<int8_t> view_lane;            // [max_views] the lane whose (unjoined) launch last touched the view, -1: none
     std::vector<void *> allocs;
     std::string err;
     uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
@@ -151,7 +166,16 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
-#define ON_DEVICE(x)                       \
+#define ON_DEVICE_QUIET(x)                 \
     DeviceGuard dev_guard_((x)->cfg.device); \
     HIPCHK((x), dev_guard_.err)
+// ... and whatever the call enqueues on the context's stream comes behind the launches the lanes hold (sl3d_run / sl3d_run_clouds
+// and the hand-over of a device-resident deferred mask are the entry points that take the QUIET form and join only where they must)
+__attribute__((visibility("hidden"))) int sl3d_lanes_join(sl3d_ctx *x);
+#define ON_DEVICE(x)                                  \
+    ON_DEVICE_QUIET(x);                               \
+    do {                                              \
+        const int join_rc_ = sl3d_lanes_join(x);      \
+        if (join_rc_) return join_rc_;                \
+    } while (0)
 

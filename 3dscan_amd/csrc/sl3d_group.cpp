@@ -222,7 +222,8 @@ try {
         c.row0 = g->cfg.row0 + s.row0;
         c.device = s.device;
         c.stream = nullptr;
-        c.flags = cfg->flags & SL3D_FLAG_KEEP_STAGES;
+        // (a stripe's launches stay on its one stream: the group orders its communication behind them by events on that stream)
+        c.flags = (cfg->flags & SL3D_FLAG_KEEP_STAGES) | SL3D_FLAG_SERIAL_LAUNCHES;
         const int rc = sl3d_create(&c, &s.ctx);
         if (rc != SL3D_OK) return bail(rc, "stripe " + std::to_string(i) + ": " + sl3d_last_error(nullptr));
         DeviceGuard dg(s.device);

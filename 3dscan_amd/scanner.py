@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("SL3D_LIB") or os.path.join(_HERE, "libsl3d.so")
 SL3D_FLAG_KEEP_STAGES = 1
 SL3D_FLAG_GROUP_FORCE_RCCL, SL3D_FLAG_GROUP_NO_RCCL, SL3D_FLAG_GROUP_DISTINCT_SIDES = 2, 4, 16
 SL3D_FLAG_EAGER_MASK = 32
+SL3D_FLAG_SERIAL_LAUNCHES = 64
 AXIS_VERTICAL, AXIS_HORIZONTAL = 0, 1
 PATTERN_FRINGE, PATTERN_GRAY, PATTERN_INVERSE_GRAY, PATTERN_BINARY = 0, 1, 2, 3
 VALID_VERTICAL, VALID_HORIZONTAL, VALID_MERGED = 0, 1, 2
@@ -186,14 +187,15 @@ class Scanner:
 
     def __init__(self, width, height, proj_width, proj_height, n_gray_v, n_gray_h, fringe_width_v, fringe_width_h,
                  n_fringe=3, n_codes_v=0, n_codes_h=0, max_views=1, device=0, keep_stages=False,
-                 full_size=None, origin=(0, 0), stream=None, eager_mask=False):
+                 full_size=None, origin=(0, 0), stream=None, eager_mask=False, serial_launches=False):
         """eager_mask: SL3D_FLAG_EAGER_MASK -- every mask is prepared by k_mask_prepare when it is set; by default a timed context
         defers masks of up to 4 views to the next launch over them (the fused kernel evaluates the selection itself)."""
         self.L = load_library()
         fw, fh = full_size if full_size else (width, height)
         self.cfg = Config(width, height, fw, fh, origin[0], origin[1], proj_width, proj_height, n_fringe,
                           n_gray_v, n_gray_h, fringe_width_v, fringe_width_h, n_codes_v, n_codes_h,
-                          max_views, device, (SL3D_FLAG_KEEP_STAGES if keep_stages else 0) | (SL3D_FLAG_EAGER_MASK if eager_mask else 0), stream)
+                          max_views, device, (SL3D_FLAG_KEEP_STAGES if keep_stages else 0) | (SL3D_FLAG_EAGER_MASK if eager_mask else 0) |
+                          (SL3D_FLAG_SERIAL_LAUNCHES if serial_launches else 0), stream)
         self.W, self.H = width, height
         self._h = C.c_void_p()
         rc = self.L.sl3d_create(C.byref(self.cfg), C.byref(self._h))

@@ -234,15 +234,18 @@ def device_copy_rate(torch, dev, nbytes=1 << 30, reps=20):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
+def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False, serial=False):
     """The reference's real call pattern (m_tech_project_console.cpp:366-395: ONE scan per loop iteration) measured from HBM: `cold_views`
     views are resident (8 x 97.5 MB of frames + 8 x 27 MB of results: three times the 256 MiB Infinity Cache), every launch processes ONE
     view and the next launch a DIFFERENT one, round robin -- by the time a view comes round again 7 x 124 MB have gone through the cache.
-    HIP events on the kernel's stream around `launches` back-to-back launches."""
+    HIP events on the context's stream around `launches` back-to-back launches.  Since round 6 launches that follow each other overlap
+    (launch lanes, csrc/sl3d_ctx.h: two internal streams in turn, the tail of one launch under the ramp of the next): launch_us is the
+    time per launch of the SERIES -- what a pipelined caller pays per scan -- and `serial` = SL3D_FLAG_SERIAL_LAUNCHES beside it, every
+    launch on the one stream: what a LONE launch takes."""
     W, H, N, fw = args.width, args.height, args.ngray, args.fringe_width
     V = max(2, args.cold_views)
     full_mask = syn.default_mask(W, H)
-    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index) as sc:
+    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index, serial_launches=serial) as sc:
         sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
         for v in range(V):
             sc.set_mask(full_mask, view=v)
@@ -280,15 +283,21 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False):
         if tab is None:
             tab = 8 if args.rig in ("reference", "radial") else 16
         moved = alg + tab
+        if serial:
+            return {"launch_us": round(ms * 1e3, 2), "frac": round(alg * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_on_moved_bytes": round(moved * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "SL3D_FLAG_SERIAL_LAUNCHES: every launch on the context's one stream (the figure up to round 5; what a lone launch takes)"}
+        lone = {} if clouds else {"serial_launches": one_view_cold(args, scm, syn, np, dev_index, launches=launches, serial=True)}
         return {"value": round(W * H / ms / 1e3, 1), "unit": "Mpixels/s", "launch_us": round(ms * 1e3, 2), "kernel": sc.fused_kernel_name(1, clouds=clouds),
                 "frac": round(alg * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_pixel": alg,
                 "frac_on_moved_bytes": round(moved * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "moved_bytes_per_pixel": moved,
-                "resident_views": V, "launches": launches, **({"to_host": to_host} if to_host else {}),
+                "resident_views": V, "launches": launches, **({"to_host": to_host} if to_host else {}), **lone,
+                "launches_overlap": "consecutive launches run on two internal streams in turn (launch lanes): launch_us = time of the series / launches",
                 "note": f"1 view per launch, a different one of {V} resident views each launch (frames + results {V * (alg + 0) * W * H / 2**20:.0f} MiB "
                         f"> 256 MiB Infinity Cache): the frames come from HBM"}
 
 
-def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=False, eager=False, lasso=False):
+def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=False, eager=False, lasso=False, serial=False):
     """What ONE iteration of the reference's scan loop costs on the device once the frames are resident (m_tech_project_console.cpp:
     366-395): a NEW selection mask (image_scissor's result, here already in device memory: no PCIe in this figure) and ONE one-view
     launch, a different resident view and a different mask every scan (frames from HBM, as in one_view_cold).  HIP events on the
@@ -313,7 +322,7 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
         for v in range(V):
             y0, x0 = (H - mh) // 2 + 3 * v, (W - mw) // 2 + 5 * v
             masks[v, y0:y0 + mh, x0:x0 + mw] = 1
-    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index, eager_mask=eager) as sc:
+    with scm.Scanner(W, H, W, H, N, N, fw, fw, max_views=V, device=dev_index, eager_mask=eager, serial_launches=serial) as sc:
         sc.set_calibration(*rig_calibration(syn, np, args.rig, W, H, W, H))
         d_masks = torch.from_numpy(masks).to(torch.device("cuda", dev_index))
         torch.cuda.synchronize()
@@ -345,12 +354,18 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
         if lasso:
             out["selected_fraction"] = round(float(masks[0].mean()), 4)
             out["frac_note"] = "frac prices the whole frame's algorithmic bytes; a gated launch moves the planes of the selected quads only"
+        if serial:
+            out["note"] = "SL3D_FLAG_SERIAL_LAUNCHES: one launch per scan, every launch on the context's one stream (what a lone scan takes)"
+            return out
         if not eager:
             out["launches_per_scan"] = 1
             out["note"] = ("per scan: sl3d_set_masks on a device-resident mask (recorded, nothing launched) + sl3d_run" + ("_clouds" if clouds else "") +
                            " of ONE view, a different view and mask each scan: ONE kernel, which evaluates the selection (the boundary removal of "
                            "stage 3 included) itself and leaves the band / 0-1 planes and the quad count k_mask_prepare would have left; frac = the "
                            "launch's algorithmic bytes (60 B/px) over its time")
+            out["launches_overlap"] = ("consecutive scans run on two internal streams in turn (launch lanes): scan_us = time of the series / scans; "
+                                       "serial_launches = every launch on the one stream")
+            out["serial_launches"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=scans, clouds=clouds, lasso=lasso, serial=True)
             out["two_kernel_route"] = per_scan_device(args, scm, syn, np, torch, dev_index, scans=scans, clouds=clouds, eager=True, lasso=lasso)
             return out
         sc.timer_start()
