@@ -353,7 +353,7 @@ def per_scan_device(args, scm, syn, np, torch, dev_index, scans=400, clouds=Fals
                "frac": round(alg * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernel": kernel, "resident_views": V, "scans": scans}
         if lasso:
             out["selected_fraction"] = round(float(masks[0].mean()), 4)
-            out["frac_note"] = "frac prices the whole frame's algorithmic bytes; a gated launch moves the planes of the selected quads only"
+            out["frac"] = None   # (a gated launch moves the planes of the selected quads only: the frame's algorithmic bytes are not its traffic)
         if serial:
             out["note"] = "SL3D_FLAG_SERIAL_LAUNCHES: one launch per scan, every launch on the context's one stream (what a lone scan takes)"
             return out

@@ -11,7 +11,11 @@ bash tools/profile.sh c2_$TAG --width 4096 --height 3000 --fringe-width 4 --view
 python3 tools/summarize_profile.py c2_$TAG > $T/profile_c2_${TAG}_summary.log 2>&1
 cp gpurun_out/profile_c2_$TAG/stats_bench.json $T/c2_${TAG}_bench.json 2>/dev/null
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc.json profiles/${TAG}_traffic.json profiles/${TAG}_traffic_clouds.json profiles/c2_${TAG}_kernel_stats.csv profiles/c2_${TAG}_pmc.json profiles/c2_${TAG}_traffic.json profiles/c2_${TAG}_traffic_clouds.json $T/ 2>/dev/null
-# every kernel on the per-scan path: new device-resident mask + one-view launch (dense, then clouds), cold views; 1080p and 12 Mpx
+# every kernel on the per-scan path: new device-resident mask + one-view launch (dense, then clouds), cold views; 1080p and 12 Mpx.
+# The rocprofv3 passes of the one-view paths run with SL3D_NO_LAUNCH_LANES=1: a kernel's duration is then that of a LONE launch (with the
+# lanes two launches share the GPU and each one's own duration says little); the overlapped series is what bench.py's HIP events time,
+# and one pass with the lanes on (<tag>_oneview_cold_lanes) shows the overlap in the trace.
+export SL3D_NO_LAUNCH_LANES=1
 STATS_LINES=6 stats ${TAG}_per_scan python3 tools/mask_timing.py 1920 1080
 STATS_LINES=6 stats c2_${TAG}_per_scan python3 tools/mask_timing.py 4096 3000
 cp $T/${TAG}_per_scan.out $T/${TAG}_per_scan.json; cp $T/c2_${TAG}_per_scan.out $T/c2_${TAG}_per_scan.json
@@ -24,6 +28,9 @@ STATS_LINES=6 stats ${TAG}_oneview python3 tools/oneview_clouds.py
 cp $T/${TAG}_oneview.out $T/${TAG}_oneview_dense_clouds_host.txt
 STATS_LINES=4 stats ${TAG}_oneview_cold python3 bench.py --one-view-cold-only --steps 4000
 cp $T/${TAG}_oneview_cold.out $T/${TAG}_oneview_cold_under_rocprof.json
+unset SL3D_NO_LAUNCH_LANES
+STATS_LINES=4 stats ${TAG}_oneview_cold_lanes python3 bench.py --one-view-cold-only --steps 4000
+cp $T/${TAG}_oneview_cold_lanes.out $T/${TAG}_oneview_cold_lanes_under_rocprof.json
 # the 16-view launches of the other kernel families (rig classes 2 / 3 / 0, 9 and 14 Gray planes): one rocprofv3 row per side.* figure
 STATS_LINES=8 stats ${TAG}_families python3 bench.py --families-only
 cp $T/${TAG}_families.out $T/${TAG}_families.json
