@@ -53,8 +53,9 @@ try {
     if (x->keep) return fail(x, SL3D_E_STATE, "sl3d_run_clouds is the timed mode: create the context without SL3D_FLAG_KEEP_STAGES");
     ON_DEVICE_QUIET(x);
     // (a small launch goes beside the one before it, sl3d_ctx.h: launch lanes -- once the cloud buffers exist; its consumers join)
-    const bool small = x->lanes_ok && x->clouds_ready && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && x->runs_in_a_row > 0;
-    if (!overlap && (rc = sl3d_lanes_join(x))) return rc;
+    const bool small = x->lanes_ok && x->clouds_ready && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && lanes_pay(x, first_view, n_views);
+    if (!small && (rc = sl3d_lanes_join(x))) return rc;
+    if (small && !overlap && (rc = lanes_wait(x))) return rc;
     if (small) x->runs_in_a_row++;
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;

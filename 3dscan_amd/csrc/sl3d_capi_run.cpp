@@ -72,13 +72,15 @@ bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep)
 
 // ---- launch lanes (sl3d_ctx.h) ------------------------------------------------------------------------------------------------------
 // everything the lanes hold comes in front of whatever the context's stream is given next
-int sl3d_lanes_join(sl3d_ctx *x)
+int lanes_wait(sl3d_ctx *x)
 {
     x->main_epoch++;  // (the caller is about to enqueue on the context's stream: a later lane launch has to come behind that)
-    x->runs_in_a_row = 0;
     if (!x->lane_busy[0] && !x->lane_busy[1]) return SL3D_OK;
     for (int l = 0; l < 2; l++) {
         if (!x->lane_busy[l]) continue;
+        // (the lane's event is recorded HERE, once per join, not behind every launch: an event between two kernels of a stream costs
+        // the later one ~4 us -- measured on launches tied to one lane)
+        HIPCHK(x, hipEventRecord(x->ev_lane[l], x->lane[l]));
         HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_lane[l], 0));
         x->lane_busy[l] = false;
     }
@@ -86,31 +88,54 @@ int sl3d_lanes_join(sl3d_ctx *x)
     return SL3D_OK;
 }
 
+// ... and a series of small launches ends here (every entry point but sl3d_run / sl3d_run_clouds: ON_DEVICE)
+int sl3d_lanes_join(sl3d_ctx *x)
+{
+    if (x->runs_in_a_row) x->last_series = x->runs_in_a_row;
+    x->runs_in_a_row = 0;
+    return lanes_wait(x);
+}
+
 // the lane the next small launch over views [first_view, first_view + n_views) goes to, made to wait for what it depends on: everything
-// the context's stream was given before (uploads, masks, tables), and the other lane where that one still works on one of these views
+// the context's stream was given before (uploads, masks, tables), and the launches that still work on one of these views
 static int lane_begin(sl3d_ctx *x, int first_view, int n_views, int *lane)
 {
     if (!x->lane[0]) {
+        // Two launches overlap only if their streams sit on different HARDWARE queues, and the runtime spreads a process's streams over
+        // a handful of them (GPU_MAX_HW_QUEUES, 4 by default: with one queue the series ran at 25.9 us per launch instead of 21.6, and in
+        // a process with many streams -- bench.py's -- the two lanes did land on one).  Streams of another priority have their own pool
+        // of queues, which nothing else in a process normally touches: both lanes a step above the default, created back to back, get
+        // two different queues of that pool.  (One lane at the default and one above it: always different queues too, but the pair is
+        // lopsided -- 23.5 us per launch.)
+        int least = 0, greatest = 0;
+        HIPCHK(x, hipDeviceGetStreamPriorityRange(&least, &greatest));
         for (int l = 0; l < 2; l++) {
-            HIPCHK(x, hipStreamCreateWithFlags(&x->lane[l], hipStreamNonBlocking));
+            HIPCHK(x, hipStreamCreateWithPriority(&x->lane[l], hipStreamNonBlocking, greatest < 0 ? greatest : 0));
             HIPCHK(x, hipEventCreateWithFlags(&x->ev_lane[l], hipEventDisableTiming));
         }
         HIPCHK(x, hipEventCreateWithFlags(&x->ev_main, hipEventDisableTiming));
         x->view_lane.assign((size_t)x->cfg.max_views, (int8_t)-1);
     }
-    const int l = x->next_lane, other = l ^ 1;
-    x->next_lane = other;
+    // a launch over a view a lane still works on goes to THAT lane (stream order is its dependency: a wait across streams costs ~10 us,
+    // and a caller that launches the same views over and over would pay it every time); a launch free of such ties takes the lanes in turn
+    int tied = -1;
+    bool both = false;
+    for (int v = first_view; v < first_view + n_views; v++) {
+        const int t = x->view_lane[(size_t)v];
+        if (t < 0 || !x->lane_busy[t]) continue;
+        if (tied < 0) tied = t;
+        else if (tied != t) both = true;
+    }
+    const int l = tied >= 0 ? tied : x->next_lane, other = l ^ 1;
+    if (tied < 0) x->next_lane = other;
     if (x->lane_epoch[l] != x->main_epoch) {
         HIPCHK(x, hipEventRecord(x->ev_main, x->stream));
         HIPCHK(x, hipStreamWaitEvent(x->lane[l], x->ev_main, 0));
         x->lane_epoch[l] = x->main_epoch;
     }
-    if (x->lane_busy[other]) {
-        for (int v = first_view; v < first_view + n_views; v++) {
-            if (x->view_lane[(size_t)v] != other) continue;
-            HIPCHK(x, hipStreamWaitEvent(x->lane[l], x->ev_lane[other], 0));  // (the other lane's work up to its last launch)
-            break;
-        }
+    if (both) {  // views of both lanes: behind everything the other lane holds
+        HIPCHK(x, hipEventRecord(x->ev_lane[other], x->lane[other]));
+        HIPCHK(x, hipStreamWaitEvent(x->lane[l], x->ev_lane[other], 0));
     }
     *lane = l;
     return SL3D_OK;
@@ -118,10 +143,21 @@ static int lane_begin(sl3d_ctx *x, int first_view, int n_views, int *lane)
 
 static int lane_end(sl3d_ctx *x, int lane, int first_view, int n_views)
 {
-    HIPCHK(x, hipEventRecord(x->ev_lane[lane], x->lane[lane]));
     x->lane_busy[lane] = true;
     for (int v = first_view; v < first_view + n_views; v++) x->view_lane[(size_t)v] = (int8_t)lane;
     return SL3D_OK;
+}
+
+// this launch follows enough small launches for the lanes to pay (sl3d_ctx.h: runs_in_a_row)
+bool lanes_pay(sl3d_ctx *x, int first_view, int n_views)
+{
+    const bool series = x->runs_in_a_row >= SL3D_LANES_AFTER || (x->runs_in_a_row > 0 && x->last_series >= SL3D_LANES_AFTER);
+    const bool repeats = x->runs_in_a_row > 0 && x->prev_on_stream && first_view < x->prev_first + x->prev_n && x->prev_first < first_view + n_views;
+    const bool pay = series && !repeats;
+    x->prev_first = first_view;
+    x->prev_n = n_views;
+    x->prev_on_stream = !pay;
+    return pay;
 }
 
 // may_overlap: the caller (sl3d_run, sl3d_run_clouds) took the QUIET form of ON_DEVICE for a small launch on a context with lanes
@@ -195,8 +231,9 @@ try {
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE_QUIET(x);
     // a small launch that follows a small launch goes beside it, on a lane (sl3d_ctx.h); anything else behind everything, on the stream
-    const bool small = x->lanes_ok && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && x->runs_in_a_row > 0;
-    if (!overlap && (rc = sl3d_lanes_join(x))) return rc;
+    const bool small = x->lanes_ok && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && lanes_pay(x, first_view, n_views);
+    if (!small && (rc = sl3d_lanes_join(x))) return rc;             // (a large launch ends a series of small ones)
+    if (small && !overlap && (rc = lanes_wait(x))) return rc;       // (a small launch on the stream itself: behind the lanes, the series goes on)
     if (small) x->runs_in_a_row++;
     return run_fused(x, first_view, n_views, x->keep, 0, overlap);
 }

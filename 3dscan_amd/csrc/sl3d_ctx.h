@@ -11,6 +11,7 @@
 
 using namespace sl3d;
 
+#define SL3D_LANES_AFTER 8u
 struct sl3d_ctx {
     sl3d_config cfg{};
     KParams P{};
@@ -33,9 +34,14 @@ struct sl3d_ctx {
     bool lane_busy[2] = {false, false};       // the lane has work the context's stream has not been made to wait for yet
     unsigned main_epoch = 1, lane_epoch[2] = {0, 0};  // what of the context's stream a lane has already been made to wait for
     int next_lane = 0;
-    unsigned runs_in_a_row = 0;               // small launches since the context's stream was last given anything: the FIRST goes to the
-                                              // stream itself (a launch behind an upload or a mask kernel pays no cross-stream hand-over,
-                                              // ~10 us each way); the lanes take over when launch follows launch
+    // small launches since the context's stream was last given anything, and how long the series before that was.  Handing work
+    // from the stream to a lane and back costs ~10 us each way and overlapping saves ~4 us per one-view launch, so the lanes pay only
+    // in a LONG series: a launch goes to a lane when it follows SL3D_LANES_AFTER launches of this series, or follows one launch and the
+    // previous series was that long (a caller that launched forty views in a row will do so again).  The first launch behind an upload
+    // or a mask kernel always stays on the stream; a caller that waits for every scan (the reference's loop) never meets a lane.
+    unsigned runs_in_a_row = 0, last_series = 0;
+    int prev_first = 0, prev_n = 0;           // the previous small launch of the series, if it ran on the stream itself: a launch over the
+    bool prev_on_stream = false;              // same views (a caller repeating one launch) stays behind it there -- no overlap to be had
     std::vector<int8_t> view_lane;            // [max_views] the lane whose (unjoined) launch last touched the view, -1: none
     std::vector<void *> allocs;
     std::string err;

@@ -72,12 +72,12 @@ enum sl3d_flags {
      * = ONE launch, the reference's per-scan call shape), any other consumer prepares it first.  With this flag every mask is prepared
      * by its own kernel when it is set (the behaviour up to 0.4; A/B measurements). */
     SL3D_FLAG_EAGER_MASK = 32u,
-    /* A context that created its own stream (config.stream == NULL) and has no KEEP_STAGES puts consecutive sl3d_run / sl3d_run_clouds
-     * launches of at most 4 views on two internal streams in turn, so that the tail of one launch runs under the ramp of the next when
-     * they work on different views (a launch over a view waits for the previous launch over that view); every other call first makes
-     * the context's stream wait for both, so nothing a caller can observe changes -- only the time: one view per launch from HBM,
-     * back to back, 25.8 -> 21.8 us per launch.  With this flag every launch goes to the context's one stream (the behaviour up to
-     * 0.5; A/B measurements, and the time of a LONE launch). */
+    /* A context that created its own stream (config.stream == NULL) and has no KEEP_STAGES puts the sl3d_run / sl3d_run_clouds launches
+     * of a LONG series of launches of at most 4 views (8 in a row, or fewer if the previous series was that long) on two internal
+     * streams in turn, so that the tail of one launch runs under the ramp of the next when they work on different views (a launch over
+     * a view a lane still works on goes behind it); every other call first makes the context's stream wait for both, so nothing a
+     * caller can observe changes -- only the time: one view per launch from HBM, back to back, 25.8 -> 21.8 us per launch.  With this
+     * flag every launch goes to the context's one stream (the behaviour up to 0.5; A/B measurements, and the time of a LONE launch). */
     SL3D_FLAG_SERIAL_LAUNCHES = 64u
     /* (8u was SL3D_FLAG_CLOUDS_LOOKBACK until 0.3: contiguous clouds in one pass by a decoupled look-back between tiles.  Removed
      * in 0.4 -- every tile waited for its predecessors, 0.53 of the roofline against 0.67 for the segmented clouds; a consumer
