@@ -172,6 +172,11 @@ int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode, bo
     x->last_fused.maskin = maskin;
     hipStream_t st = x->stream;
     int lane = -1;
+    struct Count {  // (where the launch went, whichever return below is taken)
+        sl3d_ctx *x;
+        const int &lane;
+        ~Count() { (lane < 0 ? x->launches_on_stream : x->launches_on_lanes)++; }
+    } count{x, lane};
     if (!maskin) {
         const unsigned epoch = x->main_epoch;
         int rc = flush_masks(x, first_view, n_views);  // (k_mask_prepare on the context's stream: joins the lanes itself)
@@ -212,6 +217,14 @@ int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode, bo
     mi.seq = seq & 0xffffffu;
     const int rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, st, prefer_gated, &mi));
     return rc || lane < 0 ? rc : lane_end(x, lane, first_view, n_views);
+}
+
+extern "C" int sl3d_launch_counts(sl3d_ctx *x, int64_t *on_stream, int64_t *on_lanes)
+{
+    if (!x) return SL3D_E_INVALID_ARG;
+    if (on_stream) *on_stream = x->launches_on_stream;
+    if (on_lanes) *on_lanes = x->launches_on_lanes;
+    return SL3D_OK;
 }
 
 extern "C" int sl3d_last_fused_kernel_name(sl3d_ctx *x, char *buf, size_t capacity)

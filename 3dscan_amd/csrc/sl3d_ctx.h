@@ -40,6 +40,7 @@ struct sl3d_ctx {
     // previous series was that long (a caller that launched forty views in a row will do so again).  The first launch behind an upload
     // or a mask kernel always stays on the stream; a caller that waits for every scan (the reference's loop) never meets a lane.
     unsigned runs_in_a_row = 0, last_series = 0;
+    long long launches_on_stream = 0, launches_on_lanes = 0;  // sl3d_launch_counts
     int prev_first = 0, prev_n = 0;           // the previous small launch of the series, if it ran on the stream itself: a launch over the
     bool prev_on_stream = false;              // same views (a caller repeating one launch) stays behind it there -- no overlap to be had
     std::vector<int8_t> view_lane;            // [max_views] the lane whose (unjoined) launch last touched the view, -1: none

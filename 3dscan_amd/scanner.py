@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "sl3d_version", "sl3d_strerror", "sl3d_last_error", "sl3d_create", "sl3d_destroy",
     "sl3d_set_calibration", "sl3d_get_projection_matrices", "sl3d_set_mask", "sl3d_set_masks", "sl3d_set_mask_colrow", "sl3d_set_frames_range", "sl3d_get_global_colrow", "sl3d_set_frames", "sl3d_copy_view", "sl3d_synth_view", "sl3d_get_frames",
     "sl3d_compute_wrapped_phase", "sl3d_unwrap_phase", "sl3d_compute_c_p_map", "sl3d_triangulate",
-    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_last_fused_kernel_name", "sl3d_camera_table_bytes_per_pixel", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
+    "sl3d_run", "sl3d_run_clouds", "sl3d_get_cloud_counts", "sl3d_get_cloud_segments", "sl3d_download_clouds", "sl3d_register_clouds", "sl3d_fused_kernel_name", "sl3d_last_fused_kernel_name", "sl3d_launch_counts", "sl3d_camera_table_bytes_per_pixel", "sl3d_run_timed", "sl3d_synchronize", "sl3d_timer_start", "sl3d_timer_stop",
     "sl3d_get_valid_map", "sl3d_get_wrapped_phase", "sl3d_get_unwrapped_phase", "sl3d_get_code",
     "sl3d_get_debug_image", "sl3d_get_c_p_map", "sl3d_get_intersection_points", "sl3d_get_points",
     "sl3d_get_cloud", "sl3d_set_texture", "sl3d_get_cloud_rgb", "sl3d_compact", "sl3d_compact_views", "sl3d_get_clouds", "sl3d_register_views", "sl3d_transform_cloud", "sl3d_host_alloc", "sl3d_host_free", "sl3d_process_views", "sl3d_undistort", "sl3d_set_frames_raw", "sl3d_pattern_counts", "sl3d_generate_pattern",
@@ -428,6 +428,13 @@ class Scanner:
         if n < 0:
             self._chk(n, "sl3d_camera_table_bytes_per_pixel")
         return n
+
+    def launch_counts(self):
+        """(fused launches that went to the context's stream, ... to its launch lanes)"""
+        a, b = C.c_int64(), C.c_int64()
+        self.L.sl3d_launch_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self._chk(self.L.sl3d_launch_counts(self._h, C.byref(a), C.byref(b)), "sl3d_launch_counts")
+        return a.value, b.value
 
     def last_fused_kernel_name(self):
         """The k_fused instantiation the last fused launch of this context ran."""

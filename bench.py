@@ -261,6 +261,7 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False, se
         for i in range(launches):
             run(i % V)
         ms = sc.timer_stop() / launches
+        on_lanes = sc.launch_counts()[1]
         to_host = None
         if clouds:
             # the consumer the reference has (8/save_point_cloud.cpp:85-104 fills a HOST cloud per scan): launch + the cloud in pinned
@@ -293,6 +294,7 @@ def one_view_cold(args, scm, syn, np, dev_index, launches=2000, clouds=False, se
                 "frac_on_moved_bytes": round(moved * W * H / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "moved_bytes_per_pixel": moved,
                 "resident_views": V, "launches": launches, **({"to_host": to_host} if to_host else {}), **lone,
                 "launches_overlap": "consecutive launches run on two internal streams in turn (launch lanes): launch_us = time of the series / launches",
+                "launches_on_lanes": on_lanes,
                 "note": f"1 view per launch, a different one of {V} resident views each launch (frames + results {V * (alg + 0) * W * H / 2**20:.0f} MiB "
                         f"> 256 MiB Infinity Cache): the frames come from HBM"}
 

@@ -278,6 +278,9 @@ int sl3d_fused_kernel_name(sl3d_ctx *ctx, int n_views, int clouds, char *buf, si
  * last count of that view that did arrive decides), so a later prediction could name a different one.  The choice never changes a
  * bit of the results. */
 int sl3d_last_fused_kernel_name(sl3d_ctx *ctx, char *buf, size_t capacity);
+/* How many fused launches of this context went to the context's stream and how many to its launch lanes (SL3D_FLAG_SERIAL_LAUNCHES):
+ * what a benchmark or a test states beside a per-launch time of a series.  Either pointer may be NULL.  Touches nothing on the device. */
+int sl3d_launch_counts(sl3d_ctx *ctx, int64_t *on_stream, int64_t *on_lanes);
 /* Bytes per camera pixel a fused launch of n_views views reads from the camera-side table of sl3d_set_calibration (T1 per window pixel,
  * 7/triangulation.cpp:252-307), once per LAUNCH whatever the number of views: 0 = no table (no camera distortion, parity mode),
  * 8 = the radial factor as a double, 16 = the normalised point (tangential terms).  Benchmarks state the bytes a launch moves beside

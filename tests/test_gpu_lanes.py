@@ -1,5 +1,6 @@
 """GPU tests (-m gpu): launch lanes (3dscan_amd/csrc/sl3d_ctx.h).  A context that owns its stream puts consecutive small launches on two
-internal streams in turn, so that the tail of one launch runs under the ramp of the next; every other call joins them first.  Nothing a
+internal streams in turn once a series of them is long enough to pay, so that the tail of one launch runs under the ramp of the next;
+every other call joins them first (sl3d_launch_counts tells where the launches went).  Nothing a
 caller can observe may differ from a context with SL3D_FLAG_SERIAL_LAUNCHES: every sequence below runs on both and is compared bit for
 bit -- independent views back to back, the same view over and over, launches whose views overlap, uploads and new masks between launches
 (the lane has to wait for what the context's stream was given), the per-scan loop with device-resident deferred masks (MASKIN launches),
@@ -50,11 +51,18 @@ def test_overlapping_small_launches_equal_serial_ones():
             for v in range(V):
                 _same(lanes.points(v), serial.points(v), (tag, v))
 
-        # independent views back to back, nothing waited for in between
+        # independent views back to back, nothing waited for in between: the lanes take over once the series is 8 launches long
         both(lambda c: [c.run(i % V, 1) for i in range(30)])
+        assert lanes.launch_counts() == (8, 22) and serial.launch_counts() == (30, 0)
         check("independent views")
-        # the same view over and over, and launches whose views overlap (a lane waits for the other where it must)
+        # ... and from its second launch on when the series before was that long
+        both(lambda c: [c.run(i % V, 1) for i in range(10)])
+        assert lanes.launch_counts() == (9, 31)
+        check("a second series")
+        # the same view over and over (stays on the stream: nothing to overlap), and launches whose views overlap (tied to a lane)
+        n0 = lanes.launch_counts()
         both(lambda c: [c.run(2, 1) for _ in range(6)])
+        assert lanes.launch_counts() == (n0[0] + 6, n0[1])
         both(lambda c: [c.run(f, n) for f, n in ((0, 2), (1, 2), (2, 3), (4, 2), (3, 1), (0, 4), (3, 3), (5, 1), (0, 1))])
         check("overlapping views")
         # uploads between launches: view v gets the frames of view v + 1 and is launched at once -- the lane must see the upload
@@ -71,7 +79,11 @@ def test_overlapping_small_launches_equal_serial_ones():
             for i in range(36):
                 c.set_masks_device(d_masks.data_ptr() + ((i * 5 + 1) % V) * W * H, W, 0, i % V, 1)
                 c.run(i % V, 1)
+        n0 = lanes.launch_counts()
         both(scans)
+        # (a recorded device-resident mask does not end the series; the series before this one were single launches behind uploads, so
+        # the lanes take over at the ninth launch again)
+        assert lanes.launch_counts() == (n0[0] + 8, n0[1] + 28)
         assert ", 4, " in lanes.last_fused_kernel_name() and ", 4, " in serial.last_fused_kernel_name()
         check("per-scan loop")
         for v in range(V):
@@ -85,7 +97,9 @@ def test_overlapping_small_launches_equal_serial_ones():
             for i in range(12):
                 c.set_mask(masks[(i * 5 + 2) % V], view=i % V)
                 c.run(i % V, 1)
+        n0 = lanes.launch_counts()
         both(host_masks)
+        assert lanes.launch_counts() == (n0[0] + 12, n0[1])           # (every launch behind a copy on the stream: stays there)
         check("host masks between launches")
         # clouds: small launches side by side, then their consumers
         both(lambda c: [c.run_clouds(i % V, 1) for i in range(12)])
@@ -124,5 +138,6 @@ def test_lanes_are_off_where_the_stream_is_not_the_contexts_own():
         ev = torch.cuda.Event()
         ev.record(st)            # the caller's own ordering: behind everything sl3d_run gave ITS stream
         ev.synchronize()
+        assert sc.launch_counts()[1] == 0
         for v in range(V):
             _same(sc.points(v), ref.points(v), v)
