@@ -22,7 +22,7 @@ def main():
     # FUZZ_MAXW / FUZZ_MAXH: larger frames (thousands of 1024-pixel tiles per view: long look-back chains of the fused compaction)
     MAXW, MAXH = int(os.environ.get("FUZZ_MAXW", 400)), int(os.environ.get("FUZZ_MAXH", 200))
     bad = 0
-    maskin_cases = [0, 0]
+    maskin_cases = [0, 0, 0]
     for case in range(cases):
         fullW, fullH = int(rng.integers(5, MAXW)), int(rng.integers(5, MAXH))
         if rng.random() < 0.5:
@@ -171,7 +171,7 @@ def main():
         if not msg:
             V = int(rng.integers(1, 5))
             kw = dict(n_fringe=F, max_views=V, full_size=(fullW, fullH), origin=(col0, row0))
-            with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, **kw) as sc, S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, eager_mask=True, **kw) as eg:
+            with S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, **kw) as sc, S.Scanner(W, H, PW, PH, Nv, Nh, fwv, fwh, eager_mask=True, serial_launches=True, **kw) as eg:
                 masks = []
                 for v in range(V):
                     m = (rng.random((fullH, fullW)) < rng.choice([0.7, 0.95, 1.0])).astype(np.uint8)
@@ -204,6 +204,18 @@ def main():
                     sc._d2h(pa, ba.mask + v * ba.mask_view_stride); eg._d2h(pb, bb.mask + v * bb.mask_view_stride)
                     if not np.array_equal(pa, pb):
                         msg.append(f"deferred masks, {V} views ({names}): the 0/1 plane of view {v} differs")
+                # ... and a series of one-view launches over these views, nothing waited for in between: from the ninth launch on they run on
+                # the launch lanes (two internal streams in turn); the eager context keeps every launch on its one stream
+                if V > 1 and not msg:
+                    for x in (sc, eg):
+                        for i in range(20):
+                            x.run(i % V, 1)
+                    if sc.launch_counts()[1] > 0:
+                        maskin_cases[2] += 1
+                    for v in range(V):
+                        a_, b_ = sc.points(v), eg.points(v)
+                        if not (np.array_equal(a_[1], b_[1]) and np.array_equal(a_[0], b_[0], equal_nan=True)):
+                            msg.append(f"a series of one-view launches on the lanes ({V} views): view {v} differs from the serial context")
                 if any(t in names for t in (", 4, false, true>", ", 6, false, true>")):
                     maskin_cases[0] += 1
                 if any(t in names for t in (", 4, true, false>", ", 6, true, false>")):
@@ -213,7 +225,7 @@ def main():
             bad += 1
             print("FAIL", tag, msg, flush=True)
         del o
-    print(f"{cases} cases, {bad} failures; MASKIN launches: {maskin_cases[0]} early-request, {maskin_cases[1]} gated")
+    print(f"{cases} cases, {bad} failures; MASKIN launches: {maskin_cases[0]} early-request, {maskin_cases[1]} gated; series on the launch lanes: {maskin_cases[2]}")
     return 1 if bad else 0
 
 if __name__ == "__main__":
