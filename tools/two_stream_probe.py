@@ -1,5 +1,6 @@
-"""Probe: do one-view launches of two contexts on two HIP streams overlap their ramp / tail?  Per-launch average of alternating launches on
-two streams against the same number of launches on one stream (8 resident views each, frames from HBM).   usage: two_stream_probe.py"""
+"""Probe: do launches of two contexts on two HIP streams overlap their ramp / tail?  Per-launch average of alternating launches on two streams
+against the same number of launches on one stream (resident views round robin, frames from HBM), for 1 / 2 / 4 / 16 views per launch.
+usage: two_stream_probe.py"""
 import importlib
 import os
 import sys
@@ -12,7 +13,7 @@ import torch
 
 scm = importlib.import_module("3dscan_amd.scanner")
 syn = importlib.import_module("3dscan_amd.synth")
-W, H, N, fw, V = 1920, 1080, 10, 2, 8
+W, H, N, fw, V = 1920, 1080, 10, 2, 16
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 ctxs = []
 for s in streams:
@@ -25,16 +26,20 @@ for s in streams:
     ctxs.append(sc)
 
 
-def loop(n, two):
+def loop(n, two, k):
+    groups = V // k
     for i in range(n):
-        ctxs[i & 1 if two else 0].run((i // 2) % V if two else i % V, 1)
+        c = ctxs[i & 1 if two else 0]
+        c.run((((i // 2) if two else i) % groups) * k, k)
 
 
-for two in (False, True, False, True):
-    loop(2000, two)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loop(4000, two)
-    torch.cuda.synchronize()
-    us = (time.perf_counter() - t0) / 4000 * 1e6
-    print(("two streams" if two else "one stream "), f"{us:.2f} us per one-view launch (wall clock over 4000 launches)")
+for k in (1, 2, 4, 16):
+    n = 4000 // k
+    for two in (False, True, False, True):
+        loop(n // 2, two, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(n, two, k)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / n * 1e6
+        print(f"{k:2d} view(s) per launch,", ("two streams" if two else "one stream "), f"{us:.2f} us per launch = {us / k:.2f} per view")
