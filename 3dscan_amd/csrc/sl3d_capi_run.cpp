@@ -100,7 +100,7 @@ int sl3d_lanes_join(sl3d_ctx *x)
 // the context's stream was given before (uploads, masks, tables), and the launches that still work on one of these views
 static int lane_begin(sl3d_ctx *x, int first_view, int n_views, int *lane)
 {
-    if (!x->lane[0]) {
+    if (!x->ev_main) {  // (ev_main is created last: a creation that failed half way is taken up where it stopped)
         // Two launches overlap only if their streams sit on different HARDWARE queues, and the runtime spreads a process's streams over
         // a handful of them (GPU_MAX_HW_QUEUES, 4 by default: with one queue the series ran at 25.9 us per launch instead of 21.6, and in
         // a process with many streams -- bench.py's -- the two lanes did land on one).  Streams of another priority have their own pool
@@ -110,11 +110,11 @@ static int lane_begin(sl3d_ctx *x, int first_view, int n_views, int *lane)
         int least = 0, greatest = 0;
         HIPCHK(x, hipDeviceGetStreamPriorityRange(&least, &greatest));
         for (int l = 0; l < 2; l++) {
-            HIPCHK(x, hipStreamCreateWithPriority(&x->lane[l], hipStreamNonBlocking, greatest < 0 ? greatest : 0));
-            HIPCHK(x, hipEventCreateWithFlags(&x->ev_lane[l], hipEventDisableTiming));
+            if (!x->lane[l]) HIPCHK(x, hipStreamCreateWithPriority(&x->lane[l], hipStreamNonBlocking, greatest < 0 ? greatest : 0));
+            if (!x->ev_lane[l]) HIPCHK(x, hipEventCreateWithFlags(&x->ev_lane[l], hipEventDisableTiming));
         }
-        HIPCHK(x, hipEventCreateWithFlags(&x->ev_main, hipEventDisableTiming));
         x->view_lane.assign((size_t)x->cfg.max_views, (int8_t)-1);
+        HIPCHK(x, hipEventCreateWithFlags(&x->ev_main, hipEventDisableTiming));
     }
     // a launch over a view a lane still works on goes to THAT lane (stream order is its dependency: a wait across streams costs ~10 us,
     // and a caller that launches the same views over and over would pay it every time); a launch free of such ties takes the lanes in turn
