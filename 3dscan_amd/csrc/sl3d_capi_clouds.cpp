@@ -53,10 +53,10 @@ try {
     if (x->keep) return fail(x, SL3D_E_STATE, "sl3d_run_clouds is the timed mode: create the context without SL3D_FLAG_KEEP_STAGES");
     ON_DEVICE_QUIET(x);
     // (a small launch goes beside the one before it, sl3d_ctx.h: launch lanes -- once the cloud buffers exist; its consumers join)
-    const bool small = x->lanes_ok && x->clouds_ready && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && lanes_pay(x, first_view, n_views);
-    if (!small && (rc = sl3d_lanes_join(x))) return rc;
-    if (small && !overlap && (rc = lanes_wait(x))) return rc;
-    if (small) x->runs_in_a_row++;
+    bool overlap = false;
+    if (x->lanes_ok && x->clouds_ready && n_views <= SL3D_SMALL_LAUNCH_VIEWS) rc = small_launch_overlaps(x, first_view, n_views, &overlap);
+    else rc = sl3d_lanes_join(x);
+    if (rc) return rc;
     rc = ensure_cloud_buffers(x);
     if (rc) return rc;
     rc = run_fused(x, first_view, n_views, false, 2, overlap);

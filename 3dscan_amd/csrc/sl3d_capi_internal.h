@@ -63,6 +63,5 @@ SL3D_INTERNAL int sync_for_caller(sl3d_ctx *x);
 
 // every fused launch of the library (sl3d_capi_run.cpp)
 SL3D_INTERNAL bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep);
-SL3D_INTERNAL bool lanes_pay(sl3d_ctx *x, int first_view, int n_views);
-SL3D_INTERNAL int lanes_wait(sl3d_ctx *x);
+SL3D_INTERNAL int small_launch_overlaps(sl3d_ctx *x, int first_view, int n_views, bool *overlap);
 SL3D_INTERNAL int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode, bool may_overlap = false);

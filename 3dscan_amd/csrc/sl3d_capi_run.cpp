@@ -70,29 +70,25 @@ bool maskin_launch(const sl3d_ctx *x, int first_view, int n_views, bool keep)
     return true;
 }
 
-// ---- launch lanes (sl3d_ctx.h) ------------------------------------------------------------------------------------------------------
+// ---- launch lanes (sl3d_lanes.h: the policy; here its plans become events and waits) -------------------------------------------------
 // everything the lanes hold comes in front of whatever the context's stream is given next
 int lanes_wait(sl3d_ctx *x)
 {
-    x->main_epoch++;  // (the caller is about to enqueue on the context's stream: a later lane launch has to come behind that)
-    if (!x->lane_busy[0] && !x->lane_busy[1]) return SL3D_OK;
+    const unsigned busy = x->lp.stream_gets_work();
     for (int l = 0; l < 2; l++) {
-        if (!x->lane_busy[l]) continue;
+        if (!(busy >> l & 1u)) continue;
         // (the lane's event is recorded HERE, once per join, not behind every launch: an event between two kernels of a stream costs
         // the later one ~4 us -- measured on launches tied to one lane)
         HIPCHK(x, hipEventRecord(x->ev_lane[l], x->lane[l]));
         HIPCHK(x, hipStreamWaitEvent(x->stream, x->ev_lane[l], 0));
-        x->lane_busy[l] = false;
     }
-    std::fill(x->view_lane.begin(), x->view_lane.end(), (int8_t)-1);
     return SL3D_OK;
 }
 
 // ... and a series of small launches ends here (every entry point but sl3d_run / sl3d_run_clouds: ON_DEVICE)
 int sl3d_lanes_join(sl3d_ctx *x)
 {
-    if (x->runs_in_a_row) x->last_series = x->runs_in_a_row;
-    x->runs_in_a_row = 0;
+    x->lp.series_ends();
     return lanes_wait(x);
 }
 
@@ -113,51 +109,28 @@ static int lane_begin(sl3d_ctx *x, int first_view, int n_views, int *lane)
             if (!x->lane[l]) HIPCHK(x, hipStreamCreateWithPriority(&x->lane[l], hipStreamNonBlocking, greatest < 0 ? greatest : 0));
             if (!x->ev_lane[l]) HIPCHK(x, hipEventCreateWithFlags(&x->ev_lane[l], hipEventDisableTiming));
         }
-        x->view_lane.assign((size_t)x->cfg.max_views, (int8_t)-1);
+        x->lp.reset(x->cfg.max_views);
         HIPCHK(x, hipEventCreateWithFlags(&x->ev_main, hipEventDisableTiming));
     }
-    // a launch over a view a lane still works on goes to THAT lane (stream order is its dependency: a wait across streams costs ~10 us,
-    // and a caller that launches the same views over and over would pay it every time); a launch free of such ties takes the lanes in turn
-    int tied = -1;
-    bool both = false;
-    for (int v = first_view; v < first_view + n_views; v++) {
-        const int t = x->view_lane[(size_t)v];
-        if (t < 0 || !x->lane_busy[t]) continue;
-        if (tied < 0) tied = t;
-        else if (tied != t) both = true;
-    }
-    const int l = tied >= 0 ? tied : x->next_lane, other = l ^ 1;
-    if (tied < 0) x->next_lane = other;
-    if (x->lane_epoch[l] != x->main_epoch) {
+    const LanePlan p = x->lp.begin(first_view, n_views);
+    if (p.wait_main) {
         HIPCHK(x, hipEventRecord(x->ev_main, x->stream));
-        HIPCHK(x, hipStreamWaitEvent(x->lane[l], x->ev_main, 0));
-        x->lane_epoch[l] = x->main_epoch;
+        HIPCHK(x, hipStreamWaitEvent(x->lane[p.lane], x->ev_main, 0));
     }
-    if (both) {  // views of both lanes: behind everything the other lane holds
-        HIPCHK(x, hipEventRecord(x->ev_lane[other], x->lane[other]));
-        HIPCHK(x, hipStreamWaitEvent(x->lane[l], x->ev_lane[other], 0));
+    if (p.wait_other) {  // views of both lanes: behind everything the other lane holds
+        HIPCHK(x, hipEventRecord(x->ev_lane[p.lane ^ 1], x->lane[p.lane ^ 1]));
+        HIPCHK(x, hipStreamWaitEvent(x->lane[p.lane], x->ev_lane[p.lane ^ 1], 0));
     }
-    *lane = l;
+    *lane = p.lane;
     return SL3D_OK;
 }
 
-static int lane_end(sl3d_ctx *x, int lane, int first_view, int n_views)
+// a small launch of a context with lanes: does it go beside the one before it?  If not it goes to the stream itself, behind the lanes
+// (the series goes on).  Shared by sl3d_run and sl3d_run_clouds.
+int small_launch_overlaps(sl3d_ctx *x, int first_view, int n_views, bool *overlap)
 {
-    x->lane_busy[lane] = true;
-    for (int v = first_view; v < first_view + n_views; v++) x->view_lane[(size_t)v] = (int8_t)lane;
-    return SL3D_OK;
-}
-
-// this launch follows enough small launches for the lanes to pay (sl3d_ctx.h: runs_in_a_row)
-bool lanes_pay(sl3d_ctx *x, int first_view, int n_views)
-{
-    const bool series = x->runs_in_a_row >= SL3D_LANES_AFTER || (x->runs_in_a_row > 0 && x->last_series >= SL3D_LANES_AFTER);
-    const bool repeats = x->runs_in_a_row > 0 && x->prev_on_stream && first_view < x->prev_first + x->prev_n && x->prev_first < first_view + n_views;
-    const bool pay = series && !repeats;
-    x->prev_first = first_view;
-    x->prev_n = n_views;
-    x->prev_on_stream = !pay;
-    return pay;
+    *overlap = x->lp.small_launch_pays(first_view, n_views);
+    return *overlap ? SL3D_OK : lanes_wait(x);
 }
 
 // may_overlap: the caller (sl3d_run, sl3d_run_clouds) took the QUIET form of ON_DEVICE for a small launch on a context with lanes
@@ -178,16 +151,17 @@ int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode, bo
         ~Count() { (lane < 0 ? x->launches_on_stream : x->launches_on_lanes)++; }
     } count{x, lane};
     if (!maskin) {
-        const unsigned epoch = x->main_epoch;
+        const unsigned epoch = x->lp.main_epoch;
         int rc = flush_masks(x, first_view, n_views);  // (k_mask_prepare on the context's stream: joins the lanes itself)
         if (rc) return rc;
-        if (x->main_epoch != epoch) may_overlap = false;  // (... and the launch stays behind it on that stream: no hand-over)
+        if (x->lp.main_epoch != epoch) may_overlap = false;  // (... and the launch stays behind it on that stream: no hand-over)
         if (may_overlap) {
             if ((rc = lane_begin(x, first_view, n_views, &lane))) return rc;
             st = x->lane[lane];
         }
         rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, st, prefer_gated));
-        return rc || lane < 0 ? rc : lane_end(x, lane, first_view, n_views);
+        if (!rc && lane >= 0) x->lp.end(lane, first_view, n_views);
+        return rc;
     }
     if (may_overlap) {
         const int rc = lane_begin(x, first_view, n_views, &lane);
@@ -216,7 +190,8 @@ int run_fused(sl3d_ctx *x, int first_view, int n_views, bool keep, int cmode, bo
     mi.part_stride = x->mi_part_stride;
     mi.seq = seq & 0xffffffu;
     const int rc = launched(x, launch_fused(x->P, x->d_cal, x->rig, first_view, n_views, keep, cmode, st, prefer_gated, &mi));
-    return rc || lane < 0 ? rc : lane_end(x, lane, first_view, n_views);
+    if (!rc && lane >= 0) x->lp.end(lane, first_view, n_views);
+    return rc;
 }
 
 extern "C" int sl3d_launch_counts(sl3d_ctx *x, int64_t *on_stream, int64_t *on_lanes)
@@ -243,11 +218,11 @@ try {
     if (rc) return rc;
     if (!x->have_cal) return fail(x, SL3D_E_STATE, "sl3d_set_calibration has not been called");
     ON_DEVICE_QUIET(x);
-    // a small launch that follows a small launch goes beside it, on a lane (sl3d_ctx.h); anything else behind everything, on the stream
-    const bool small = x->lanes_ok && n_views <= SL3D_SMALL_LAUNCH_VIEWS, overlap = small && lanes_pay(x, first_view, n_views);
-    if (!small && (rc = sl3d_lanes_join(x))) return rc;             // (a large launch ends a series of small ones)
-    if (small && !overlap && (rc = lanes_wait(x))) return rc;       // (a small launch on the stream itself: behind the lanes, the series goes on)
-    if (small) x->runs_in_a_row++;
+    // a small launch of a long series goes beside the one before it, on a lane (sl3d_lanes.h); anything else behind everything, on the stream
+    bool overlap = false;
+    if (x->lanes_ok && n_views <= SL3D_SMALL_LAUNCH_VIEWS) rc = small_launch_overlaps(x, first_view, n_views, &overlap);
+    else rc = sl3d_lanes_join(x);  // (a large launch ends a series of small ones)
+    if (rc) return rc;
     return run_fused(x, first_view, n_views, x->keep, 0, overlap);
 }
 SL3D_CATCH(x)

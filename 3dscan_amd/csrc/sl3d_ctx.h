@@ -8,10 +8,10 @@
 
 #include "../../include/sl3d.h"
 #include "sl3d_internal.h"
+#include "sl3d_lanes.h"
 
 using namespace sl3d;
 
-#define SL3D_LANES_AFTER 8u
 struct sl3d_ctx {
     sl3d_config cfg{};
     KParams P{};
@@ -23,27 +23,15 @@ struct sl3d_ctx {
     bool own_stream = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // Launch lanes (sl3d_capi_run.cpp: lane_begin / lanes_join).  A one-view launch spends ~3 of its 25 us ramping up and draining;
-    // consecutive small launches over DIFFERENT views are independent, so sl3d_run / sl3d_run_clouds put them on two internal
-    // streams in turn and the tail of one runs under the ramp of the next (one view per launch from HBM: 25.8 -> 21.8 us per launch,
-    // 0.60 -> 0.71 of the roofline).  Every other entry point first makes the context's stream wait for both lanes (ON_DEVICE), so the
-    // one-stream ordering the ABI promises holds for everything a caller can observe.  Only on a stream the context created itself.
+    // Launch lanes (sl3d_lanes.h: the policy; sl3d_capi_run.cpp turns its plans into events and waits): consecutive small launches of a
+    // LONG series run on two internal streams in turn, the tail of one under the ramp of the next.  Every other entry point first makes
+    // the context's stream wait for both lanes (ON_DEVICE), so the one-stream ordering the ABI promises holds for everything a caller
+    // can observe.  Only on a stream the context created itself.
     bool lanes_ok = false;
     hipStream_t lane[2] = {nullptr, nullptr};
     hipEvent_t ev_lane[2] = {nullptr, nullptr}, ev_main = nullptr;
-    bool lane_busy[2] = {false, false};       // the lane has work the context's stream has not been made to wait for yet
-    unsigned main_epoch = 1, lane_epoch[2] = {0, 0};  // what of the context's stream a lane has already been made to wait for
-    int next_lane = 0;
-    // small launches since the context's stream was last given anything, and how long the series before that was.  Handing work
-    // from the stream to a lane and back costs ~10 us each way and overlapping saves ~4 us per one-view launch, so the lanes pay only
-    // in a LONG series: a launch goes to a lane when it follows SL3D_LANES_AFTER launches of this series, or follows one launch and the
-    // previous series was that long (a caller that launched forty views in a row will do so again).  The first launch behind an upload
-    // or a mask kernel always stays on the stream; a caller that waits for every scan (the reference's loop) never meets a lane.
-    unsigned runs_in_a_row = 0, last_series = 0;
+    LanePolicy lp;
     long long launches_on_stream = 0, launches_on_lanes = 0;  // sl3d_launch_counts
-    int prev_first = 0, prev_n = 0;           // the previous small launch of the series, if it ran on the stream itself: a launch over the
-    bool prev_on_stream = false;              // same views (a caller repeating one launch) stays behind it there -- no overlap to be had
-    std::vector<int8_t> view_lane;            // [max_views] the lane whose (unjoined) launch last touched the view, -1: none
     std::vector<void *> allocs;
     std::string err;
     uint8_t *d_frames = nullptr, *d_mask = nullptr, *d_valid = nullptr, *d_band = nullptr;
