@@ -54,7 +54,7 @@ try {
     ON_DEVICE_QUIET(x);
     // (a small launch goes beside the one before it, sl3d_ctx.h: launch lanes -- once the cloud buffers exist; its consumers join)
     bool overlap = false;
-    if (x->lanes_ok && x->clouds_ready && n_views <= SL3D_SMALL_LAUNCH_VIEWS) rc = small_launch_overlaps(x, first_view, n_views, &overlap);
+    if (x->lanes_ok && x->clouds_ready && n_views <= LanePolicy::MAX_VIEWS) rc = small_launch_overlaps(x, first_view, n_views, &overlap);
     else rc = sl3d_lanes_join(x);
     if (rc) return rc;
     rc = ensure_cloud_buffers(x);

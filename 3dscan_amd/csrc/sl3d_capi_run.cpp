@@ -220,7 +220,7 @@ try {
     ON_DEVICE_QUIET(x);
     // a small launch of a long series goes beside the one before it, on a lane (sl3d_lanes.h); anything else behind everything, on the stream
     bool overlap = false;
-    if (x->lanes_ok && n_views <= SL3D_SMALL_LAUNCH_VIEWS) rc = small_launch_overlaps(x, first_view, n_views, &overlap);
+    if (x->lanes_ok && n_views <= LanePolicy::MAX_VIEWS) rc = small_launch_overlaps(x, first_view, n_views, &overlap);
     else rc = sl3d_lanes_join(x);  // (a large launch ends a series of small ones)
     if (rc) return rc;
     return run_fused(x, first_view, n_views, x->keep, 0, overlap);

@@ -30,6 +30,9 @@ struct LanePlan {
 
 struct LanePolicy {
     static constexpr unsigned LANES_AFTER = 8u;
+    // what overlapping buys shrinks with the launch (tools/two_stream_probe.py: 1 view per launch -12.6 %, 2 views -4.4 %, 4 views -1.4 %,
+    // i.e. 3.1 / 2.0 / 1.2 us per launch against ~20 us of hand-overs per series): launches of at most this many views take part
+    static constexpr int MAX_VIEWS = 2;
     bool lane_busy[2] = {false, false};                // the lane holds work the stream has not been made to wait for yet
     unsigned main_epoch = 1, lane_epoch[2] = {0, 0};   // what of the stream's work a lane has already been made to wait for
     int next_lane = 0;

@@ -73,7 +73,7 @@ enum sl3d_flags {
      * by its own kernel when it is set (the behaviour up to 0.4; A/B measurements). */
     SL3D_FLAG_EAGER_MASK = 32u,
     /* A context that created its own stream (config.stream == NULL) and has no KEEP_STAGES puts the sl3d_run / sl3d_run_clouds launches
-     * of a LONG series of launches of at most 4 views (8 in a row, or fewer if the previous series was that long) on two internal
+     * of a LONG series of launches of at most 2 views (8 in a row, or fewer if the previous series was that long) on two internal
      * streams in turn, so that the tail of one launch runs under the ramp of the next when they work on different views (a launch over
      * a view a lane still works on goes behind it); every other call first makes the context's stream wait for both, so nothing a
      * caller can observe changes -- only the time: one view per launch from HBM, back to back, 25.8 -> 21.8 us per launch.  With this
